@@ -1,0 +1,175 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark: audio samples/s (+ RTF) for 128-phoneme zero-shot synthesis @22.05 kHz.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" = one pass of the whole hot path (phoneme encoder + variance adaptor + length regulator + mel
+decoder + HiFi-GAN) over one batch of 32 synthetic 128-phoneme utterances per GPU (BASELINE.json
+configs[1]; weak scaling: configs[2] is 8 such shards), forced durations = 7 -> 896 frames -> 229 376
+samples (10.40 s) per utterance, tts_medium_styledec dims + HiFi-GAN V1, seeded synthetic weights.
+For N>1 every step ends with the one collective of the path: the RCCL waveform gather to rank 0.
+Timing: W untimed steps, then exactly K steps bracketed by barrier + device synchronize; MAX over ranks.
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
+MFMA_PEAK = {"bf16": 2500.0, "f32": 157.3}   # dense TFLOP/s (MI355X_MICROARCH.md)
+
+
+def cpu_baseline(cfg, sd, hcfg, hsd, T, pad_to):
+    """The NumPy oracle (a port of the reference's PyTorch CPU path) on ONE utterance of the workload, timed on
+    this box's host cores.  Bounded sample: ~10-30 s of CPU work."""
+    from oracle import zvx_oracle as O            # checker / baseline only -- never on the product path
+    from zerovox_amd import synthetic
+    try:
+        from threadpoolctl import threadpool_info
+        cores = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+    except Exception:
+        cores = os.cpu_count() or 1
+    ph, pu, spk, dur = synthetic.utterance(T, 0, "const7")
+    O.hifigan_generator(np.zeros((80, 8), np.float32), hsd, hcfg)      # BLAS thread-pool warm-up
+    t0 = time.time()
+    out = O.inference_ex(sd, hsd, cfg, hcfg, ph, pu, spk, duration=dur, pad_to=pad_to)
+    dt = time.time() - t0
+    return {"value": len(out["wav"]) / dt, "unit": "samples/s", "cores": int(cores), "kind": "port",
+            "sample": f"1 utterance of the workload ({T} phonemes -> {out['mel_len']} frames -> {len(out['wav'])} "
+                      f"samples) through oracle/zvx_oracle.py (NumPy/BLAS fp32) in {dt:.1f} s",
+            "rtf_ref": (len(out["wav"]) / cfg["audio"]["sampling_rate"]) / dt}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32, help="utterances per GPU")
+    ap.add_argument("--phonemes", type=int, default=128)
+    ap.add_argument("--decoder", default="styletts", choices=["styletts", "fastspeech2"])
+    ap.add_argument("--vocoder", default="v1")
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile", type=int, default=2, help="0 none, 1 stage events, 2 + per-launch GEMM events")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+    import torch
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback on the product path)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from zerovox_amd import _lib, config as zcfg, pack, synthetic, weights as zw
+    from zerovox_amd.dist import gather_waveforms
+
+    cfg = zcfg.medium_modelcfg(args.decoder)
+    sd = zw.tts_state_dict(cfg, 0)
+    hcfg = zcfg.hifigan_config(args.vocoder)
+    hsd = zw.hifigan_state_dict(hcfg, 0)
+    manifest, blob = pack.pack_model(cfg, sd, hcfg, hsd, args.precision)
+    ctx = _lib.Context(manifest, blob, local_rank)
+
+    B, T = args.batch, args.phonemes
+    ph, pu, Tlen, spk, dur = synthetic.batch(B, T, first_utt=rank * B, dur_mode="const7")
+    L = int(dur[0].sum())
+    hop, sr = cfg["audio"]["hop_size"], cfg["audio"]["sampling_rate"]
+    N = L * hop
+    pad_to = np.full(B, max(689, L), np.int32)          # fresh-model semantics of model.py:331-335
+    wav = torch.zeros((B, N), dtype=torch.float32, device=f"cuda:{local_rank}")
+    lens_t = torch.full((B,), L, dtype=torch.int32, device=f"cuda:{local_rank}")
+
+    def step():
+        out = ctx.synthesize(ph, pu, Tlen, spk, dur, pad_to, want_mel=False, wav_device_ptr=wav.data_ptr(), wav_stride=N)
+        if world > 1:
+            gather_waveforms(wav, lens_t, dst=0)
+        return out
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        ctx.sync()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    ctx.set_int("profile", args.profile)
+    ctx.reset_stats()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    stage_ms = ctx.stage_times()
+    kstats = ctx.kernel_stats()
+    ctx.set_int("profile", 0)
+
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # sanity on the produced audio (not timed)
+    w = wav[0].cpu().numpy()
+    finite = bool(np.isfinite(w).all()) and float(np.abs(w).max()) <= 1.0 and float(np.abs(w).max()) > 0
+
+    if rank == 0:
+        total_samples = float(world) * B * N * args.steps
+        value = total_samples / elapsed
+        audio_s = total_samples / sr
+        res = {
+            "metric": "audio samples/sec + RTF, 128-phoneme zero-shot synth @22.05kHz, 1/2/4/8 GPU",
+            "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+            "config": {"workload": f"batch={B}/GPU x {T}-phoneme utterances, precomputed spk-embed, forced durations=7 "
+                                   f"-> {L} frames -> {N} samples each; tts_medium_{'styledec' if args.decoder == 'styletts' else 'fs2'} "
+                                   f"+ HiFi-GAN {args.vocoder.upper()}, end-to-end phoneme->waveform"
+                                   + (", RCCL waveform gather to rank 0 each step" if world > 1 else ""),
+                       "global_batch": B * world, "phonemes": T, "frames": L, "samples_per_utt": N,
+                       "decoder": args.decoder, "vocoder": args.vocoder, "pad_to": int(pad_to[0])},
+            "rtf_ref_audio_s_per_s": audio_s / elapsed, "rtf_s_per_audio_s": elapsed / audio_s,
+            "stage_ms_last_step": stage_ms, "output_ok": finite,
+        }
+        if kstats:
+            dom = max(kstats, key=lambda k: k["ms"])
+            avg_ms = dom["ms"] / dom["launches"]
+            achieved = dom["flops"] / dom["launches"] / (avg_ms * 1e-3) / 1e12
+            peak = MFMA_PEAK[args.precision]
+            res["roofline"] = {"bound": "mfma", "kernel": dom["name"], "achieved": achieved, "peak": peak,
+                               "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None,
+                               "launches": dom["launches"], "avg_launch_ms": avg_ms,
+                               "flops_per_launch": dom["flops"] / dom["launches"],
+                               "alg_bytes_per_launch": dom["bytes"] / dom["launches"],
+                               "alg_GBps": dom["bytes"] / (dom["ms"] * 1e-3) / 1e9}
+            res["kernels"] = [{"name": k["name"], "launches": k["launches"], "ms": round(k["ms"], 3),
+                               "TFLOPs": round(k["flops"] / (k["ms"] * 1e-3) / 1e12, 2) if k["ms"] > 0 else None}
+                              for k in sorted(kstats, key=lambda k: -k["ms"])]
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(cfg, sd, hcfg, hsd, T, int(pad_to[0]))
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

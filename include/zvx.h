@@ -1,0 +1,126 @@
+/*
+ * zvx.h -- C-ABI of libzvx, the MI355X-native ZeroVOX synthesis path.
+ *
+ * The reference (gooofy/zerovox) has no FFI/plugin interface: its seam is the Python object API
+ * (SURVEY.md 8b).  Each entry point below names the reference call it replaces.  A maintainer binds
+ * them with ctypes; no torch types appear in any signature.
+ *
+ * Conventions
+ *   - every function returns a zvx_status (0 = ok); zvx_last_error() returns the message of the last
+ *     failure on that context (or of zvx_create when ctx is NULL);
+ *   - one context per device, NOT thread-safe (like the reference object), no globals;
+ *   - buffers are caller-allocated.  Host pointers by default; outputs flagged ZVX_DEVICE_OUT are
+ *     device pointers on the context's device (used for the RCCL waveform gather);
+ *   - batches are padded row-major: [B][Tmax] ids, [B][Lmax][80] mels, wav rows of `wav_stride` floats;
+ *     every utterance is computed exactly as an independent batch-1 reference call
+ *     (model.py:325-328 is batch-1 only), i.e. no statistic ever sees padding;
+ *   - activations are time-major / channel-contiguous on the device ([time][channel]).
+ */
+#ifndef ZVX_H
+#define ZVX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct zvx_ctx zvx_ctx;
+typedef int zvx_status;
+
+enum {
+    ZVX_OK = 0,
+    ZVX_E_INVALID = 1,   /* bad argument / id out of range (reference: torch IndexError, assert) */
+    ZVX_E_MANIFEST = 2,  /* manifest or weight blob malformed, tensor missing, unknown decoder kind (model.py:244) */
+    ZVX_E_HIP = 3,       /* HIP runtime failure (message carries hipGetErrorString) */
+    ZVX_E_STATE = 4,     /* call order violated (e.g. zvx_decode before zvx_encode) */
+    ZVX_E_BUFFER = 5,    /* caller buffer too small for the produced length */
+    ZVX_E_UNSUPPORTED = 6
+};
+
+enum {                   /* flags */
+    ZVX_DEVICE_OUT = 1,  /* wav (and mel, if given) output pointers are device pointers */
+    ZVX_NO_SYNC = 2      /* do not hipStreamSynchronize before returning (device outputs only) */
+};
+
+enum {                   /* zvx_stage_times indices (milliseconds, hipEvent-timed on the ctx stream) */
+    ZVX_T_ENCODER = 0, ZVX_T_VARIANCE = 1, ZVX_T_LENREG = 2, ZVX_T_DECODER = 3, ZVX_T_VOCODER = 4,
+    ZVX_T_SPKEMB = 5, ZVX_T_COUNT = 8
+};
+
+/* Build a synthesis context on HIP device `device` from a text manifest + fp32 weight blob produced
+ * by zerovox_amd.pack (weight-norm folded, conv weights laid out [tap][Cout][Cin]).
+ * Replaces ZeroVoxTTS.__init__ / ZeroVox.load_from_checkpoint + get_meldec
+ * (synthesize.py:48-97, model.py:86-118, model.py:206-249). */
+zvx_status zvx_create(const char* manifest, const void* weights, size_t nbytes, int device, zvx_ctx** out);
+void       zvx_destroy(zvx_ctx* ctx);
+const char* zvx_last_error(const zvx_ctx* ctx);
+/* "precision" -> 0 bf16 / 1 f32; "hidden", "n_mels", "hop", "device" ... ; -1 if unknown */
+int64_t    zvx_get_int(const zvx_ctx* ctx, const char* key);
+/* "profile" 0/1/2 (0 off, 1 per-stage events, 2 + per-GEMM-launch events) */
+zvx_status zvx_set_int(zvx_ctx* ctx, const char* key, int64_t value);
+
+/* Speaker encoder: ref_mels [B][Tmax][80] log-mels, lens[B] frames -> out [B][hidden], L2-normalised.
+ * Replaces ResNetSE34V2.forward (ResNetSE34V2.py:176-212) as called by ZeroVoxTTS.speaker_embed
+ * (synthesize.py:139-141). */
+zvx_status zvx_spkemb(zvx_ctx* ctx, const float* ref_mels, const int32_t* lens, int B, int Tmax, float* out);
+
+/* Phoneme encoder + variance adaptor + length regulator.  duration == NULL -> predicted durations
+ * (fs2.py:678-681), else forced (force_duration=True, fs2.py:745).  Writes mel_len[B]; optional
+ * log_duration / pitch / energy [B][Tmax].  The expanded features stay in the context.
+ * Replaces FS2Encoder.forward (fs2.py:732-775). */
+zvx_status zvx_encode(zvx_ctx* ctx, const int32_t* phoneme, const int32_t* puncts, const int32_t* duration,
+                      const int32_t* T, int B, int Tmax, const float* spk,
+                      int32_t* mel_len, float* log_duration, float* pitch, float* energy);
+
+/* Mel decoder on the context's features; mel_out [B][Lstride][n_mels] may be NULL.
+ * Replaces FS2Decoder.forward (fs2.py:281-315) / StyleTTSDecoder.forward (styletts.py:181-205). */
+zvx_status zvx_decode(zvx_ctx* ctx, float* mel_out, int Lstride, int flags);
+
+/* Same on caller-supplied features [B][Lmax][hidden] (L[B] valid frames, spk [B][hidden]). */
+zvx_status zvx_decode_features(zvx_ctx* ctx, const float* features, const int32_t* L, int B, int Lmax,
+                               const float* spk, float* mel_out, int Lstride);
+
+/* HiFi-GAN on the context's mel.  pad_to[B]: utterance b is vocoded on max(pad_to[b], mel_len[b]) frames,
+ * rows >= mel_len zero (the reference's stateful `_min_mel_len`, model.py:331-335; NULL = no padding);
+ * wav row b receives mel_len[b]*hop samples (model.py:347), wav_stride floats between rows.
+ * Replaces hifigan.Generator.forward (hifigan.py:114-130). */
+zvx_status zvx_vocode(zvx_ctx* ctx, const int32_t* pad_to, float* wav, int64_t wav_stride, int flags);
+
+/* Stand-alone vocoder: mel [B][Pmax][n_mels], P[B] frames -> wav rows of P[b]*hop samples. */
+zvx_status zvx_vocode_mel(zvx_ctx* ctx, const float* mel, const int32_t* P, int B, int Pmax,
+                          float* wav, int64_t wav_stride, int flags);
+
+/* encode + decode + vocode.  mel_out / log_duration may be NULL.  With predicted durations the caller
+ * sizes wav for Lmax_cap frames per utterance; ZVX_E_BUFFER if a prediction exceeds it.
+ * Replaces ZeroVox.inference_ex (model.py:308-347) over B independent utterances. */
+zvx_status zvx_synthesize(zvx_ctx* ctx, const int32_t* phoneme, const int32_t* puncts, const int32_t* duration,
+                          const int32_t* T, int B, int Tmax, const float* spk, const int32_t* pad_to,
+                          int Lmax_cap, float* wav, int64_t wav_stride, int32_t* mel_len,
+                          float* mel_out, int Lstride, float* log_duration, int flags);
+
+/* Debug/parity taps: copy an intermediate of the last call to host fp32.
+ * what: "encoder_out" [B][Tmax][hidden] (after the style add), "features" [B][Lmax][hidden],
+ *       "mel" [B][Lmax][n_mels], "pitch_idx"/"energy_idx"/"duration" [B][Tmax] (as float). */
+zvx_status zvx_fetch(zvx_ctx* ctx, const char* what, float* out, size_t out_floats);
+
+zvx_status zvx_sync(zvx_ctx* ctx);
+zvx_status zvx_stage_times(zvx_ctx* ctx, float ms[ZVX_T_COUNT]);
+
+/* Per-kernel-variant counters accumulated while "profile" == 2: launches, summed milliseconds,
+ * algorithmic FLOPs and algorithmic bytes.  Returns the number of variants; name buffers are 64 bytes. */
+typedef struct {
+    char   name[64];
+    int64_t launches;
+    double ms;
+    double flops;
+    double bytes;
+} zvx_kernel_stat;
+int        zvx_kernel_stats(zvx_ctx* ctx, zvx_kernel_stat* out, int max_out);
+zvx_status zvx_reset_stats(zvx_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ZVX_H */

@@ -1,0 +1,234 @@
+"""ctypes binding of libzvx (include/zvx.h).  No fallback: if the HIP library or a GPU is missing,
+every entry point raises -- the product path never routes through a CPU implementation."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libzvx.so")
+
+ZVX_OK = 0
+ZVX_E_INVALID, ZVX_E_MANIFEST, ZVX_E_HIP, ZVX_E_STATE, ZVX_E_BUFFER, ZVX_E_UNSUPPORTED = 1, 2, 3, 4, 5, 6
+ZVX_DEVICE_OUT, ZVX_NO_SYNC = 1, 2
+STAGES = ("encoder", "variance", "lenreg", "decoder", "vocoder", "spkemb")
+ZVX_T_COUNT = 8
+
+EXPORTS = ("zvx_create", "zvx_destroy", "zvx_last_error", "zvx_get_int", "zvx_set_int", "zvx_spkemb", "zvx_encode",
+           "zvx_decode", "zvx_decode_features", "zvx_vocode", "zvx_vocode_mel", "zvx_synthesize", "zvx_fetch",
+           "zvx_sync", "zvx_stage_times", "zvx_kernel_stats", "zvx_reset_stats")
+
+
+class ZvxError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"zvx error {code}: {msg}")
+        self.code = code
+
+
+class KernelStat(C.Structure):
+    _fields_ = [("name", C.c_char * 64), ("launches", C.c_int64), ("ms", C.c_double), ("flops", C.c_double),
+                ("bytes", C.c_double)]
+
+
+_lib = None
+
+
+def load():
+    """dlopen libzvx.so (built in-tree by zerovox_amd.build).  Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ZvxError(ZVX_E_HIP, f"{LIB_PATH} not found: build it with `python -m zerovox_amd.build` "
+                                  f"(there is no CPU fallback)")
+    lib = C.CDLL(LIB_PATH)
+    vp, i32p, f32p = C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_float)
+    lib.zvx_create.argtypes = [C.c_char_p, vp, C.c_size_t, C.c_int, C.POINTER(vp)]
+    lib.zvx_destroy.argtypes = [vp]
+    lib.zvx_destroy.restype = None
+    lib.zvx_last_error.argtypes = [vp]
+    lib.zvx_last_error.restype = C.c_char_p
+    lib.zvx_get_int.argtypes = [vp, C.c_char_p]
+    lib.zvx_get_int.restype = C.c_int64
+    lib.zvx_set_int.argtypes = [vp, C.c_char_p, C.c_int64]
+    lib.zvx_spkemb.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp]
+    lib.zvx_encode.argtypes = [vp, vp, vp, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp, vp]
+    lib.zvx_decode.argtypes = [vp, vp, C.c_int, C.c_int]
+    lib.zvx_decode_features.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp, vp, C.c_int]
+    lib.zvx_vocode.argtypes = [vp, vp, vp, C.c_int64, C.c_int]
+    lib.zvx_vocode_mel.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp, C.c_int64, C.c_int]
+    lib.zvx_synthesize.argtypes = [vp, vp, vp, vp, vp, C.c_int, C.c_int, vp, vp, C.c_int, vp, C.c_int64, vp, vp,
+                                   C.c_int, vp, C.c_int]
+    lib.zvx_fetch.argtypes = [vp, C.c_char_p, vp, C.c_size_t]
+    lib.zvx_sync.argtypes = [vp]
+    lib.zvx_stage_times.argtypes = [vp, vp]
+    lib.zvx_kernel_stats.argtypes = [vp, C.POINTER(KernelStat), C.c_int]
+    lib.zvx_reset_stats.argtypes = [vp]
+    _lib = lib
+    return lib
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _i32(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.int32)
+    if shape is not None:
+        assert a.shape == tuple(shape), (a.shape, shape)
+    return a
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+class Context:
+    """One synthesis context on one HIP device (wraps zvx_ctx*)."""
+
+    def __init__(self, manifest: str, blob: np.ndarray, device: int = 0):
+        self._lib = load()
+        self._h = C.c_void_p()
+        blob = _f32(blob)
+        rc = self._lib.zvx_create(manifest.encode(), _ptr(blob), blob.nbytes, device, C.byref(self._h))
+        if rc != ZVX_OK:
+            raise ZvxError(rc, self._lib.zvx_last_error(None).decode())
+        self.hidden = self.get_int("hidden")
+        self.n_mels = self.get_int("n_mels")
+        self.hop = self.get_int("hop")
+        self.device = device
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.zvx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != ZVX_OK:
+            raise ZvxError(rc, self._lib.zvx_last_error(self._h).decode())
+
+    def get_int(self, key):
+        return int(self._lib.zvx_get_int(self._h, key.encode()))
+
+    def set_int(self, key, value):
+        self._chk(self._lib.zvx_set_int(self._h, key.encode(), int(value)))
+
+    # ---- stages -------------------------------------------------------------------------------
+    def spkemb(self, ref_mels, lens):
+        ref_mels = _f32(ref_mels)
+        B, Tmax, F = ref_mels.shape
+        assert F == self.n_mels
+        lens = _i32(lens, (B,))
+        out = np.empty((B, self.hidden), np.float32)
+        self._chk(self._lib.zvx_spkemb(self._h, _ptr(ref_mels), _ptr(lens), B, Tmax, _ptr(out)))
+        return out
+
+    def encode(self, phoneme, puncts, T, spk, duration=None):
+        phoneme = _i32(phoneme)
+        B, Tmax = phoneme.shape
+        puncts = _i32(puncts, (B, Tmax))
+        T = _i32(T, (B,))
+        spk = _f32(spk).reshape(B, self.hidden)
+        dur = _i32(duration, (B, Tmax)) if duration is not None else None
+        mel_len = np.zeros(B, np.int32)
+        logd = np.zeros((B, Tmax), np.float32)
+        pitch = np.zeros((B, Tmax), np.float32)
+        energy = np.zeros((B, Tmax), np.float32)
+        self._chk(self._lib.zvx_encode(self._h, _ptr(phoneme), _ptr(puncts), _ptr(dur), _ptr(T), B, Tmax, _ptr(spk),
+                                       _ptr(mel_len), _ptr(logd), _ptr(pitch), _ptr(energy)))
+        return mel_len, logd, pitch, energy
+
+    def decode(self, B, Lmax):
+        mel = np.zeros((B, max(Lmax, 1), self.n_mels), np.float32)
+        self._chk(self._lib.zvx_decode(self._h, _ptr(mel), max(Lmax, 1), 0))
+        return mel
+
+    def decode_features(self, features, L, spk):
+        features = _f32(features)
+        B, Lmax, H = features.shape
+        assert H == self.hidden
+        L = _i32(L, (B,))
+        spk = _f32(spk).reshape(B, H)
+        mel = np.zeros((B, Lmax, self.n_mels), np.float32)
+        self._chk(self._lib.zvx_decode_features(self._h, _ptr(features), _ptr(L), B, Lmax, _ptr(spk), _ptr(mel), Lmax))
+        return mel
+
+    def vocode(self, B, mel_len, pad_to=None):
+        n = max(int(np.max(mel_len)) * self.hop, 1)
+        wav = np.zeros((B, n), np.float32)
+        pt = _i32(pad_to, (B,)) if pad_to is not None else None
+        self._chk(self._lib.zvx_vocode(self._h, _ptr(pt), _ptr(wav), n, 0))
+        return wav
+
+    def vocode_mel(self, mel, P):
+        mel = _f32(mel)
+        B, Pmax, nm = mel.shape
+        assert nm == self.n_mels
+        P = _i32(P, (B,))
+        n = Pmax * self.hop
+        wav = np.zeros((B, n), np.float32)
+        self._chk(self._lib.zvx_vocode_mel(self._h, _ptr(mel), _ptr(P), B, Pmax, _ptr(wav), n, 0))
+        return wav
+
+    def synthesize(self, phoneme, puncts, T, spk, duration=None, pad_to=None, want_mel=True, Lmax_cap=0,
+                   wav_device_ptr=None, wav_stride=None, no_sync=False):
+        """Batched phoneme -> waveform.  Returns dict(wav [B][N] (None if device output), mel_len, mel, log_duration)."""
+        phoneme = _i32(phoneme)
+        B, Tmax = phoneme.shape
+        puncts = _i32(puncts, (B, Tmax))
+        T = _i32(T, (B,))
+        spk = _f32(spk).reshape(B, self.hidden)
+        dur = _i32(duration, (B, Tmax)) if duration is not None else None
+        pt = _i32(pad_to, (B,)) if pad_to is not None else None
+        if dur is not None:
+            Lmax = int(max(np.maximum(dur[b, :T[b]], 0).sum() for b in range(B)))
+        else:
+            Lmax = int(Lmax_cap)
+            if Lmax <= 0:
+                raise ZvxError(ZVX_E_INVALID, "predicted durations need Lmax_cap (or use encode/decode/vocode)")
+        mel_len = np.zeros(B, np.int32)
+        logd = np.zeros((B, Tmax), np.float32)
+        mel = np.zeros((B, max(Lmax, 1), self.n_mels), np.float32) if want_mel else None
+        flags = 0
+        if wav_device_ptr is not None:
+            wav, wptr, stride = None, C.c_void_p(int(wav_device_ptr)), int(wav_stride)
+            flags |= ZVX_DEVICE_OUT | (ZVX_NO_SYNC if no_sync else 0)
+        else:
+            stride = max(Lmax * self.hop, 1)
+            wav = np.zeros((B, stride), np.float32)
+            wptr = _ptr(wav)
+        self._chk(self._lib.zvx_synthesize(self._h, _ptr(phoneme), _ptr(puncts), _ptr(dur), _ptr(T), B, Tmax, _ptr(spk),
+                                           _ptr(pt), Lmax, wptr, stride, _ptr(mel_len), _ptr(mel), max(Lmax, 1),
+                                           _ptr(logd), flags))
+        return dict(wav=wav, mel_len=mel_len, mel=mel, log_duration=logd)
+
+    # ---- introspection ------------------------------------------------------------------------
+    def fetch(self, what, shape):
+        out = np.zeros(shape, np.float32)
+        self._chk(self._lib.zvx_fetch(self._h, what.encode(), _ptr(out), out.size))
+        return out
+
+    def sync(self):
+        self._chk(self._lib.zvx_sync(self._h))
+
+    def stage_times(self):
+        ms = np.zeros(ZVX_T_COUNT, np.float32)
+        self._chk(self._lib.zvx_stage_times(self._h, _ptr(ms)))
+        return {n: float(ms[i]) for i, n in enumerate(STAGES)}
+
+    def kernel_stats(self):
+        arr = (KernelStat * 32)()
+        n = self._lib.zvx_kernel_stats(self._h, arr, 32)
+        return [dict(name=arr[i].name.decode(), launches=int(arr[i].launches), ms=float(arr[i].ms),
+                     flops=float(arr[i].flops), bytes=float(arr[i].bytes)) for i in range(n)]
+
+    def reset_stats(self):
+        self._chk(self._lib.zvx_reset_stats(self._h))

@@ -1,0 +1,445 @@
+// ops.hip -- the HBM-bound kernels of the synthesis path (norms, softmax, gathers, pooling, conv_post).
+// All tensors are time-major [row][channel]; 64-lane waves; one wave per row for row reductions,
+// channel-contiguous vector loads elsewhere.
+#include "zvx_kernels.h"
+
+namespace zvx {
+
+__device__ __forceinline__ float ld(const void* p, int dt, long i) {
+    return dt == DT_F32 ? ((const float*)p)[i] : __uint_as_float(((unsigned)((const unsigned short*)p)[i]) << 16);
+}
+__device__ __forceinline__ unsigned short tobf(float f) {
+    unsigned u = __float_as_uint(f);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+__device__ __forceinline__ void st(void* p, int dt, long i, float v) {
+    if (dt == DT_F32) ((float*)p)[i] = v; else ((unsigned short*)p)[i] = tobf(v);
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ float act_apply(float v, int act, float slope) {
+    if (act == ACT_RELU) return fmaxf(v, 0.f);
+    if (act == ACT_LRELU) return v >= 0.f ? v : v * slope;
+    if (act == ACT_TANH) return tanhf(v);
+    return v;
+}
+
+// ---------------------------------------------------------------- casts
+__global__ void k_cast(const void* in, int idt, void* out, int odt, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) st(out, odt, i, ld(in, idt, i));
+}
+void launch_cast(const void* in, int in_dt, void* out, int out_dt, size_t n, hipStream_t s) {
+    if (!n) return;
+    int blocks = (int)((n + 255) / 256); if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_cast, dim3(blocks), dim3(256), 0, s, in, in_dt, out, out_dt, n);
+}
+void launch_f32_to_bf16(const float* in, bf16_t* out, size_t n, hipStream_t s) { launch_cast(in, DT_F32, out, DT_BF16, n, s); }
+
+// ---------------------------------------------------------------- embedding + positional encoding
+__global__ void k_embed(const int* ph, const int* pu, const float* emb, int ed, const float* pemb, int pd,
+                        const float* pe, float* out, int Tmax, const int* T) {
+    const int b = blockIdx.y, t = blockIdx.x;
+    if (t >= T[b]) return;
+    const int H = ed + pd;
+    const int p = ph[b * Tmax + t], q = pu[b * Tmax + t];
+    float* o = out + ((long)b * Tmax + t) * H;
+    for (int c = threadIdx.x; c < H; c += blockDim.x) {
+        float v = c < ed ? emb[(long)p * ed + c] : pemb[(long)q * pd + (c - ed)];
+        o[c] = v + pe[(long)t * H + c];
+    }
+}
+void launch_embed(const int* phoneme, const int* puncts, const float* emb, int emb_dim, const float* pemb,
+                  int pemb_dim, const float* pe, float* out, int B, int Tmax, const int* T, hipStream_t s) {
+    hipLaunchKernelGGL(k_embed, dim3(Tmax, B), dim3(128), 0, s, phoneme, puncts, emb, emb_dim, pemb, pemb_dim, pe, out, Tmax, T);
+}
+
+// ---------------------------------------------------------------- LayerNorm / SCLN, one wave per row
+__global__ void k_layernorm(const void* x, int xdt, int ldx, void* y, int ydt, int ldy, int rows_max, const int* rows,
+                            int C, int mode, float eps, const float* gamma, const float* beta, const float* bg,
+                            long bg_bs, const float* post_add) {
+    const int b = blockIdx.y;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int nr = rows ? rows[b] : rows_max;
+    if (r >= nr) return;
+    const long xo = ((long)b * rows_max + r) * ldx, yo = ((long)b * rows_max + r) * ldy;
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s += ld(x, xdt, xo + c);
+    const float mu = wave_sum(s) / C;
+    float q = 0.f;
+    for (int c = lane; c < C; c += 64) { float d = ld(x, xdt, xo + c) - mu; q += d * d; }
+    q = wave_sum(q);
+    float inv;
+    if (mode == 0) inv = 1.0f / sqrtf(q / C + eps);            // torch LayerNorm: biased var, eps inside sqrt
+    else inv = 1.0f / (sqrtf(q / (C - 1)) + eps);              // SCLN: unbiased std, (sigma + eps)  fs2.py:79-81
+    for (int c = lane; c < C; c += 64) {
+        float g, be;
+        if (mode == 0) { g = gamma[c]; be = beta[c]; }
+        else { be = bg[(long)b * bg_bs + c]; g = bg[(long)b * bg_bs + C + c]; }   // b = first half (fs2.py:85)
+        float v = (ld(x, xdt, xo + c) - mu) * inv * g + be;
+        if (post_add) v += post_add[(long)b * C + c];
+        st(y, ydt, yo + c, v);
+    }
+}
+void launch_layernorm(const void* x, int x_dt, int ldx, void* y, int y_dt, int ldy, int B, int rows_max,
+                      const int* rows, int C, int mode, float eps, const float* gamma, const float* beta,
+                      const float* bg, long bg_bs, const float* post_add, hipStream_t s) {
+    hipLaunchKernelGGL(k_layernorm, dim3((rows_max + 3) / 4, B), dim3(256), 0, s, x, x_dt, ldx, y, y_dt, ldy, rows_max,
+                       rows, C, mode, eps, gamma, beta, bg, bg_bs, post_add);
+}
+
+// ---------------------------------------------------------------- row softmax with key-length mask
+__global__ void k_softmax_rows(const float* sc, int lds, void* P, int pdt, int ldp, int nheads, int Lmax, const int* len) {
+    const int z = blockIdx.y, b = z / nheads;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int L = len[b];
+    if (r >= L) return;
+    const float* row = sc + ((long)z * Lmax + r) * lds;
+    const long po = ((long)z * Lmax + r) * ldp;
+    float m = -INFINITY;
+    for (int c = lane; c < L; c += 64) m = fmaxf(m, row[c]);
+    m = wave_max(m);
+    float s = 0.f;
+    for (int c = lane; c < L; c += 64) s += expf(row[c] - m);
+    s = wave_sum(s);
+    const float inv = 1.0f / s;
+    const int Lp = (L + 7) & ~7;
+    for (int c = lane; c < Lp; c += 64) st(P, pdt, po + c, c < L ? expf(row[c] - m) * inv : 0.f);
+}
+void launch_softmax_rows(const float* scores, int lds, void* P, int p_dt, int ldp, int nbatch, int nheads,
+                         int Lmax, const int* len, hipStream_t s) {
+    hipLaunchKernelGGL(k_softmax_rows, dim3((Lmax + 3) / 4, nbatch * nheads), dim3(256), 0, s, scores, lds, P, p_dt, ldp, nheads, Lmax, len);
+}
+
+// ---------------------------------------------------------------- row dot (variance predictor head)
+__global__ void k_rowdot(const float* x, int ldx, const float* w, float bias, float* out, int Tmax, const int* T, int C) {
+    const int b = blockIdx.y, t = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (t >= T[b]) return;
+    const float* row = x + ((long)b * Tmax + t) * ldx;
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s += row[c] * w[c];
+    s = wave_sum(s);
+    if (lane == 0) out[b * Tmax + t] = s + bias;
+}
+void launch_rowdot(const float* x, int ldx, const float* w, float bias, float* out, int B, int Tmax,
+                   const int* T, int C, hipStream_t s) {
+    hipLaunchKernelGGL(k_rowdot, dim3((Tmax + 3) / 4, B), dim3(256), 0, s, x, ldx, w, bias, out, Tmax, T, C);
+}
+
+// ---------------------------------------------------------------- bucketise + embedding add
+__global__ void k_bucket_embed_add(const float* pred, const float* table, int nb, float* x, int ldx, int C, int* idx_out,
+                                   int Tmax, const int* T) {
+    const int b = blockIdx.y, t = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (t >= T[b]) return;
+    float p = rintf(pred[b * Tmax + t] * (float)(nb - 1));        // torch.round: half-to-even
+    p = fminf(fmaxf(p, 0.f), (float)(nb - 1));
+    const int idx = (int)p;
+    if (lane == 0 && idx_out) idx_out[b * Tmax + t] = idx;
+    float* row = x + ((long)b * Tmax + t) * ldx;
+    for (int c = lane; c < C; c += 64) row[c] += table[(long)idx * C + c];
+}
+void launch_bucket_embed_add(const float* pred, const float* table, int nbins, float* x, int ldx, int C,
+                             int* idx_out, int B, int Tmax, const int* T, hipStream_t s) {
+    hipLaunchKernelGGL(k_bucket_embed_add, dim3((Tmax + 3) / 4, B), dim3(256), 0, s, pred, table, nbins, x, ldx, C, idx_out, Tmax, T);
+}
+
+// ---------------------------------------------------------------- durations + inclusive scan (one wave / utterance)
+__global__ void k_durations(const int* forced, const float* logd, int* dur, int* cum, int* mel_len, int Tmax, const int* T) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const int n = T[b];
+    int carry = 0;
+    for (int t0 = 0; t0 < n; t0 += 64) {
+        const int t = t0 + lane;
+        int d = 0;
+        if (t < n) {
+            if (forced) d = max(forced[b * Tmax + t], 0);                                  // fs2.py:452 max(int(d),0)
+            else d = (int)fmaxf(rintf(expf(logd[b * Tmax + t]) - 1.0f), 0.f);               // fs2.py:678-681
+            dur[b * Tmax + t] = d;
+        }
+        int v = d;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { int u = __shfl_up(v, o, 64); if (lane >= o) v += u; }
+        if (t < n) cum[b * Tmax + t] = carry + v;
+        carry += __shfl(v, 63, 64);
+    }
+    if (lane == 0) mel_len[b] = carry;
+}
+void launch_durations(const int* forced, const float* logd, int* dur, int* cum, int* mel_len, int B, int Tmax,
+                      const int* T, hipStream_t s) {
+    hipLaunchKernelGGL(k_durations, dim3(B), dim3(64), 0, s, forced, logd, dur, cum, mel_len, Tmax, T);
+}
+
+// ---------------------------------------------------------------- length regulator: scan-indexed coalesced row gather
+__global__ void k_length_regulate(const float* x, int ldx, const int* cum, const int* T, const int* mel_len, float* feats,
+                                  int Tmax, int Lmax, int C) {
+    const int b = blockIdx.y, l = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (l >= mel_len[b]) return;
+    const int* cb = cum + b * Tmax;
+    int lo = 0, hi = T[b] - 1;                 // first t with cum[t] > l
+    while (lo < hi) { int mid = (lo + hi) >> 1; if (cb[mid] > l) hi = mid; else lo = mid + 1; }
+    const float4* src = (const float4*)(x + ((long)b * Tmax + lo) * ldx);
+    float4* dst = (float4*)(feats + ((long)b * Lmax + l) * C);
+    for (int c = lane; c < C / 4; c += 64) dst[c] = src[c];
+}
+void launch_length_regulate(const float* x, int ldx, const int* cum, const int* T, const int* mel_len,
+                            float* feats, int B, int Tmax, int Lmax, int C, hipStream_t s) {
+    if (Lmax <= 0) return;
+    hipLaunchKernelGGL(k_length_regulate, dim3((Lmax + 3) / 4, B), dim3(256), 0, s, x, ldx, cum, T, mel_len, feats, Tmax, Lmax, C);
+}
+
+__global__ void k_add_pe_cast(const float* x, const float* pe, void* y, int ydt, int ldy, int Lmax, const int* L, int C) {
+    const int b = blockIdx.y, l = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (l >= L[b]) return;
+    const float* row = x + ((long)b * Lmax + l) * C;
+    const long yo = ((long)b * Lmax + l) * ldy;
+    for (int c = lane; c < C; c += 64) st(y, ydt, yo + c, row[c] + (pe ? pe[(long)l * C + c] : 0.f));
+}
+void launch_add_pe_cast(const float* x, const float* pe, void* y, int y_dt, int ldy, int B, int Lmax,
+                        const int* L, int C, hipStream_t s) {
+    if (Lmax <= 0) return;
+    hipLaunchKernelGGL(k_add_pe_cast, dim3((Lmax + 3) / 4, B), dim3(256), 0, s, x, pe, y, y_dt, ldy, Lmax, L, C);
+}
+
+// ---------------------------------------------------------------- per-(utterance, channel) statistics over valid rows
+// x [b][H*Wmax][ldx]; row r valid iff (r % Wmax) < W[b].  4 row-groups x 64 channels per block, two passes.
+__global__ void k_colstats(const void* x, int xdt, int ldx, int H, int Wmax, const int* W, int C, float eps, float* mean, float* rstd) {
+    __shared__ float red[4][64];
+    const int b = blockIdx.y, c = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
+    const int Wb = W[b];
+    const long base = (long)b * H * Wmax * ldx;
+    const bool cok = c < C;
+    float s = 0.f;
+    for (int hh = 0; hh < H; hh++)
+        for (int w = g; w < Wb; w += 4) if (cok) s += ld(x, xdt, base + ((long)hh * Wmax + w) * ldx + c);
+    red[g][threadIdx.x & 63] = s;
+    __syncthreads();
+    const float cnt = (float)H * (float)Wb;
+    const float mu = (red[0][threadIdx.x & 63] + red[1][threadIdx.x & 63] + red[2][threadIdx.x & 63] + red[3][threadIdx.x & 63]) / cnt;
+    __syncthreads();
+    float q = 0.f;
+    if (rstd) {
+        for (int hh = 0; hh < H; hh++)
+            for (int w = g; w < Wb; w += 4) if (cok) { float d = ld(x, xdt, base + ((long)hh * Wmax + w) * ldx + c) - mu; q += d * d; }
+        red[g][threadIdx.x & 63] = q;
+        __syncthreads();
+    }
+    if (g == 0 && cok) {
+        mean[(long)b * C + c] = mu;
+        if (rstd) {
+            const float var = (red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]) / cnt;
+            rstd[(long)b * C + c] = 1.0f / sqrtf(var + eps);          // InstanceNorm1d: biased var, eps 1e-5
+        }
+    }
+}
+void launch_instnorm_stats(const void* x, int x_dt, int ldx, int B, int Lmax, const int* L, int C, float eps,
+                           float* mean, float* rstd, hipStream_t s) {
+    hipLaunchKernelGGL(k_colstats, dim3((C + 63) / 64, B), dim3(256), 0, s, x, x_dt, ldx, 1, Lmax, L, C, eps, mean, rstd);
+}
+void launch_se_pool(const void* x, int x_dt, int B, int H, int Wmax, const int* W, int C, float* mean, hipStream_t s) {
+    hipLaunchKernelGGL(k_colstats, dim3((C + 63) / 64, B), dim3(256), 0, s, x, x_dt, C, H, Wmax, W, C, 0.f, mean, (float*)nullptr);
+}
+
+__global__ void k_norm_affine_act(const void* x, int xdt, int ldx, void* y, int ydt, int ldy, int Lmax, const int* L, int C,
+                                  const float* mean, const float* rstd, const float* gamma, const float* beta, long g_bs,
+                                  int one_plus, int act, float slope) {
+    const int b = blockIdx.y, l = blockIdx.x;
+    if (l >= L[b]) return;
+    const long xo = ((long)b * Lmax + l) * ldx, yo = ((long)b * Lmax + l) * ldy;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float v = (ld(x, xdt, xo + c) - mean[(long)b * C + c]) * rstd[(long)b * C + c];
+        if (gamma) v = v * ((one_plus ? 1.f : 0.f) + gamma[b * g_bs + c]) + beta[b * g_bs + c];
+        st(y, ydt, yo + c, act_apply(v, act, slope));
+    }
+}
+void launch_norm_affine_act(const void* x, int x_dt, int ldx, void* y, int y_dt, int ldy, int B, int Lmax,
+                            const int* L, int C, const float* mean, const float* rstd, const float* gamma,
+                            const float* beta, long g_bs, int one_plus, int act, float slope, hipStream_t s) {
+    if (Lmax <= 0) return;
+    hipLaunchKernelGGL(k_norm_affine_act, dim3(Lmax, B), dim3(256), 0, s, x, x_dt, ldx, y, y_dt, ldy, Lmax, L, C, mean, rstd,
+                       gamma, beta, g_bs, one_plus, act, slope);
+}
+
+// ---------------------------------------------------------------- mel -> zero-padded vocoder input
+__global__ void k_mel_pad(const void* mel, int mdt, int ldm, int Lmax, const int* mel_len, void* v, int vdt, int ldv, int Pmax,
+                          const int* P, int nm) {
+    const int b = blockIdx.y, p = blockIdx.x;
+    if (p >= P[b]) return;
+    const bool real = p < mel_len[b];
+    for (int c = threadIdx.x; c < nm; c += blockDim.x)
+        st(v, vdt, ((long)b * Pmax + p) * ldv + c, real ? ld(mel, mdt, ((long)b * Lmax + p) * ldm + c) : 0.f);
+}
+void launch_mel_pad(const void* mel, int m_dt, int ldm, int Lmax, const int* mel_len, void* v, int v_dt,
+                    int ldv, int Pmax, const int* P, int B, int nm, hipStream_t s) {
+    hipLaunchKernelGGL(k_mel_pad, dim3(Pmax, B), dim3(128), 0, s, mel, m_dt, ldm, Lmax, mel_len, v, v_dt, ldv, Pmax, P, nm);
+}
+
+__global__ void k_copy_rows_f32(const void* src, int sdt, int lds, long s_bs, float* dst, long ldd, long d_bs, int rows_max,
+                                const int* rows, int C) {
+    const int b = blockIdx.y, r = blockIdx.x;
+    if (r >= (rows ? rows[b] : rows_max)) return;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) dst[b * d_bs + r * ldd + c] = ld(src, sdt, b * s_bs + (long)r * lds + c);
+}
+void launch_copy_rows_f32(const void* src, int s_dt, int lds, long s_bs, float* dst, long ldd, long d_bs,
+                          int B, int rows_max, const int* rows, int C, hipStream_t s) {
+    if (rows_max <= 0) return;
+    hipLaunchKernelGGL(k_copy_rows_f32, dim3(rows_max, B), dim3(128), 0, s, src, s_dt, lds, s_bs, dst, ldd, d_bs, rows_max, rows, C);
+}
+
+// ---------------------------------------------------------------- conv_post (C -> 1) + tanh      hifigan.py:127-128
+// x is the activated last stage [b][Nmax][ldx]; one thread per output sample, weights broadcast from LDS.
+__global__ void k_conv_post_tanh(const void* x, int xdt, int ldx, long x_bs, const float* w, float bias, int kt, int C,
+                                 float* wav, long wav_bs, const int* in_len, int len_mul, const int* out_len, int out_mul) {
+    extern __shared__ float wl[];
+    for (int i = threadIdx.x; i < kt * C; i += blockDim.x) wl[i] = w[i];
+    __syncthreads();
+    const int b = blockIdx.y;
+    const long n = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long nin = (long)in_len[b] * len_mul, nout = (long)out_len[b] * out_mul;
+    if (n >= nout) return;
+    const int half = (kt - 1) / 2;
+    float acc = bias;
+    for (int k = 0; k < kt; k++) {
+        const long m = n + k - half;
+        if (m < 0 || m >= nin) continue;
+        const long o = b * x_bs + m * ldx;
+        if (xdt == DT_BF16) {
+            for (int c = 0; c < C; c += 8) {
+                const uint4 t = *(const uint4*)((const unsigned short*)x + o + c);
+                const float* ww = wl + k * C + c;
+                acc += __uint_as_float(t.x << 16) * ww[0] + __uint_as_float(t.x & 0xffff0000u) * ww[1]
+                     + __uint_as_float(t.y << 16) * ww[2] + __uint_as_float(t.y & 0xffff0000u) * ww[3]
+                     + __uint_as_float(t.z << 16) * ww[4] + __uint_as_float(t.z & 0xffff0000u) * ww[5]
+                     + __uint_as_float(t.w << 16) * ww[6] + __uint_as_float(t.w & 0xffff0000u) * ww[7];
+            }
+        } else {
+            for (int c = 0; c < C; c += 4) {
+                const float4 t = *(const float4*)((const float*)x + o + c);
+                const float* ww = wl + k * C + c;
+                acc += t.x * ww[0] + t.y * ww[1] + t.z * ww[2] + t.w * ww[3];
+            }
+        }
+    }
+    wav[b * wav_bs + n] = tanhf(acc);
+}
+void launch_conv_post_tanh(const void* x, int x_dt, int ldx, long x_bs, const float* w, float bias,
+                           int ktaps, int C, float* wav, long wav_bs, int B, int Nmax, const int* in_len,
+                           int len_mul, const int* out_len, int out_mul, hipStream_t s) {
+    if (Nmax <= 0) return;
+    hipLaunchKernelGGL(k_conv_post_tanh, dim3((Nmax + 255) / 256, B), dim3(256), ktaps * C * sizeof(float), s, x, x_dt, ldx, x_bs, w,
+                       bias, ktaps, C, wav, wav_bs, in_len, len_mul, out_len, out_mul);
+}
+
+// ---------------------------------------------------------------- speaker encoder pieces
+// first layer: InstanceNorm1d(F) over time folded in (mean/rstd given) + Conv2d(1->C0,3x3,p1) + ReLU + BN affine
+__global__ void k_spk_front(const float* mels, int Tmax, const int* lens, int F, const float* mean, const float* rstd,
+                            const float* w, const float* bias, const float* bs, const float* bt, int C0, void* out, int odt) {
+    const int b = blockIdx.z, f = blockIdx.y, t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int Tb = lens[b];
+    if (t >= Tb) return;
+    float xn[9];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            const int ff = f + i - 1, tt = t + j - 1;
+            float v = 0.f;
+            if (ff >= 0 && ff < F && tt >= 0 && tt < Tb)
+                v = (mels[((long)b * Tmax + tt) * F + ff] - mean[b * F + ff]) * rstd[b * F + ff];
+            xn[i * 3 + j] = v;
+        }
+    const long o = (((long)b * F + f) * Tmax + t) * C0;
+    for (int c = 0; c < C0; c++) {
+        float a = bias[c];
+#pragma unroll
+        for (int k = 0; k < 9; k++) a += xn[k] * w[k * C0 + c];
+        a = fmaxf(a, 0.f) * bs[c] + bt[c];                  // conv -> ReLU -> BN  (ResNetSE34V2.py:184-186)
+        st(out, odt, o + c, a);
+    }
+}
+void launch_spk_front(const float* mels, int Tmax, const int* lens, int F, const float* mean, const float* rstd,
+                      const float* w, const float* bias, const float* bn_scale, const float* bn_shift, int C0,
+                      void* out, int o_dt, int B, hipStream_t s) {
+    hipLaunchKernelGGL(k_spk_front, dim3((Tmax + 63) / 64, F, B), dim3(64), 0, s, mels, Tmax, lens, F, mean, rstd, w, bias,
+                       bn_scale, bn_shift, C0, out, o_dt);
+}
+
+__global__ void k_se_fc(const float* mean, const float* w1, const float* b1, const float* w2, const float* b2, int C, int Cr, float* scale) {
+    extern __shared__ float hbuf[];
+    const int b = blockIdx.x;
+    const float* m = mean + (long)b * C;
+    for (int j = threadIdx.x; j < Cr; j += blockDim.x) {
+        float a = b1[j];
+        for (int c = 0; c < C; c++) a += w1[(long)j * C + c] * m[c];
+        hbuf[j] = fmaxf(a, 0.f);
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float a = b2[c];
+        for (int j = 0; j < Cr; j++) a += w2[(long)c * Cr + j] * hbuf[j];
+        scale[(long)b * C + c] = 1.0f / (1.0f + expf(-a));
+    }
+}
+void launch_se_fc(const float* mean, const float* w1, const float* b1, const float* w2, const float* b2, int C,
+                  int Cr, float* scale, int B, hipStream_t s) {
+    hipLaunchKernelGGL(k_se_fc, dim3(B), dim3(256), Cr * sizeof(float), s, mean, w1, b1, w2, b2, C, Cr, scale);
+}
+
+__global__ void k_se_apply(const void* x, const void* res, void* y, int dt, const float* scale, int H, int Wmax, const int* W, int C) {
+    const int b = blockIdx.z, hh = blockIdx.y, w = blockIdx.x;
+    if (w >= W[b]) return;
+    const long o = (((long)b * H + hh) * Wmax + w) * C;
+    for (int c = threadIdx.x; c < C; c += blockDim.x)
+        st(y, dt, o + c, fmaxf(ld(x, dt, o + c) * scale[(long)b * C + c] + ld(res, dt, o + c), 0.f));
+}
+void launch_se_apply(const void* x, const void* res, void* y, int dt, const float* scale, int B, int H, int Wmax,
+                     const int* W, int C, hipStream_t s) {
+    hipLaunchKernelGGL(k_se_apply, dim3(Wmax, H, B), dim3(C < 256 ? C : 256), 0, s, x, res, y, dt, scale, H, Wmax, W, C);
+}
+
+// attentive statistics pooling: softmax over time per feature column, weighted mean / std
+__global__ void k_asp_pool(const void* x, int xdt, const float* logits, int F, int Wmax, const int* W, int C, float* out) {
+    const int b = blockIdx.y, j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int D = F * C;
+    if (j >= D) return;
+    const int f = j / C, c = j - f * C, Wb = W[b];
+    float m = -INFINITY;
+    for (int t = 0; t < Wb; t++) m = fmaxf(m, logits[((long)b * Wmax + t) * D + j]);
+    float s = 0.f, sx = 0.f, sxx = 0.f;
+    for (int t = 0; t < Wb; t++) {
+        const float e = expf(logits[((long)b * Wmax + t) * D + j] - m);
+        const float v = ld(x, xdt, (((long)b * F + f) * Wmax + t) * C + c);
+        s += e; sx += e * v; sxx += e * v * v;
+    }
+    const float mu = sx / s;
+    const float sg = sqrtf(fmaxf(sxx / s - mu * mu, 1e-5f));      // ResNetSE34V2.py:204 clamp(min=1e-5)
+    out[(long)b * 2 * D + j] = mu;
+    out[(long)b * 2 * D + D + j] = sg;
+}
+void launch_asp_pool(const void* x, int x_dt, const float* logits, int B, int F, int Wmax, const int* W, int C,
+                     float* out, hipStream_t s) {
+    hipLaunchKernelGGL(k_asp_pool, dim3((F * C + 255) / 256, B), dim3(256), 0, s, x, x_dt, logits, F, Wmax, W, C, out);
+}
+
+__global__ void k_l2norm_rows(float* x, int C) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    float* row = x + (long)b * C;
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s += row[c] * row[c];
+    s = wave_sum(s);
+    const float inv = 1.0f / fmaxf(sqrtf(s), 1e-12f);              // F.normalize eps
+    for (int c = lane; c < C; c += 64) row[c] *= inv;
+}
+void launch_l2norm_rows(float* x, int B, int C, hipStream_t s) { hipLaunchKernelGGL(k_l2norm_rows, dim3(B), dim3(64), 0, s, x, C); }
+
+}  // namespace zvx

@@ -1,0 +1,1097 @@
+// zvx.hip -- libzvx context, weight loading, launch sequences and the C-ABI (include/zvx.h).
+//
+// Host-side C++ only sequences kernels: every contraction is a launch_gemm() (gemm.hip), everything
+// else a kernel from ops.hip.  One HIP stream per context; workspaces are grown on demand and reused.
+// Reference call structure being replaced: ZeroVox.inference_ex (model.py:308-347).
+#include "../../include/zvx.h"
+#include "zvx_kernels.h"
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <map>
+#include <sstream>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+using namespace zvx;
+
+namespace {
+
+struct ZvxError : std::runtime_error {
+    int code;
+    ZvxError(int c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+[[noreturn]] void fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+    throw ZvxError(code, buf);
+}
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) fail(ZVX_E_HIP, "%s failed: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
+
+thread_local std::string g_create_error;
+
+struct Tensor {
+    char kind = 'p';
+    std::vector<int> dims;
+    size_t off = 0, numel = 0;
+    void* dev = nullptr;
+    int dtype = DT_F32;
+    const float* host = nullptr;
+    int dim(int i) const { return dims.at(i); }
+};
+
+struct DevBuf { void* p = nullptr; size_t cap = 0; };
+
+struct GemmEvent { hipEvent_t a, b; int variant; double flops, bytes; };
+
+}  // namespace
+
+struct zvx_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    std::map<std::string, std::string> cfg;
+    std::map<std::string, Tensor> tensors;
+    std::vector<float> host_blob;
+    std::map<std::string, DevBuf> bufs;
+    int dt = DT_BF16;               // activation / weight dtype of the bf16-able stages
+    // config
+    int H = 0, emb_dim = 0, punct_dim = 0, n_phone_rows = 0, n_punct_rows = 0, max_txt_len = 0, max_mel_len = 0;
+    int enc_layers = 0, enc_heads = 0, ffn_dim = 0, ffn_k0 = 0, ffn_k1 = 0, vp_dim = 0, vp_k = 0, n_bins = 0;
+    int dec_layers = 0, dec_heads = 0, dec_scln = 0, n_mels = 0, hop = 0, res_dim = 0, dec_kind = 0, rn_asp = 1;
+    std::vector<int> rn_layers, rn_filters, voc_rates, voc_ksizes, voc_rb_k;
+    std::vector<std::vector<int>> voc_rb_d;
+    int voc_resblock = 1, voc_c0 = 0;
+    // per-call state
+    int B = 0, Tmax = 0, Lmax = 0;
+    std::vector<int> T_host, mel_len_host;
+    bool have_features = false, have_mel = false;
+    // profiling
+    int profile = 0;
+    hipEvent_t stage_ev[ZVX_T_COUNT][2];
+    bool stage_used[ZVX_T_COUNT];
+    float stage_ms[ZVX_T_COUNT];
+    std::vector<GemmEvent> pending;
+    std::vector<zvx_kernel_stat> stats;
+    std::vector<hipEvent_t> event_pool;
+
+    // ------------------------------------------------------------------ helpers
+    int cfg_int(const char* k) const {
+        auto it = cfg.find(k);
+        if (it == cfg.end()) fail(ZVX_E_MANIFEST, "manifest: missing cfg '%s'", k);
+        return atoi(it->second.c_str());
+    }
+    std::vector<int> cfg_list(const char* k) const {
+        auto it = cfg.find(k);
+        if (it == cfg.end()) fail(ZVX_E_MANIFEST, "manifest: missing cfg '%s'", k);
+        std::vector<int> v; std::stringstream ss(it->second); std::string tok;
+        while (std::getline(ss, tok, ',')) if (!tok.empty()) v.push_back(atoi(tok.c_str()));
+        return v;
+    }
+    const Tensor& t(const std::string& name) const {
+        auto it = tensors.find(name);
+        if (it == tensors.end()) fail(ZVX_E_MANIFEST, "weights: tensor '%s' missing", name.c_str());
+        return it->second;
+    }
+    bool has(const std::string& name) const { return tensors.count(name) != 0; }
+    const float* pf(const std::string& name) const { return (const float*)t(name).dev; }
+
+    void* buf(const std::string& name, size_t bytes) {
+        DevBuf& d = bufs[name];
+        if (bytes > d.cap) {
+            if (d.p) { HIPCHK(hipStreamSynchronize(stream)); HIPCHK(hipFree(d.p)); d.p = nullptr; }
+            size_t cap = bytes + bytes / 8 + 256;
+            HIPCHK(hipMalloc(&d.p, cap));
+            HIPCHK(hipMemsetAsync(d.p, 0, cap, stream));
+            d.cap = cap;
+        }
+        return d.p;
+    }
+    int* ibuf(const std::string& name, size_t n) { return (int*)buf(name, n * sizeof(int)); }
+    float* fbuf(const std::string& name, size_t n) { return (float*)buf(name, n * sizeof(float)); }
+    int* upload_ints(const std::string& name, const int* v, size_t n) {
+        int* d = ibuf(name, n);
+        HIPCHK(hipMemcpyAsync(d, v, n * sizeof(int), hipMemcpyHostToDevice, stream));
+        return d;
+    }
+    size_t es() const { return dtype_size(dt); }
+
+    hipEvent_t new_event() {
+        hipEvent_t e;
+        if (!event_pool.empty()) { e = event_pool.back(); event_pool.pop_back(); return e; }
+        HIPCHK(hipEventCreate(&e));
+        return e;
+    }
+    void stage_begin(int s) { if (profile) { HIPCHK(hipEventRecord(stage_ev[s][0], stream)); } }
+    void stage_end(int s) { if (profile) { HIPCHK(hipEventRecord(stage_ev[s][1], stream)); stage_used[s] = true; } }
+
+    void gemm(GemmArgs& a) {
+        if (a.flops <= 0) a.flops = 2.0 * (double)a.M * a.nbatch * a.nheads * (double)a.N * (double)a.K * a.ntaps;
+        GemmEvent ev{};
+        const bool prof = profile >= 2;
+        if (prof) { ev.a = new_event(); ev.b = new_event(); HIPCHK(hipEventRecord(ev.a, stream)); }
+        int id = launch_gemm(a, stream);
+        if (id < 0) fail(ZVX_E_INVALID, "launch_gemm rejected shape M=%d N=%d K=%d taps=%d", a.M, a.N, a.K, a.ntaps);
+        if (prof) {
+            HIPCHK(hipEventRecord(ev.b, stream));
+            ev.variant = id; ev.flops = a.flops;
+            const double esz = dtype_size(a.dtype);
+            ev.bytes = ((double)a.M * a.nbatch * a.nheads) * ((double)a.K * esz + (double)a.N * dtype_size(a.out_dtype)) +
+                       (double)a.N * a.K * a.ntaps * esz;
+            pending.push_back(ev);
+        }
+    }
+    void resolve_events() {
+        if (stats.empty()) {
+            stats.resize(gemm_num_variants());
+            for (int i = 0; i < gemm_num_variants(); i++) { memset(&stats[i], 0, sizeof stats[i]); snprintf(stats[i].name, 64, "%s", gemm_variant_name(i)); }
+        }
+        for (auto& e : pending) {
+            float ms = 0.f;
+            HIPCHK(hipEventElapsedTime(&ms, e.a, e.b));
+            auto& s = stats[e.variant];
+            s.launches++; s.ms += ms; s.flops += e.flops; s.bytes += e.bytes;
+            event_pool.push_back(e.a); event_pool.push_back(e.b);
+        }
+        pending.clear();
+        for (int s = 0; s < ZVX_T_COUNT; s++)
+            if (stage_used[s]) { float ms = 0.f; HIPCHK(hipEventElapsedTime(&ms, stage_ev[s][0], stage_ev[s][1])); stage_ms[s] = ms; stage_used[s] = false; }
+    }
+    void sync() { HIPCHK(hipStreamSynchronize(stream)); if (profile) resolve_events(); }
+};
+
+namespace {
+
+GemmArgs gemm_base(int dtype) {
+    GemmArgs a;
+    memset(&a, 0, sizeof a);
+    a.dtype = dtype; a.nbatch = 1; a.nheads = 1; a.ntaps = 1; a.stride = 1; a.wout = 0; a.hin = 1; a.win = 0;
+    a.alpha = 1.f; a.out_scale = 1.f; a.out_dtype = dtype; a.res_dtype = dtype;
+    return a;
+}
+void set_taps_1d(GemmArgs& a, int k, int dilation) {
+    a.ntaps = k;
+    for (int i = 0; i < k; i++) { a.du[i] = 0; a.dv[i] = (short)((i - (k - 1) / 2) * dilation); }
+}
+
+// ------------------------------------------------------------------------------------------------
+// manifest
+// ------------------------------------------------------------------------------------------------
+void parse_manifest(zvx_ctx* c, const char* manifest, const void* weights, size_t nbytes) {
+    if (!manifest || !weights) fail(ZVX_E_MANIFEST, "manifest/weights pointer is NULL");
+    const size_t nfloats = nbytes / 4;
+    c->host_blob.assign((const float*)weights, (const float*)weights + nfloats);
+    std::stringstream ss(manifest);
+    std::string line;
+    bool first = true;
+    while (std::getline(ss, line)) {
+        if (line.empty()) continue;
+        std::stringstream ls(line);
+        std::string kw; ls >> kw;
+        if (first) { if (kw != "zvx_manifest") fail(ZVX_E_MANIFEST, "manifest: bad magic '%s'", kw.c_str()); first = false; continue; }
+        if (kw == "cfg") {
+            std::string k, v; ls >> k; std::getline(ls, v);
+            size_t p = v.find_first_not_of(' ');
+            c->cfg[k] = p == std::string::npos ? "" : v.substr(p);
+        } else if (kw == "tensor") {
+            std::string name, kind; int nd = 0; ls >> name >> kind >> nd;
+            Tensor t; t.kind = kind.empty() ? 'p' : kind[0]; t.numel = 1;
+            for (int i = 0; i < nd; i++) { int d; ls >> d; t.dims.push_back(d); t.numel *= (size_t)d; }
+            ls >> t.off;
+            if (ls.fail() || t.off + t.numel > nfloats) fail(ZVX_E_MANIFEST, "manifest: tensor '%s' out of blob bounds", name.c_str());
+            c->tensors[name] = t;
+        } else {
+            fail(ZVX_E_MANIFEST, "manifest: unknown line '%s'", line.c_str());
+        }
+    }
+    if (first) fail(ZVX_E_MANIFEST, "manifest: empty");
+}
+
+void upload_weights(zvx_ctx* c) {
+    // one device arena for all tensors; 'w' tensors are converted to the context precision on device
+    size_t total = 0;
+    for (auto& kv : c->tensors) {
+        Tensor& t = kv.second;
+        t.dtype = (t.kind == 'w') ? c->dt : DT_F32;
+        total += (t.numel * dtype_size(t.dtype) + 255) & ~(size_t)255;
+    }
+    char* arena = (char*)c->buf("weights", total);
+    float* staging = c->fbuf("weights_staging", c->host_blob.size());
+    HIPCHK(hipMemcpyAsync(staging, c->host_blob.data(), c->host_blob.size() * 4, hipMemcpyHostToDevice, c->stream));
+    size_t off = 0;
+    for (auto& kv : c->tensors) {
+        Tensor& t = kv.second;
+        t.dev = arena + off;
+        t.host = c->host_blob.data() + t.off;
+        launch_cast(staging + t.off, DT_F32, t.dev, t.dtype, t.numel, c->stream);
+        off += (t.numel * dtype_size(t.dtype) + 255) & ~(size_t)255;
+    }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    DevBuf& st = c->bufs["weights_staging"];
+    HIPCHK(hipFree(st.p)); st.p = nullptr; st.cap = 0;
+}
+
+void read_config(zvx_ctx* c) {
+    auto it = c->cfg.find("precision");
+    if (it == c->cfg.end()) fail(ZVX_E_MANIFEST, "manifest: missing cfg 'precision'");
+    if (it->second == "bf16") c->dt = DT_BF16; else if (it->second == "f32") c->dt = DT_F32;
+    else fail(ZVX_E_MANIFEST, "manifest: unknown precision '%s'", it->second.c_str());
+    c->H = c->cfg_int("hidden"); c->emb_dim = c->cfg_int("emb_dim"); c->punct_dim = c->cfg_int("punct_dim");
+    c->n_phone_rows = c->cfg_int("n_phone_rows"); c->n_punct_rows = c->cfg_int("n_punct_rows");
+    c->max_txt_len = c->cfg_int("max_txt_len"); c->max_mel_len = c->cfg_int("max_mel_len");
+    c->enc_layers = c->cfg_int("enc_layers"); c->enc_heads = c->cfg_int("enc_heads"); c->ffn_dim = c->cfg_int("ffn_dim");
+    auto fk = c->cfg_list("ffn_k"); if (fk.size() != 2) fail(ZVX_E_MANIFEST, "manifest: ffn_k needs 2 entries");
+    c->ffn_k0 = fk[0]; c->ffn_k1 = fk[1];
+    c->vp_dim = c->cfg_int("vp_dim"); c->vp_k = c->cfg_int("vp_k"); c->n_bins = c->cfg_int("n_bins");
+    c->dec_layers = c->cfg_int("dec_layers"); c->dec_heads = c->cfg_int("dec_heads"); c->dec_scln = c->cfg_int("dec_scln");
+    c->n_mels = c->cfg_int("n_mels"); c->hop = c->cfg_int("hop"); c->res_dim = c->cfg_int("res_dim");
+    c->rn_layers = c->cfg_list("rn_layers"); c->rn_filters = c->cfg_list("rn_filters"); c->rn_asp = c->cfg_int("rn_asp");
+    const std::string dk = c->cfg["dec_kind"];
+    if (dk == "fastspeech2") c->dec_kind = 0; else if (dk == "styletts") c->dec_kind = 1;
+    else fail(ZVX_E_MANIFEST, "unknown decoder kind: '%s'", dk.c_str());                 // model.py:244
+    c->voc_resblock = c->cfg_int("voc_resblock"); c->voc_c0 = c->cfg_int("voc_c0");
+    c->voc_rates = c->cfg_list("voc_rates"); c->voc_ksizes = c->cfg_list("voc_ksizes"); c->voc_rb_k = c->cfg_list("voc_rb_k");
+    {
+        std::stringstream ss(c->cfg["voc_rb_d"]); std::string grp;
+        while (std::getline(ss, grp, ';')) {
+            std::vector<int> v; std::stringstream gs(grp); std::string tok;
+            while (std::getline(gs, tok, ',')) if (!tok.empty()) v.push_back(atoi(tok.c_str()));
+            c->voc_rb_d.push_back(v);
+        }
+    }
+    int prod = 1; for (int r : c->voc_rates) prod *= r;
+    if (prod != c->hop) fail(ZVX_E_MANIFEST, "prod(voc_rates)=%d != hop=%d", prod, c->hop);
+    if (c->voc_rb_d.size() != c->voc_rb_k.size()) fail(ZVX_E_MANIFEST, "voc_rb_d / voc_rb_k size mismatch");
+    if (c->H % 8 || (c->H / c->enc_heads) % 8 || (c->H / c->dec_heads) % 8) fail(ZVX_E_UNSUPPORTED, "hidden/head dims must be multiples of 8");
+}
+
+// ------------------------------------------------------------------------------------------------
+// FFT block (fs2.py:221-230): x [B][Lmax][H] (dtype dt) -> x, in place.
+// ------------------------------------------------------------------------------------------------
+struct FftWeights { std::string p; bool scln; const float* bg; long bg_bs; const float* post_add; };
+
+void fft_block(zvx_ctx* c, void* x, int dt, int B, int Lmax, const int* len_dev, int nheads, const FftWeights& w) {
+    const int H = c->H, d = H / nheads, Lp = (Lmax + 7) & ~7, F = c->ffn_dim;
+    const size_t es = dtype_size(dt);
+    void* qk = c->buf("fft.qk", (size_t)B * Lmax * 2 * H * es);
+    void* vt = c->buf("fft.vt", (size_t)B * H * Lp * es);
+    float* sc = c->fbuf("fft.scores", (size_t)B * nheads * Lmax * Lp);
+    void* P = c->buf("fft.P", (size_t)B * nheads * Lmax * Lp * es);
+    void* o = c->buf("fft.o", (size_t)B * Lmax * H * es);
+    float* y = c->fbuf("fft.y", (size_t)B * Lmax * H);
+    void* hbuf = c->buf("fft.h", (size_t)B * Lmax * F * es);
+
+    {   // [Q | K] = x Wqk^T + b                                       fs2.py:143-144
+        GemmArgs a = gemm_base(dt);
+        a.X = x; a.x_bs = (long)Lmax * H; a.ldx = H; a.W = c->t(w.p + ".wqk").dev; a.ldw = H;
+        a.M = Lmax; a.N = 2 * H; a.K = H; a.nbatch = B; a.in_len = len_dev; a.out_len = len_dev;
+        a.bias = c->pf(w.p + ".bqk"); a.bias_mode = 1;
+        a.out = qk; a.o_bs = (long)Lmax * 2 * H; a.ldo = 2 * H;
+        c->gemm(a);
+    }
+    {   // V^T[h*d + j][l] = Wv x^T + b  (stored transposed so that P.V is K-contiguous)   fs2.py:145
+        GemmArgs a = gemm_base(dt);
+        a.X = c->t(w.p + ".wv").dev; a.x_bs = 0; a.ldx = H; a.W = x; a.w_bs = (long)Lmax * H; a.ldw = H;
+        a.M = H; a.N = Lmax; a.K = H; a.nbatch = B; a.in_len_static = H;
+        a.bias = c->pf(w.p + ".bv"); a.bias_mode = 2;
+        a.out = vt; a.o_bs = (long)H * Lp; a.ldo = Lp;
+        // columns in [len, Lmax) hold finite junk (x rows beyond len are never NaN: buffers start zeroed and
+        // only ever receive finite values); P is exactly zero there, so they never contribute
+        c->gemm(a);
+    }
+    {   // scores = Q K^T / sqrt(d)                                    fs2.py:49-50
+        GemmArgs a = gemm_base(dt);
+        a.X = qk; a.x_bs = (long)Lmax * 2 * H; a.x_hs = d; a.ldx = 2 * H;
+        a.W = (const char*)qk + (size_t)H * es; a.w_bs = (long)Lmax * 2 * H; a.w_hs = d; a.ldw = 2 * H;
+        a.M = Lmax; a.N = Lmax; a.K = d; a.nbatch = B; a.nheads = nheads; a.in_len = len_dev; a.out_len = len_dev;
+        a.alpha = (float)(1.0 / pow((double)d, 0.5));
+        a.out = sc; a.out_dtype = DT_F32; a.o_bs = (long)nheads * Lmax * Lp; a.o_hs = (long)Lmax * Lp; a.ldo = Lp;
+        a.flops = 2.0 * B * nheads * (double)Lmax * Lmax * d;
+        c->gemm(a);
+    }
+    launch_softmax_rows(sc, Lp, P, dt, Lp, B, nheads, Lmax, len_dev, c->stream);      // fs2.py:52-55
+    {   // O = P V                                                      fs2.py:56
+        GemmArgs a = gemm_base(dt);
+        a.X = P; a.x_bs = (long)nheads * Lmax * Lp; a.x_hs = (long)Lmax * Lp; a.ldx = Lp;
+        a.W = vt; a.w_bs = (long)H * Lp; a.w_hs = (long)d * Lp; a.ldw = Lp;
+        a.M = Lmax; a.N = d; a.K = Lp; a.k_len = len_dev; a.nbatch = B; a.nheads = nheads; a.in_len = len_dev; a.out_len = len_dev;
+        a.out = o; a.o_bs = (long)Lmax * H; a.o_hs = d; a.ldo = H;
+        a.flops = 2.0 * B * nheads * (double)Lmax * Lmax * d;
+        c->gemm(a);
+    }
+    {   // y = fc(O) + residual                                         fs2.py:158-162
+        GemmArgs a = gemm_base(dt);
+        a.X = o; a.x_bs = (long)Lmax * H; a.ldx = H; a.W = c->t(w.p + ".wo").dev; a.ldw = H;
+        a.M = Lmax; a.N = H; a.K = H; a.nbatch = B; a.in_len = len_dev; a.out_len = len_dev;
+        a.bias = c->pf(w.p + ".bo"); a.bias_mode = 1;
+        a.res = x; a.r_bs = (long)Lmax * H; a.ldr = H; a.res_mode = 1; a.res_dtype = dt;
+        a.out = y; a.out_dtype = DT_F32; a.o_bs = (long)Lmax * H; a.ldo = H;
+        c->gemm(a);
+    }
+    if (w.scln) launch_layernorm(y, DT_F32, H, x, dt, H, B, Lmax, len_dev, H, 1, 1e-8f, nullptr, nullptr, w.bg, w.bg_bs, nullptr, c->stream);
+    else launch_layernorm(y, DT_F32, H, x, dt, H, B, Lmax, len_dev, H, 0, 1e-5f, c->pf(w.p + ".ln1_g"), c->pf(w.p + ".ln1_b"), nullptr, 0, nullptr, c->stream);
+    {   // h = relu(conv_k9(x))                                         fs2.py:198-200
+        GemmArgs a = gemm_base(dt);
+        a.X = x; a.x_bs = (long)Lmax * H; a.ldx = H; a.W = c->t(w.p + ".w1").dev; a.ldw = H; a.w_ts = (long)F * H;
+        a.M = Lmax; a.N = F; a.K = H; a.nbatch = B; a.in_len = len_dev; a.out_len = len_dev;
+        set_taps_1d(a, c->ffn_k0, 1);
+        a.bias = c->pf(w.p + ".b1"); a.bias_mode = 1; a.act = ACT_RELU;
+        a.out = hbuf; a.o_bs = (long)Lmax * F; a.ldo = F;
+        c->gemm(a);
+    }
+    {   // y = conv_k1(h) + residual                                    fs2.py:201-207
+        GemmArgs a = gemm_base(dt);
+        a.X = hbuf; a.x_bs = (long)Lmax * F; a.ldx = F; a.W = c->t(w.p + ".w2").dev; a.ldw = F; a.w_ts = (long)H * F;
+        a.M = Lmax; a.N = H; a.K = F; a.nbatch = B; a.in_len = len_dev; a.out_len = len_dev;
+        set_taps_1d(a, c->ffn_k1, 1);
+        a.bias = c->pf(w.p + ".b2"); a.bias_mode = 1;
+        a.res = x; a.r_bs = (long)Lmax * H; a.ldr = H; a.res_mode = 1; a.res_dtype = dt;
+        a.out = y; a.out_dtype = DT_F32; a.o_bs = (long)Lmax * H; a.ldo = H;
+        c->gemm(a);
+    }
+    if (w.scln) launch_layernorm(y, DT_F32, H, x, dt, H, B, Lmax, len_dev, H, 1, 1e-8f, nullptr, nullptr, w.bg + 2 * H, w.bg_bs, w.post_add, c->stream);
+    else launch_layernorm(y, DT_F32, H, x, dt, H, B, Lmax, len_dev, H, 0, 1e-5f, c->pf(w.p + ".ln2_g"), c->pf(w.p + ".ln2_b"), nullptr, 0, w.post_add, c->stream);
+}
+
+// ------------------------------------------------------------------------------------------------
+// encoder + variance adaptor + length regulator   (fs2.py:732-775)
+// ------------------------------------------------------------------------------------------------
+void variance_predictor(zvx_ctx* c, const char* nm, const float* x, int B, int Tmax, const int* T_dev, float* pred) {
+    const int H = c->H, Fv = c->vp_dim;
+    const std::string p = std::string("va.") + nm;
+    float* h1 = c->fbuf("va.h1", (size_t)B * Tmax * Fv);
+    float* h2 = c->fbuf("va.h2", (size_t)B * Tmax * Fv);
+    {
+        GemmArgs a = gemm_base(DT_F32);
+        a.X = x; a.x_bs = (long)Tmax * H; a.ldx = H; a.W = c->t(p + ".c1").dev; a.ldw = H; a.w_ts = (long)Fv * H;
+        a.M = Tmax; a.N = Fv; a.K = H; a.nbatch = B; a.in_len = T_dev; a.out_len = T_dev;
+        set_taps_1d(a, c->vp_k, 1);
+        a.bias = c->pf(p + ".b1"); a.bias_mode = 1; a.act = ACT_RELU;
+        a.out = h1; a.o_bs = (long)Tmax * Fv; a.ldo = Fv;
+        c->gemm(a);
+    }
+    launch_layernorm(h1, DT_F32, Fv, h1, DT_F32, Fv, B, Tmax, T_dev, Fv, 0, 1e-5f, c->pf(p + ".ln1_g"), c->pf(p + ".ln1_b"), nullptr, 0, nullptr, c->stream);
+    {
+        GemmArgs a = gemm_base(DT_F32);
+        a.X = h1; a.x_bs = (long)Tmax * Fv; a.ldx = Fv; a.W = c->t(p + ".c2").dev; a.ldw = Fv; a.w_ts = (long)Fv * Fv;
+        a.M = Tmax; a.N = Fv; a.K = Fv; a.nbatch = B; a.in_len = T_dev; a.out_len = T_dev;
+        // fs2.py:543 hard-codes padding=1: taps are k - 1 for k in [0, vp_k)
+        a.ntaps = c->vp_k;
+        for (int k = 0; k < c->vp_k; k++) { a.du[k] = 0; a.dv[k] = (short)(k - 1); }
+        a.bias = c->pf(p + ".b2"); a.bias_mode = 1; a.act = ACT_RELU;
+        a.out = h2; a.o_bs = (long)Tmax * Fv; a.ldo = Fv;
+        c->gemm(a);
+    }
+    launch_layernorm(h2, DT_F32, Fv, h2, DT_F32, Fv, B, Tmax, T_dev, Fv, 0, 1e-5f, c->pf(p + ".ln2_g"), c->pf(p + ".ln2_b"), nullptr, 0, nullptr, c->stream);
+    launch_rowdot(h2, Fv, c->pf(p + ".lw"), c->t(p + ".lb").host[0], pred, B, Tmax, T_dev, Fv, c->stream);
+}
+
+void run_encode(zvx_ctx* c, const int32_t* phoneme, const int32_t* puncts, const int32_t* duration, const int32_t* T,
+                int B, int Tmax, const float* spk) {
+    const int H = c->H;
+    if (B <= 0 || Tmax <= 0) fail(ZVX_E_INVALID, "B and Tmax must be positive");
+    if (c->vp_k != 3) fail(ZVX_E_UNSUPPORTED, "vp_kernel_size != 3 changes the sequence length (fs2.py:543 padding=1)");
+    c->T_host.assign(T, T + B);
+    for (int b = 0; b < B; b++) {
+        if (T[b] <= 0 || T[b] > Tmax) fail(ZVX_E_INVALID, "T[%d]=%d out of range (1..%d)", b, T[b], Tmax);
+        for (int t = 0; t < T[b]; t++) {
+            const int ph = phoneme[b * Tmax + t], pu = puncts[b * Tmax + t];
+            if (ph < 0 || ph >= c->n_phone_rows) fail(ZVX_E_INVALID, "phoneme id %d out of range at [%d][%d]", ph, b, t);   // nn.Embedding IndexError
+            if (pu < 0 || pu >= c->n_punct_rows) fail(ZVX_E_INVALID, "punct id %d out of range at [%d][%d]", pu, b, t);
+        }
+    }
+    c->B = B; c->Tmax = Tmax; c->have_features = false; c->have_mel = false;
+    const size_t nid = (size_t)B * Tmax;
+    int* ph_d = c->upload_ints("in.phoneme", phoneme, nid);
+    int* pu_d = c->upload_ints("in.puncts", puncts, nid);
+    int* T_d = c->upload_ints("in.T", T, B);
+    int* dur_in = duration ? c->upload_ints("in.duration", duration, nid) : nullptr;
+    float* spk_d = c->fbuf("in.spk", (size_t)B * H);
+    HIPCHK(hipMemcpyAsync(spk_d, spk, (size_t)B * H * 4, hipMemcpyHostToDevice, c->stream));
+
+    c->stage_begin(ZVX_T_ENCODER);
+    // positional table: stored rows cover max_txt_len; longer inputs recompute it (fs2.py:383-388)
+    const float* pe = c->pf("enc.pe");
+    if (Tmax > c->t("enc.pe").dim(0)) {
+        std::vector<float> tab((size_t)Tmax * H);
+        for (int pos = 0; pos < Tmax; pos++)
+            for (int j = 0; j < H; j++) {
+                const double ang = pos / pow(10000.0, 2.0 * (j / 2) / H);
+                tab[(size_t)pos * H + j] = (float)((j & 1) ? cos(ang) : sin(ang));
+            }
+        float* d = c->fbuf("enc.pe_ext", tab.size());
+        HIPCHK(hipMemcpyAsync(d, tab.data(), tab.size() * 4, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        pe = d;
+    }
+    float* x = c->fbuf("enc.x", nid * H);
+    launch_embed(ph_d, pu_d, c->pf("enc.emb"), c->emb_dim, c->pf("enc.pemb"), c->punct_dim, pe, x, B, Tmax, T_d, c->stream);
+    for (int i = 0; i < c->enc_layers; i++) {
+        FftWeights w{"enc." + std::to_string(i), false, nullptr, 0, (i == c->enc_layers - 1) ? spk_d : nullptr};   // + style (fs2.py:740-741)
+        fft_block(c, x, DT_F32, B, Tmax, T_d, c->enc_heads, w);
+    }
+    c->stage_end(ZVX_T_ENCODER);
+
+    c->stage_begin(ZVX_T_VARIANCE);
+    HIPCHK(hipMemcpyAsync(c->fbuf("enc.out", nid * H), x, nid * H * 4, hipMemcpyDeviceToDevice, c->stream));
+    float* logd = c->fbuf("va.logd", nid); float* pitch = c->fbuf("va.pitch", nid); float* energy = c->fbuf("va.energy", nid);
+    HIPCHK(hipMemsetAsync(logd, 0, nid * 4, c->stream)); HIPCHK(hipMemsetAsync(pitch, 0, nid * 4, c->stream)); HIPCHK(hipMemsetAsync(energy, 0, nid * 4, c->stream));
+    int* pidx = c->ibuf("va.pitch_idx", nid); int* eidx = c->ibuf("va.energy_idx", nid);
+    HIPCHK(hipMemsetAsync(pidx, 0, nid * 4, c->stream)); HIPCHK(hipMemsetAsync(eidx, 0, nid * 4, c->stream));
+    variance_predictor(c, "dur", x, B, Tmax, T_d, logd);                                               // fs2.py:663
+    variance_predictor(c, "pitch", x, B, Tmax, T_d, pitch);                                            // fs2.py:665-668
+    launch_bucket_embed_add(pitch, c->pf("va.pitch_emb"), c->n_bins, x, H, H, pidx, B, Tmax, T_d, c->stream);
+    variance_predictor(c, "energy", x, B, Tmax, T_d, energy);                                          // fs2.py:669-672
+    launch_bucket_embed_add(energy, c->pf("va.energy_emb"), c->n_bins, x, H, H, eidx, B, Tmax, T_d, c->stream);
+    c->stage_end(ZVX_T_VARIANCE);
+
+    c->stage_begin(ZVX_T_LENREG);
+    int* dur = c->ibuf("va.dur", nid); int* cum = c->ibuf("va.cum", nid); int* ml = c->ibuf("va.mel_len", B);
+    HIPCHK(hipMemsetAsync(dur, 0, nid * 4, c->stream));
+    launch_durations(dur_in, logd, dur, cum, ml, B, Tmax, T_d, c->stream);
+    c->mel_len_host.resize(B);
+    HIPCHK(hipMemcpyAsync(c->mel_len_host.data(), ml, B * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));            // the one data-dependent host sync (model.py:325)
+    int Lmax = 0; for (int b = 0; b < B; b++) Lmax = std::max(Lmax, c->mel_len_host[b]);
+    c->Lmax = Lmax;
+    if (Lmax > 0) {
+        float* feats = c->fbuf("features", (size_t)B * Lmax * H);
+        launch_length_regulate(x, H, cum, T_d, ml, feats, B, Tmax, Lmax, H, c->stream);
+    }
+    c->stage_end(ZVX_T_LENREG);
+    c->have_features = true;
+}
+
+// ------------------------------------------------------------------------------------------------
+// mel decoders
+// ------------------------------------------------------------------------------------------------
+void decoder_fs2(zvx_ctx* c, const float* feats, const float* spk_d, const int* L_d, int B, int Lmax, float* mel) {
+    const int H = c->H, dt = c->dt;
+    const float* pe = c->pf("dec.pe");
+    if (Lmax > c->t("dec.pe").dim(0)) {                   // fs2.py:287-294: table recomputed for longer inputs
+        std::vector<float> tab((size_t)Lmax * H);
+        for (int pos = 0; pos < Lmax; pos++)
+            for (int j = 0; j < H; j++) {
+                const double ang = pos / pow(10000.0, 2.0 * (j / 2) / H);
+                tab[(size_t)pos * H + j] = (float)((j & 1) ? cos(ang) : sin(ang));
+            }
+        float* d = c->fbuf("dec.pe_ext", tab.size());
+        HIPCHK(hipMemcpyAsync(d, tab.data(), tab.size() * 4, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+        pe = d;
+    }
+    void* x = c->buf("dec.x", (size_t)B * Lmax * H * c->es());
+    launch_add_pe_cast(feats, pe, x, dt, H, B, Lmax, L_d, H, c->stream);
+    float* bg = nullptr; long bg_bs = 0;
+    if (c->dec_scln) {      // all 2*layers SCLN affine vectors of the call in one GEMM: [b | g] = W s   (fs2.py:85)
+        const int NA = 2 * c->dec_layers * 2 * H;
+        bg = c->fbuf("dec.bg", (size_t)B * NA); bg_bs = NA;
+        GemmArgs a = gemm_base(DT_F32);
+        a.X = spk_d; a.ldx = H; a.W = c->t("dec.scln_all").dev; a.ldw = H; a.M = B; a.N = NA; a.K = H; a.in_len_static = B;
+        a.out = bg; a.ldo = NA;
+        c->gemm(a);
+    }
+    for (int i = 0; i < c->dec_layers; i++) {
+        FftWeights w{"dec." + std::to_string(i), c->dec_scln != 0, bg ? bg + (long)i * 4 * H : nullptr, bg_bs, nullptr};
+        fft_block(c, x, dt, B, Lmax, L_d, c->dec_heads, w);
+    }
+    GemmArgs a = gemm_base(dt);                             // mel_linear   fs2.py:313
+    a.X = x; a.x_bs = (long)Lmax * H; a.ldx = H; a.W = c->t("dec.mel_w").dev; a.ldw = H;
+    a.M = Lmax; a.N = c->n_mels; a.K = H; a.nbatch = B; a.in_len = L_d; a.out_len = L_d;
+    a.bias = c->pf("dec.mel_b"); a.bias_mode = 1;
+    a.out = mel; a.out_dtype = DT_F32; a.o_bs = (long)Lmax * c->n_mels; a.ldo = c->n_mels;
+    c->gemm(a);
+}
+
+struct StyCtx { zvx_ctx* c; int B, Lmax; const int* L_d; float* mean; float* rstd; };
+
+void sty_conv(const StyCtx& s, const std::string& wname, const void* x, int ldx, int Cin, void* out, int ldo, int out_dt,
+              int Cout, const void* res, int ldr, float out_scale) {
+    zvx_ctx* c = s.c;
+    const Tensor& w = c->t(wname);
+    GemmArgs a = gemm_base(c->dt);
+    a.X = x; a.x_bs = (long)s.Lmax * ldx; a.ldx = ldx; a.W = w.dev; a.ldw = Cin; a.w_ts = (long)Cout * Cin;
+    a.M = s.Lmax; a.N = Cout; a.K = Cin; a.nbatch = s.B; a.in_len = s.L_d; a.out_len = s.L_d;
+    set_taps_1d(a, w.dim(0), 1);
+    if (c->has(wname + "_b")) { a.bias = c->pf(wname + "_b"); a.bias_mode = 1; }
+    if (res) { a.res = res; a.r_bs = (long)s.Lmax * ldr; a.ldr = ldr; a.res_mode = 1; a.res_dtype = c->dt; }
+    a.out_scale = out_scale;
+    a.out = out; a.o_bs = (long)s.Lmax * ldo; a.ldo = ldo; a.out_dtype = out_dt;
+    c->gemm(a);
+}
+// y = lrelu_0.2(affine(IN(x)))  (InstanceNorm over each utterance's true length only)
+void sty_norm(const StyCtx& s, const void* x, int ldx, int C, void* y, int ldy, const float* gamma, const float* beta,
+              long g_bs, int one_plus, int act) {
+    launch_instnorm_stats(x, s.c->dt, ldx, s.B, s.Lmax, s.L_d, C, 1e-5f, s.mean, s.rstd, s.c->stream);
+    launch_norm_affine_act(x, s.c->dt, ldx, y, s.c->dt, ldy, s.B, s.Lmax, s.L_d, C, s.mean, s.rstd, gamma, beta, g_bs, one_plus,
+                           act, 0.2f, s.c->stream);
+}
+
+void decoder_styletts(zvx_ctx* c, const float* feats, const float* spk_d, const int* L_d, int B, int Lmax, float* mel) {
+    const int H = c->H, H2 = 2 * H, R = c->res_dim, CW = H2 + R, dt = c->dt;
+    const size_t es = c->es(), rows = (size_t)B * Lmax;
+    const float inv_sqrt2 = (float)(1.0 / sqrt(2.0));
+    StyCtx s{c, B, Lmax, L_d, c->fbuf("sty.mean", (size_t)B * CW), c->fbuf("sty.rstd", (size_t)B * CW)};
+    void* e = c->buf("sty.e", rows * H * es);
+    void* t0 = c->buf("sty.t0", rows * CW * es);
+    void* t1 = c->buf("sty.t1", rows * H2 * es);
+    void* r = c->buf("sty.r", rows * H2 * es);
+    void* catA = c->buf("sty.catA", rows * CW * es);
+    void* catB = c->buf("sty.catB", rows * CW * es);
+    launch_add_pe_cast(feats, nullptr, e, dt, H, B, Lmax, L_d, H, c->stream);
+
+    // AdaIN affine vectors for all 10 norms: h = fc(s)          styletts.py:89-91
+    const Tensor& aw = c->t("sty.adain_w");
+    const int NA = aw.dim(1);
+    float* hall = c->fbuf("sty.adain_h", (size_t)B * NA);
+    {
+        GemmArgs a = gemm_base(DT_F32);
+        a.X = spk_d; a.ldx = H; a.W = aw.dev; a.ldw = H; a.M = B; a.N = NA; a.K = H; a.in_len_static = B;
+        a.bias = c->pf("sty.adain_b"); a.bias_mode = 1; a.out = hall; a.ldo = NA;
+        c->gemm(a);
+    }
+    // encode.0: ResBlk1d(H -> 2H, normalize)                       styletts.py:44-69
+    sty_norm(s, e, H, H, t0, H, c->pf("sty.enc0.norm1_g"), c->pf("sty.enc0.norm1_b"), 0, 0, ACT_LRELU);
+    sty_conv(s, "sty.enc0.c1", t0, H, H, t1, H, dt, H, nullptr, 0, 1.f);
+    sty_norm(s, t1, H, H, t0, H, c->pf("sty.enc0.norm2_g"), c->pf("sty.enc0.norm2_b"), 0, 0, ACT_LRELU);
+    sty_conv(s, "sty.enc0.c2", t0, H, H, r, H2, dt, H2, nullptr, 0, 1.f);
+    sty_conv(s, "sty.enc0.sc", e, H, H, catA, CW, dt, H2, r, H2, inv_sqrt2);
+    // encode.1: ResBlk1d(2H -> 2H), identity shortcut (in place on catA[:, 0:2H])
+    sty_norm(s, catA, CW, H2, t0, H2, c->pf("sty.enc1.norm1_g"), c->pf("sty.enc1.norm1_b"), 0, 0, ACT_LRELU);
+    sty_conv(s, "sty.enc1.c1", t0, H2, H2, t1, H2, dt, H2, nullptr, 0, 1.f);
+    sty_norm(s, t1, H2, H2, t0, H2, c->pf("sty.enc1.norm2_g"), c->pf("sty.enc1.norm2_b"), 0, 0, ACT_LRELU);
+    sty_conv(s, "sty.enc1.c2", t0, H2, H2, catA, CW, dt, H2, catA, CW, inv_sqrt2);
+    // asr_res = IN_affine(conv1x1(e)) -> columns [2H, 2H+R) of both concat buffers (concat-free torch.cat, styletts.py:195)
+    sty_conv(s, "sty.asr", e, H, H, t1, R, dt, R, nullptr, 0, 1.f);
+    launch_instnorm_stats(t1, dt, R, B, Lmax, L_d, R, 1e-5f, s.mean, s.rstd, c->stream);
+    for (void* cat : {catA, catB})
+        launch_norm_affine_act(t1, dt, R, (char*)cat + (size_t)H2 * es, dt, CW, B, Lmax, L_d, R, s.mean, s.rstd, c->pf("sty.asr_g"),
+                               c->pf("sty.asr_beta"), 0, 0, ACT_NONE, 0.f, c->stream);
+    // decode.0..4: AdainResBlk1d                                    styletts.py:119-139
+    struct Blk { int cin, cout; bool cat_out; };
+    const Blk blks[5] = {{CW, H2, true}, {CW, H2, true}, {CW, H, false}, {H, H, false}, {H, H, false}};
+    void* cur = catA; int cur_ld = CW;
+    void* nxtcat = catB;
+    void* xa = c->buf("sty.xa", rows * H * es);
+    void* xb = c->buf("sty.xb", rows * H * es);
+    long hoff = 0;
+    for (int i = 0; i < 5; i++) {
+        const Blk& bk = blks[i];
+        const std::string p = "sty.dec" + std::to_string(i);
+        const float* g1 = hall + hoff;            const float* b1 = g1 + bk.cin;  hoff += 2 * bk.cin;
+        const float* g2 = hall + hoff;            const float* b2 = g2 + bk.cout; hoff += 2 * bk.cout;
+        sty_norm(s, cur, cur_ld, bk.cin, t0, bk.cin, g1, b1, NA, 1, ACT_LRELU);
+        sty_conv(s, p + ".c1", t0, bk.cin, bk.cin, t1, bk.cout, dt, bk.cout, nullptr, 0, 1.f);
+        sty_norm(s, t1, bk.cout, bk.cout, t0, bk.cout, g2, b2, NA, 1, ACT_LRELU);
+        void* out; int out_ld;
+        if (bk.cat_out) { out = nxtcat; out_ld = CW; } else { out = (cur == xa) ? xb : xa; out_ld = H; }
+        if (c->has(p + ".sc")) {
+            sty_conv(s, p + ".c2", t0, bk.cout, bk.cout, r, bk.cout, dt, bk.cout, nullptr, 0, 1.f);
+            sty_conv(s, p + ".sc", cur, cur_ld, bk.cin, out, out_ld, dt, bk.cout, r, bk.cout, inv_sqrt2);
+        } else {
+            sty_conv(s, p + ".c2", t0, bk.cout, bk.cout, out, out_ld, dt, bk.cout, cur, cur_ld, inv_sqrt2);
+        }
+        if (bk.cat_out) { nxtcat = cur; }
+        cur = out; cur_ld = out_ld;
+    }
+    sty_conv(s, "sty.out", cur, cur_ld, H, mel, c->n_mels, DT_F32, c->n_mels, nullptr, 0, 1.f);
+}
+
+void run_decode(zvx_ctx* c, const float* feats, const float* spk_d, const int* L_d, int B, int Lmax) {
+    c->stage_begin(ZVX_T_DECODER);
+    float* mel = c->fbuf("mel", (size_t)B * std::max(Lmax, 1) * c->n_mels);
+    if (Lmax > 0) {
+        if (c->dec_kind == 0) decoder_fs2(c, feats, spk_d, L_d, B, Lmax, mel);
+        else decoder_styletts(c, feats, spk_d, L_d, B, Lmax, mel);
+    }
+    c->stage_end(ZVX_T_DECODER);
+    c->have_mel = true;
+}
+
+// ------------------------------------------------------------------------------------------------
+// HiFi-GAN generator (hifigan.py:114-130).  Activations are stored in the *activated* domain:
+// every tensor a later conv consumes through leaky_relu(., 0.1) is written as leaky_relu(x); the raw
+// residual is recovered exactly-enough by the inverse map in the consumer's epilogue (res_mode 2).
+// ------------------------------------------------------------------------------------------------
+void run_vocoder(zvx_ctx* c, const float* mel, int ldm, int Lmel_max, const int* mel_len_host, const int* P_host, int B,
+                 float* wav_dev, long wav_stride) {
+    const int dt = c->dt, nm = c->n_mels;
+    const size_t es = c->es();
+    int Pmax = 0; for (int b = 0; b < B; b++) Pmax = std::max(Pmax, P_host[b]);
+    if (Pmax <= 0) return;
+    const int ns = (int)c->voc_rates.size(), nk = (int)c->voc_rb_k.size();
+    // per-stage valid row counts
+    std::vector<int> lens((size_t)(ns + 2) * B);
+    for (int b = 0; b < B; b++) { lens[b] = mel_len_host[b]; lens[B + b] = P_host[b]; }
+    int mul = 1;
+    for (int i = 0; i < ns; i++) { mul *= c->voc_rates[i]; for (int b = 0; b < B; b++) lens[(size_t)(i + 2) * B + b] = P_host[b] * mul; }
+    int* lens_d = c->upload_ints("voc.lens", lens.data(), lens.size());
+    const int* mel_len_d = lens_d; const int* P_d = lens_d + B;
+
+    size_t maxel = (size_t)Pmax * c->voc_c0; mul = 1;
+    for (int i = 0; i < ns; i++) { mul *= c->voc_rates[i]; maxel = std::max(maxel, (size_t)Pmax * mul * (size_t)(c->voc_c0 >> (i + 1))); }
+    maxel *= B;
+    void* vin = c->buf("voc.in", (size_t)B * Pmax * nm * es);
+    void* A = c->buf("voc.A", maxel * es);        // stage input (activated)
+    void* X0 = c->buf("voc.X0", maxel * es);      // upsampled stage tensor (activated)
+    void* T1 = c->buf("voc.T1", maxel * es);
+    void* PP[2] = {c->buf("voc.PP0", maxel * es), c->buf("voc.PP1", maxel * es)};
+    float* XS = c->fbuf("voc.XS", maxel);
+
+    launch_mel_pad(mel, DT_F32, ldm, Lmel_max, mel_len_d, vin, dt, nm, Pmax, P_d, B, nm, c->stream);     // model.py:331-335
+    {   // conv_pre, stored as leaky_relu(x, 0.1) (its only consumer, hifigan.py:115-117)
+        GemmArgs a = gemm_base(dt);
+        a.X = vin; a.x_bs = (long)Pmax * nm; a.ldx = nm; a.W = c->t("voc.pre_w").dev; a.ldw = nm; a.w_ts = (long)c->voc_c0 * nm;
+        a.M = Pmax; a.N = c->voc_c0; a.K = nm; a.nbatch = B; a.in_len = P_d; a.out_len = P_d;
+        set_taps_1d(a, c->t("voc.pre_w").dim(0), 1);
+        a.bias = c->pf("voc.pre_b"); a.bias_mode = 1; a.act = ACT_LRELU; a.slope = 0.1f;
+        a.out = A; a.o_bs = (long)Pmax * c->voc_c0; a.ldo = c->voc_c0;
+        c->gemm(a);
+    }
+    int Cin = c->voc_c0; mul = 1;
+    for (int i = 0; i < ns; i++) {
+        const int u = c->voc_rates[i], ku = c->voc_ksizes[i], Cout = Cin / 2;
+        const int rows_in = Pmax * mul, rows = rows_in * u;
+        const int* len_in = lens_d + (size_t)(i + 1) * B; const int* len = lens_d + (size_t)(i + 2) * B;
+        {   // ConvTranspose1d as a 3-tap polyphase GEMM: out[t][ph*Cout+co]        hifigan.py:118
+            GemmArgs a = gemm_base(dt);
+            a.X = A; a.x_bs = (long)rows_in * Cin; a.ldx = Cin; a.W = c->t("voc.up" + std::to_string(i) + "_w").dev; a.ldw = Cin;
+            a.w_ts = (long)u * Cout * Cin;
+            a.M = rows_in; a.N = u * Cout; a.K = Cin; a.nbatch = B; a.in_len = len_in; a.out_len = len_in;
+            a.ntaps = 3; a.dv[0] = -1; a.dv[1] = 0; a.dv[2] = 1;
+            a.bias = c->pf("voc.up" + std::to_string(i) + "_b"); a.bias_mode = 1; a.act = ACT_LRELU; a.slope = 0.1f;
+            a.out = X0; a.o_bs = (long)rows_in * u * Cout; a.ldo = u * Cout;
+            a.flops = 2.0 * B * (double)rows_in * Cin * Cout * ku;
+            c->gemm(a);
+        }
+        const float next_slope = (i == ns - 1) ? 0.01f : 0.1f;          // hifigan.py:126 uses the default slope 0.01
+        for (int j = 0; j < nk; j++) {
+            const int k = c->voc_rb_k[j];
+            const std::vector<int>& dil = c->voc_rb_d[j];
+            const int nd = (int)dil.size();
+            const std::string rb = "voc.rb" + std::to_string(i * nk + j);
+            const void* cur = X0;
+            int pp = 0;
+            for (int t = 0; t < nd; t++) {
+                const bool last = (t == nd - 1);
+                const void* cin_buf = cur;
+                GemmArgs a = gemm_base(dt);
+                a.M = rows; a.N = Cout; a.K = Cout; a.nbatch = B; a.in_len = len; a.out_len = len; a.ldw = Cout; a.w_ts = (long)Cout * Cout;
+                a.x_bs = (long)rows * Cout; a.ldx = Cout; a.o_bs = (long)rows * Cout; a.ldo = Cout;
+                if (c->voc_resblock == 1) {
+                    // xt = c1(lrelu(x)); stored as lrelu(xt)                       hifigan.py:51-53
+                    a.X = cur; a.W = c->t(rb + ".c1_" + std::to_string(t) + "_w").dev;
+                    set_taps_1d(a, k, dil[t]);
+                    a.bias = c->pf(rb + ".c1_" + std::to_string(t) + "_b"); a.bias_mode = 1; a.act = ACT_LRELU; a.slope = 0.1f;
+                    a.out = T1;
+                    c->gemm(a);
+                    // x = c2(.) + x                                                hifigan.py:54-55
+                    a = gemm_base(dt);
+                    a.M = rows; a.N = Cout; a.K = Cout; a.nbatch = B; a.in_len = len; a.out_len = len; a.ldw = Cout; a.w_ts = (long)Cout * Cout;
+                    a.x_bs = (long)rows * Cout; a.ldx = Cout; a.o_bs = (long)rows * Cout; a.ldo = Cout;
+                    a.X = T1; a.W = c->t(rb + ".c2_" + std::to_string(t) + "_w").dev;
+                    set_taps_1d(a, k, 1);
+                    a.bias = c->pf(rb + ".c2_" + std::to_string(t) + "_b");
+                } else {
+                    // x = c(lrelu(x)) + x                                          hifigan.py:78-81
+                    a.X = cur; a.W = c->t(rb + ".c_" + std::to_string(t) + "_w").dev;
+                    set_taps_1d(a, k, dil[t]);
+                    a.bias = c->pf(rb + ".c_" + std::to_string(t) + "_b");
+                }
+                a.bias_mode = 1;
+                a.res = cin_buf; a.r_bs = (long)rows * Cout; a.ldr = Cout; a.res_mode = 2; a.res_inv_slope = 10.0f; a.res_dtype = dt;
+                if (!last) {
+                    a.act = ACT_LRELU; a.slope = 0.1f; a.out = PP[pp];
+                    c->gemm(a);
+                    cur = PP[pp]; pp ^= 1;
+                } else {
+                    // xs (+)= resblock output; last kernel size: x = xs / num_kernels, stored activated for the next stage
+                    a.accum = XS; a.a_bs = (long)rows * Cout; a.lda = Cout;
+                    if (nk == 1) { a.accum_mode = 0; a.accum = nullptr; }
+                    else if (j == 0) a.accum_mode = 2;
+                    else if (j < nk - 1) a.accum_mode = 3;
+                    else a.accum_mode = 1;
+                    if (j == nk - 1) {
+                        a.out = A; a.out_scale = 1.0f / nk; a.act = ACT_LRELU; a.slope = next_slope;
+                    } else {
+                        a.out = nullptr;
+                    }
+                    c->gemm(a);
+                }
+            }
+        }
+        Cin = Cout; mul *= u;
+    }
+    // conv_post + tanh on the first mel_len*hop samples            hifigan.py:127-128, model.py:347
+    launch_conv_post_tanh(A, dt, Cin, (long)Pmax * mul * Cin, c->pf("voc.post_w"), c->t("voc.post_b").host[0], c->t("voc.post_w").dim(0),
+                          Cin, wav_dev, wav_stride, B, Lmel_max * c->hop, P_d, c->hop, mel_len_d, c->hop, c->stream);
+}
+
+// ------------------------------------------------------------------------------------------------
+// speaker encoder (ResNetSE34V2.py:176-212)
+// ------------------------------------------------------------------------------------------------
+void run_spkemb(zvx_ctx* c, const float* ref_mels, const int32_t* lens, int B, int Tmax, float* out_host) {
+    const int dt = c->dt, F0 = c->n_mels, H = c->H;
+    const size_t es = c->es();
+    for (int b = 0; b < B; b++) if (lens[b] < 2 || lens[b] > Tmax) fail(ZVX_E_INVALID, "ref mel length %d out of range (2..%d)", lens[b], Tmax);
+    c->stage_begin(ZVX_T_SPKEMB);
+    float* mels_d = c->fbuf("spk.mels", (size_t)B * Tmax * F0);
+    HIPCHK(hipMemcpyAsync(mels_d, ref_mels, (size_t)B * Tmax * F0 * 4, hipMemcpyHostToDevice, c->stream));
+    // widths per resolution level: w0 = T, w_{l+1} = (w_l - 1)/2 + 1  (3x3 stride-2 pad-1 conv)
+    std::vector<int> W(4 * (size_t)B);
+    int Wmax[4] = {Tmax, 0, 0, 0};
+    for (int b = 0; b < B; b++) { int w = lens[b]; for (int l = 0; l < 4; l++) { W[(size_t)l * B + b] = w; w = (w - 1) / 2 + 1; } }
+    for (int l = 1; l < 4; l++) Wmax[l] = (Wmax[l - 1] - 1) / 2 + 1;
+    int Fh[4]; Fh[0] = F0; for (int l = 1; l < 4; l++) Fh[l] = (Fh[l - 1] - 1) / 2 + 1;
+    int* W_d = c->upload_ints("spk.W", W.data(), W.size());
+
+    const int C0 = c->rn_filters[0];
+    size_t maxel = 0;
+    for (int l = 0; l < 4; l++) maxel = std::max(maxel, (size_t)B * Fh[l] * Wmax[l] * c->rn_filters[l]);
+    void* mA = c->buf("spk.mA", maxel * es); void* mB = c->buf("spk.mB", maxel * es);
+    void* mC = c->buf("spk.mC", maxel * es); void* mD = c->buf("spk.mD", maxel * es);
+    float* mean = c->fbuf("spk.mean", (size_t)B * 256 * 16); float* rstd = c->fbuf("spk.rstd", (size_t)B * 256 * 16);
+    float* sescale = c->fbuf("spk.sescale", (size_t)B * 1024);
+
+    // InstanceNorm1d over time (no affine) folded into the first conv          ResNetSE34V2.py:182-186
+    launch_instnorm_stats(mels_d, DT_F32, F0, B, Tmax, W_d, F0, 1e-5f, mean, rstd, c->stream);
+    launch_spk_front(mels_d, Tmax, W_d, F0, mean, rstd, c->pf("spk.c1_w"), c->pf("spk.c1_b"), c->pf("spk.bn1_s"), c->pf("spk.bn1_t"), C0,
+                     mA, dt, B, c->stream);
+    void* x = mA; void* o1 = mB; void* o2 = mC; void* rs = mD;
+    int lvl = 0, Cin = C0;
+    for (size_t li = 0; li < c->rn_layers.size(); li++) {
+        const int planes = c->rn_filters[li];
+        for (int bi = 0; bi < c->rn_layers[li]; bi++) {
+            const std::string p = "spk.l" + std::to_string(li + 1) + "." + std::to_string(bi);
+            const int stride = (li > 0 && bi == 0) ? 2 : 1;
+            const int lin = lvl, lout = (stride == 2) ? lvl + 1 : lvl;
+            const int Hin = Fh[lin], Win = Wmax[lin], Hout = Fh[lout], Wout = Wmax[lout];
+            const int* win_d = W_d + (size_t)lin * B; const int* wout_d = W_d + (size_t)lout * B;
+            auto conv3 = [&](const std::string& wn, const void* in, int cin, int hin, int win, const int* inlen, int st, void* out,
+                             const float* bias, int act, const float* ps, const float* pt, int ksz) {
+                GemmArgs a = gemm_base(dt);
+                a.X = in; a.x_bs = (long)hin * win * cin; a.ldx = cin; a.W = c->t(wn).dev; a.ldw = cin; a.w_ts = (long)planes * cin;
+                a.M = Hout * Wout; a.N = planes; a.K = cin; a.nbatch = B; a.in_len = inlen; a.out_len = wout_d;
+                a.stride = st; a.wout = Wout; a.hin = hin; a.win = win;
+                a.ntaps = ksz * ksz;
+                for (int i = 0; i < ksz; i++) for (int j = 0; j < ksz; j++) { a.du[i * ksz + j] = (short)(i - ksz / 2); a.dv[i * ksz + j] = (short)(j - ksz / 2); }
+                if (bias) { a.bias = bias; a.bias_mode = 1; }
+                a.act = act; a.post_scale = ps; a.post_shift = pt;
+                a.out = out; a.o_bs = (long)Hout * Wout * planes; a.ldo = planes;
+                c->gemm(a);
+            };
+            // conv1 -> ReLU -> BN1                                          ResNetSE34V2.py:86-88
+            conv3(p + ".c1", x, Cin, Hin, Win, win_d, stride, o1, nullptr, ACT_RELU, c->pf(p + ".bn1_s"), c->pf(p + ".bn1_t"), 3);
+            // conv2 (+ folded BN2)                                           :90-91
+            conv3(p + ".c2", o1, planes, Hout, Wout, wout_d, 1, o2, c->pf(p + ".c2_b"), ACT_NONE, nullptr, nullptr, 3);
+            // SE: global average pool -> fc -> relu -> fc -> sigmoid        :63-67
+            launch_se_pool(o2, dt, B, Hout, Wout, wout_d, planes, mean, c->stream);
+            launch_se_fc(mean, c->pf(p + ".se_w1"), c->pf(p + ".se_b1"), c->pf(p + ".se_w2"), c->pf(p + ".se_b2"), planes, planes / 8, sescale, B, c->stream);
+            const void* resid = x;
+            if (c->has(p + ".ds")) {                                          // 1x1 stride-s conv + folded BN   :94-95
+                conv3(p + ".ds", x, Cin, Hin, Win, win_d, stride, rs, c->pf(p + ".ds_b"), ACT_NONE, nullptr, nullptr, 1);
+                resid = rs;
+            }
+            launch_se_apply(o2, resid, o1, dt, sescale, B, Hout, Wout, wout_d, planes, c->stream);     // out*y + residual -> ReLU  :97-98
+            std::swap(x, o1);
+            lvl = lout; Cin = planes;
+        }
+    }
+    // attention + ASP pooling                                               ResNetSE34V2.py:195-205
+    const int Fp = Fh[3], Wp = Wmax[3], C4 = c->rn_filters[3], D = Fp * C4;
+    const int* w3_d = W_d + (size_t)3 * B;
+    void* ah = c->buf("spk.ah", (size_t)B * Wp * 128 * es);
+    float* logits = c->fbuf("spk.logits", (size_t)B * Wp * D);
+    {
+        GemmArgs a = gemm_base(dt);       // Conv1d(D -> 128) over features (f, c): one tap per frequency row of the map
+        a.X = x; a.x_bs = (long)Fp * Wp * C4; a.ldx = C4; a.W = c->t("spk.att1_w").dev; a.ldw = C4; a.w_ts = (long)128 * C4;
+        a.M = Wp; a.N = 128; a.K = C4; a.nbatch = B; a.in_len = w3_d; a.out_len = w3_d;
+        a.wout = Wp; a.hin = Fp; a.win = Wp; a.stride = 1;
+        a.ntaps = Fp; for (int f = 0; f < Fp; f++) { a.du[f] = (short)f; a.dv[f] = 0; }
+        a.bias = c->pf("spk.att1_b"); a.bias_mode = 1; a.act = ACT_RELU; a.post_scale = c->pf("spk.att_bn_s"); a.post_shift = c->pf("spk.att_bn_t");
+        a.out = ah; a.o_bs = (long)Wp * 128; a.ldo = 128;
+        c->gemm(a);
+    }
+    {
+        GemmArgs a = gemm_base(dt);
+        a.X = ah; a.x_bs = (long)Wp * 128; a.ldx = 128; a.W = c->t("spk.att2_w").dev; a.ldw = 128;
+        a.M = Wp; a.N = D; a.K = 128; a.nbatch = B; a.in_len = w3_d; a.out_len = w3_d;
+        a.bias = c->pf("spk.att2_b"); a.bias_mode = 1;
+        a.out = logits; a.out_dtype = DT_F32; a.o_bs = (long)Wp * D; a.ldo = D;
+        c->gemm(a);
+    }
+    if (!c->rn_asp) fail(ZVX_E_UNSUPPORTED, "SAP pooling is not built (the shipped configs use ASP)");
+    float* pooled = c->fbuf("spk.pooled", (size_t)B * 2 * D);
+    launch_asp_pool(x, dt, logits, B, Fp, Wp, w3_d, C4, pooled, c->stream);
+    float* emb = c->fbuf("spk.emb", (size_t)B * H);
+    {
+        GemmArgs a = gemm_base(DT_F32);
+        a.X = pooled; a.ldx = 2 * D; a.W = c->t("spk.fc_w").dev; a.ldw = 2 * D; a.M = B; a.N = H; a.K = 2 * D; a.in_len_static = B;
+        a.bias = c->pf("spk.fc_b"); a.bias_mode = 1; a.out = emb; a.ldo = H;
+        c->gemm(a);
+    }
+    launch_l2norm_rows(emb, B, H, c->stream);                                  // F.normalize   :209-210
+    c->stage_end(ZVX_T_SPKEMB);
+    HIPCHK(hipMemcpyAsync(out_host, emb, (size_t)B * H * 4, hipMemcpyDeviceToHost, c->stream));
+    c->sync();
+}
+
+// copy device rows [B][rows_max][C] (f32 contiguous) to a caller buffer with row stride
+void copy_out_rows(zvx_ctx* c, const float* src, int rows_max, int C, float* dst, long dst_rows_stride, int B, bool device_out) {
+    if (!dst) return;
+    if (dst_rows_stride < rows_max) fail(ZVX_E_BUFFER, "output row stride %ld < %d rows", dst_rows_stride, rows_max);
+    HIPCHK(hipMemcpy2DAsync(dst, (size_t)dst_rows_stride * C * 4, src, (size_t)rows_max * C * 4, (size_t)rows_max * C * 4, B,
+                            device_out ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, c->stream));
+}
+
+void do_vocode(zvx_ctx* c, const int32_t* pad_to, float* wav, int64_t wav_stride, int flags) {
+    if (!c->have_mel) fail(ZVX_E_STATE, "zvx_vocode: no mel in the context (call zvx_decode first)");
+    const int B = c->B;
+    std::vector<int> P(B);
+    int need = 0;
+    for (int b = 0; b < B; b++) { P[b] = std::max(pad_to ? pad_to[b] : 0, c->mel_len_host[b]); need = std::max(need, c->mel_len_host[b] * c->hop); }
+    if (wav_stride < need) fail(ZVX_E_BUFFER, "wav_stride %lld < %d samples", (long long)wav_stride, need);
+    c->stage_begin(ZVX_T_VOCODER);
+    float* wdev; long wstride;
+    const bool dev_out = flags & ZVX_DEVICE_OUT;
+    if (dev_out) { wdev = wav; wstride = wav_stride; }
+    else { wstride = std::max(need, 1); wdev = c->fbuf("wav", (size_t)B * wstride); }
+    run_vocoder(c, c->fbuf("mel", 0), c->n_mels, c->Lmax, c->mel_len_host.data(), P.data(), B, wdev, wstride);
+    c->stage_end(ZVX_T_VOCODER);
+    if (!dev_out && need > 0)
+        HIPCHK(hipMemcpy2DAsync(wav, (size_t)wav_stride * 4, wdev, (size_t)wstride * 4, (size_t)need * 4, B, hipMemcpyDeviceToHost, c->stream));
+    if (!(dev_out && (flags & ZVX_NO_SYNC))) c->sync();
+}
+
+template <typename F>
+zvx_status guarded(zvx_ctx* ctx, F&& f) {
+    if (!ctx) return ZVX_E_INVALID;
+    try {
+        HIPCHK(hipSetDevice(ctx->device));
+        f();
+        return ZVX_OK;
+    } catch (const ZvxError& e) {
+        ctx->err = e.what();
+        return e.code;
+    } catch (const std::exception& e) {
+        ctx->err = e.what();
+        return ZVX_E_INVALID;
+    }
+}
+
+}  // namespace
+
+// ================================================================================================
+// C-ABI
+// ================================================================================================
+extern "C" {
+
+zvx_status zvx_create(const char* manifest, const void* weights, size_t nbytes, int device, zvx_ctx** out) {
+    if (!out) return ZVX_E_INVALID;
+    *out = nullptr;
+    zvx_ctx* c = new zvx_ctx();
+    try {
+        int ndev = 0;
+        hipError_t e = hipGetDeviceCount(&ndev);
+        if (e != hipSuccess || ndev <= 0) fail(ZVX_E_HIP, "no HIP device available (%s)", hipGetErrorString(e));
+        if (device < 0 || device >= ndev) fail(ZVX_E_INVALID, "device %d out of range (%d visible)", device, ndev);
+        c->device = device;
+        HIPCHK(hipSetDevice(device));
+        HIPCHK(hipStreamCreate(&c->stream));
+        for (int s = 0; s < ZVX_T_COUNT; s++) { HIPCHK(hipEventCreate(&c->stage_ev[s][0])); HIPCHK(hipEventCreate(&c->stage_ev[s][1])); c->stage_used[s] = false; c->stage_ms[s] = 0.f; }
+        parse_manifest(c, manifest, weights, nbytes);
+        read_config(c);
+        upload_weights(c);
+        *out = c;
+        return ZVX_OK;
+    } catch (const ZvxError& e) {
+        g_create_error = e.what();
+        delete c;
+        return e.code;
+    } catch (const std::exception& e) {
+        g_create_error = e.what();
+        delete c;
+        return ZVX_E_INVALID;
+    }
+}
+
+void zvx_destroy(zvx_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (auto& kv : c->bufs) if (kv.second.p) (void)hipFree(kv.second.p);
+    for (auto e : c->event_pool) (void)hipEventDestroy(e);
+    if (c->stream) {
+        for (int s = 0; s < ZVX_T_COUNT; s++) { (void)hipEventDestroy(c->stage_ev[s][0]); (void)hipEventDestroy(c->stage_ev[s][1]); }
+        (void)hipStreamDestroy(c->stream);
+    }
+    delete c;
+}
+
+const char* zvx_last_error(const zvx_ctx* c) { return c ? c->err.c_str() : g_create_error.c_str(); }
+
+int64_t zvx_get_int(const zvx_ctx* c, const char* key) {
+    if (!c || !key) return -1;
+    const std::string k(key);
+    if (k == "precision") return c->dt == DT_F32 ? 1 : 0;
+    if (k == "hidden") return c->H;
+    if (k == "n_mels") return c->n_mels;
+    if (k == "hop") return c->hop;
+    if (k == "device") return c->device;
+    if (k == "dec_kind") return c->dec_kind;
+    if (k == "Lmax") return c->Lmax;
+    if (k == "profile") return c->profile;
+    auto it = c->cfg.find(k);
+    if (it != c->cfg.end()) return atoll(it->second.c_str());
+    return -1;
+}
+
+zvx_status zvx_set_int(zvx_ctx* c, const char* key, int64_t value) {
+    return guarded(c, [&] {
+        if (!key) fail(ZVX_E_INVALID, "key is NULL");
+        if (std::string(key) == "profile") { c->sync(); c->profile = (int)value; }
+        else fail(ZVX_E_INVALID, "unknown option '%s'", key);
+    });
+}
+
+zvx_status zvx_spkemb(zvx_ctx* c, const float* ref_mels, const int32_t* lens, int B, int Tmax, float* out) {
+    return guarded(c, [&] {
+        if (!ref_mels || !lens || !out || B <= 0 || Tmax <= 0) fail(ZVX_E_INVALID, "zvx_spkemb: bad arguments");
+        run_spkemb(c, ref_mels, lens, B, Tmax, out);
+    });
+}
+
+zvx_status zvx_encode(zvx_ctx* c, const int32_t* phoneme, const int32_t* puncts, const int32_t* duration, const int32_t* T,
+                      int B, int Tmax, const float* spk, int32_t* mel_len, float* log_duration, float* pitch, float* energy) {
+    return guarded(c, [&] {
+        if (!phoneme || !puncts || !T || !spk) fail(ZVX_E_INVALID, "zvx_encode: NULL input");
+        run_encode(c, phoneme, puncts, duration, T, B, Tmax, spk);
+        const size_t nid = (size_t)B * Tmax;
+        if (mel_len) memcpy(mel_len, c->mel_len_host.data(), B * sizeof(int));
+        if (log_duration) HIPCHK(hipMemcpyAsync(log_duration, c->fbuf("va.logd", nid), nid * 4, hipMemcpyDeviceToHost, c->stream));
+        if (pitch) HIPCHK(hipMemcpyAsync(pitch, c->fbuf("va.pitch", nid), nid * 4, hipMemcpyDeviceToHost, c->stream));
+        if (energy) HIPCHK(hipMemcpyAsync(energy, c->fbuf("va.energy", nid), nid * 4, hipMemcpyDeviceToHost, c->stream));
+        c->sync();
+    });
+}
+
+zvx_status zvx_decode(zvx_ctx* c, float* mel_out, int Lstride, int flags) {
+    return guarded(c, [&] {
+        if (!c->have_features) fail(ZVX_E_STATE, "zvx_decode: no features in the context (call zvx_encode first)");
+        const int B = c->B;
+        int* L_d = c->upload_ints("dec.L", c->mel_len_host.data(), B);
+        run_decode(c, c->fbuf("features", 0), c->fbuf("in.spk", 0), L_d, B, c->Lmax);
+        if (mel_out && c->Lmax > 0) copy_out_rows(c, c->fbuf("mel", 0), c->Lmax, c->n_mels, mel_out, Lstride, B, flags & ZVX_DEVICE_OUT);
+        c->sync();
+    });
+}
+
+zvx_status zvx_decode_features(zvx_ctx* c, const float* features, const int32_t* L, int B, int Lmax, const float* spk,
+                               float* mel_out, int Lstride) {
+    return guarded(c, [&] {
+        if (!features || !L || !spk || B <= 0 || Lmax <= 0) fail(ZVX_E_INVALID, "zvx_decode_features: bad arguments");
+        for (int b = 0; b < B; b++) if (L[b] < 2 || L[b] > Lmax) fail(ZVX_E_INVALID, "L[%d]=%d out of range (2..%d)", b, L[b], Lmax);
+        c->B = B; c->Lmax = Lmax; c->mel_len_host.assign(L, L + B); c->Tmax = 0;
+        float* f = c->fbuf("features", (size_t)B * Lmax * c->H);
+        HIPCHK(hipMemcpyAsync(f, features, (size_t)B * Lmax * c->H * 4, hipMemcpyHostToDevice, c->stream));
+        float* spk_d = c->fbuf("in.spk", (size_t)B * c->H);
+        HIPCHK(hipMemcpyAsync(spk_d, spk, (size_t)B * c->H * 4, hipMemcpyHostToDevice, c->stream));
+        int* L_d = c->upload_ints("dec.L", L, B);
+        c->have_features = true;
+        run_decode(c, f, spk_d, L_d, B, Lmax);
+        if (mel_out) copy_out_rows(c, c->fbuf("mel", 0), Lmax, c->n_mels, mel_out, Lstride, B, false);
+        c->sync();
+    });
+}
+
+zvx_status zvx_vocode(zvx_ctx* c, const int32_t* pad_to, float* wav, int64_t wav_stride, int flags) {
+    return guarded(c, [&] {
+        if (!wav) fail(ZVX_E_INVALID, "zvx_vocode: wav is NULL");
+        do_vocode(c, pad_to, wav, wav_stride, flags);
+    });
+}
+
+zvx_status zvx_vocode_mel(zvx_ctx* c, const float* mel, const int32_t* P, int B, int Pmax, float* wav, int64_t wav_stride, int flags) {
+    return guarded(c, [&] {
+        if (!mel || !P || !wav || B <= 0 || Pmax <= 0) fail(ZVX_E_INVALID, "zvx_vocode_mel: bad arguments");
+        for (int b = 0; b < B; b++) if (P[b] < 1 || P[b] > Pmax) fail(ZVX_E_INVALID, "P[%d]=%d out of range (1..%d)", b, P[b], Pmax);
+        c->B = B; c->Lmax = Pmax; c->mel_len_host.assign(P, P + B);
+        float* m = c->fbuf("mel", (size_t)B * Pmax * c->n_mels);
+        HIPCHK(hipMemcpyAsync(m, mel, (size_t)B * Pmax * c->n_mels * 4, hipMemcpyHostToDevice, c->stream));
+        c->have_mel = true;
+        do_vocode(c, nullptr, wav, wav_stride, flags);
+    });
+}
+
+zvx_status zvx_synthesize(zvx_ctx* c, const int32_t* phoneme, const int32_t* puncts, const int32_t* duration, const int32_t* T,
+                          int B, int Tmax, const float* spk, const int32_t* pad_to, int Lmax_cap, float* wav, int64_t wav_stride,
+                          int32_t* mel_len, float* mel_out, int Lstride, float* log_duration, int flags) {
+    return guarded(c, [&] {
+        if (!phoneme || !puncts || !T || !spk || !wav) fail(ZVX_E_INVALID, "zvx_synthesize: NULL input");
+        run_encode(c, phoneme, puncts, duration, T, B, Tmax, spk);
+        if (mel_len) memcpy(mel_len, c->mel_len_host.data(), B * sizeof(int));
+        if (Lmax_cap > 0 && c->Lmax > Lmax_cap) fail(ZVX_E_BUFFER, "predicted mel length %d exceeds Lmax_cap %d", c->Lmax, Lmax_cap);
+        if (log_duration) HIPCHK(hipMemcpyAsync(log_duration, c->fbuf("va.logd", 0), (size_t)B * Tmax * 4, hipMemcpyDeviceToHost, c->stream));
+        int* L_d = c->upload_ints("dec.L", c->mel_len_host.data(), B);
+        run_decode(c, c->fbuf("features", 0), c->fbuf("in.spk", 0), L_d, B, c->Lmax);
+        if (mel_out && c->Lmax > 0) copy_out_rows(c, c->fbuf("mel", 0), c->Lmax, c->n_mels, mel_out, Lstride, B, flags & ZVX_DEVICE_OUT);
+        do_vocode(c, pad_to, wav, wav_stride, flags);
+    });
+}
+
+zvx_status zvx_fetch(zvx_ctx* c, const char* what, float* out, size_t out_floats) {
+    return guarded(c, [&] {
+        if (!what || !out) fail(ZVX_E_INVALID, "zvx_fetch: NULL argument");
+        const std::string w(what);
+        const size_t nid = (size_t)c->B * c->Tmax;
+        auto copy_f = [&](const char* name, size_t n) {
+            if (out_floats < n) fail(ZVX_E_BUFFER, "zvx_fetch('%s'): need %zu floats", what, n);
+            HIPCHK(hipMemcpyAsync(out, c->fbuf(name, n), n * 4, hipMemcpyDeviceToHost, c->stream));
+            c->sync();
+        };
+        auto copy_i = [&](const char* name, size_t n) {
+            if (out_floats < n) fail(ZVX_E_BUFFER, "zvx_fetch('%s'): need %zu floats", what, n);
+            std::vector<int> tmp(n);
+            HIPCHK(hipMemcpyAsync(tmp.data(), c->ibuf(name, n), n * 4, hipMemcpyDeviceToHost, c->stream));
+            c->sync();
+            for (size_t i = 0; i < n; i++) out[i] = (float)tmp[i];
+        };
+        if (w == "encoder_out") copy_f("enc.out", nid * c->H);
+        else if (w == "features") copy_f("features", (size_t)c->B * c->Lmax * c->H);
+        else if (w == "mel") copy_f("mel", (size_t)c->B * c->Lmax * c->n_mels);
+        else if (w == "pitch") copy_f("va.pitch", nid);
+        else if (w == "energy") copy_f("va.energy", nid);
+        else if (w == "log_duration") copy_f("va.logd", nid);
+        else if (w == "pitch_idx") copy_i("va.pitch_idx", nid);
+        else if (w == "energy_idx") copy_i("va.energy_idx", nid);
+        else if (w == "duration") copy_i("va.dur", nid);
+        else fail(ZVX_E_INVALID, "zvx_fetch: unknown tensor '%s'", what);
+    });
+}
+
+zvx_status zvx_sync(zvx_ctx* c) { return guarded(c, [&] { c->sync(); }); }
+
+zvx_status zvx_stage_times(zvx_ctx* c, float ms[ZVX_T_COUNT]) {
+    return guarded(c, [&] { c->sync(); for (int s = 0; s < ZVX_T_COUNT; s++) ms[s] = c->stage_ms[s]; });
+}
+
+int zvx_kernel_stats(zvx_ctx* c, zvx_kernel_stat* out, int max_out) {
+    if (!c) return 0;
+    int n = 0;
+    guarded(c, [&] {
+        c->sync();
+        for (auto& s : c->stats) if (s.launches > 0 && n < max_out) out[n++] = s;
+    });
+    return n;
+}
+
+zvx_status zvx_reset_stats(zvx_ctx* c) {
+    return guarded(c, [&] { c->sync(); for (auto& s : c->stats) { s.launches = 0; s.ms = s.flops = s.bytes = 0; } });
+}
+
+}  // extern "C"

@@ -1,0 +1,147 @@
+// zvx_kernels.h -- launcher declarations for the gfx950 kernels of libzvx.
+// Activations are time-major [row = time][channel] in HBM, fp32 or bf16 (precision mode).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace zvx {
+
+typedef unsigned short bf16_t;   // raw bf16 bits
+
+enum DType { DT_F32 = 0, DT_BF16 = 1 };
+static inline size_t dtype_size(int dt) { return dt == DT_F32 ? 4 : 2; }
+
+enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_LRELU = 2, ACT_TANH = 3 };
+
+#define ZVX_MAX_TAPS 16
+
+// ------------------------------------------------------------------------------------------------
+// Gathered-row GEMM ("conv-GEMM"), the workhorse:
+//
+//   out[z][r][n] = epilogue( alpha * sum_tap sum_k X[z][rowmap(r, tap)][k] * W[tap][n][k] )
+//
+// X ("row operand", usually activations) and W ("col operand", usually weights, [tap][N][ldw]) are both
+// K-contiguous.  rowmap() implements 1-D convolution taps (dilated Conv1d, polyphase ConvTranspose1d,
+// plain Linear with one tap) and 2-D taps with stride (ResNet Conv2d on a [H][W][C] map):
+//     r -> (u, v) = (r / wout, r % wout);  in_u = u*stride + du[tap];  in_v = v*stride + dv[tap]
+//     valid iff 0 <= in_u < hin and 0 <= in_v < in_len[z];  X row = in_u*win + in_v  (else zero)
+// Both operands may be batched (z = batch*nheads + head) with batch and head strides, which also covers
+// Q.K^T and P.V of the attention (W := K or V^T of that (utterance, head)).
+// ------------------------------------------------------------------------------------------------
+struct GemmArgs {
+    // operands
+    const void* X; long x_bs, x_hs; int ldx;
+    const void* W; long w_bs, w_hs, w_ts; int ldw;
+    int dtype;                 // DType of X and W (same)
+    int M, N, K;               // M = max rows per z, N cols, K per tap (multiple of 8 elements bf16 / 4 f32)
+    int nbatch, nheads;
+    const int* in_len;         // [nbatch] valid input width (1-D: valid rows of X); NULL -> in_len_static
+    const int* out_len;        // [nbatch] valid output width (1-D: valid rows of out); NULL -> M
+    const int* k_len;          // [nbatch] per-batch K (rounded up to 8 internally); NULL -> K
+    int in_len_static;
+    // row map
+    int ntaps; short du[ZVX_MAX_TAPS], dv[ZVX_MAX_TAPS];
+    int stride, wout, hin, win; // wout <= 0 -> 1-D (u = 0, v = r)
+    // epilogue: v = alpha*acc + bias; v += res; v += accum; [accum = v]; v *= out_scale; v = act(v);
+    //           v = v*post_scale[n] + post_shift[n]; out = (T)v
+    float alpha;
+    const float* bias; int bias_mode;            // 0 none, 1 per n, 2 per row r
+    const void* res; long r_bs, r_hs; int ldr; int res_dtype; int res_mode;  // 0 none, 1 raw, 2 inverse leaky-relu
+    float res_inv_slope;                         // res_mode 2: x = y >= 0 ? y : y * res_inv_slope
+    float* accum; long a_bs; int lda; int accum_mode;  // bit0: v += accum, bit1: accum = v (after add)
+    float out_scale;
+    int act; float slope;
+    const float* post_scale; const float* post_shift;
+    void* out; long o_bs, o_hs; int ldo; int out_dtype;   // out may be NULL (accum only)
+    // accounting
+    double flops;              // algorithmic FLOPs of this launch (filled by the launcher)
+};
+
+// Returns the kernel-variant id used (index into gemm_variant_name) or <0 on error.
+int launch_gemm(const GemmArgs& a, hipStream_t stream);
+const char* gemm_variant_name(int id);
+int gemm_num_variants();
+
+// ------------------------------------------------------------------------------------------------
+// Small kernels (ops.hip).  T-typed pointers are void* + dtype.
+// ------------------------------------------------------------------------------------------------
+void launch_f32_to_bf16(const float* in, bf16_t* out, size_t n, hipStream_t s);
+void launch_cast(const void* in, int in_dt, void* out, int out_dt, size_t n, hipStream_t s);
+
+// encoder front: out[b][t][:] = cat(emb[ph], pemb[pu]) + pe[t]      (fs2.py:372-392)
+void launch_embed(const int* phoneme, const int* puncts, const float* emb, int emb_dim, const float* pemb,
+                  int pemb_dim, const float* pe, float* out, int B, int Tmax, const int* T, hipStream_t s);
+
+// Row LayerNorm family over C channels, one wave per row.
+//   mode 0: torch LayerNorm (biased var, eps in sqrt), gamma/beta [C]
+//   mode 1: SCLN (unbiased std, /(sigma+eps)), bg rows of stride bg_bs: beta = bg[b][0:C], gamma = bg[b][C:2C]  (fs2.py:76-90)
+// post_add [B][C] (may be NULL) is added after the affine (the style-embedding add, fs2.py:740-741).
+void launch_layernorm(const void* x, int x_dt, int ldx, void* y, int y_dt, int ldy, int B, int rows_max,
+                      const int* rows, int C, int mode, float eps, const float* gamma, const float* beta,
+                      const float* bg, long bg_bs, const float* post_add, hipStream_t s);
+
+// scores [z][L][lds] f32 -> P (dtype) [z][L][ldp]: softmax over n < len[b]; zero-fill [len, roundup8(len))
+void launch_softmax_rows(const float* scores, int lds, void* P, int p_dt, int ldp, int nbatch, int nheads,
+                         int Lmax, const int* len, hipStream_t s);
+
+// out[b][t] = dot(x[b][t][0:C], w) + bias            (VariancePredictor.linear_layer, fs2.py:553-558)
+void launch_rowdot(const float* x, int ldx, const float* w, float bias, float* out, int B, int Tmax,
+                   const int* T, int C, hipStream_t s);
+
+// idx = clamp(rint(pred*(nb-1)), 0, nb-1); x[b][t][:] += table[idx][:]     (fs2.py:639,649,668,672)
+void launch_bucket_embed_add(const float* pred, const float* table, int nbins, float* x, int ldx, int C,
+                             int* idx_out, int B, int Tmax, const int* T, hipStream_t s);
+
+// durations: forced (int) or max(rint(exp(logd)-1),0) (fs2.py:678-681) -> dur[b][t], cum[b][t] (inclusive
+// prefix sum), mel_len[b]
+void launch_durations(const int* forced, const float* logd, int* dur, int* cum, int* mel_len, int B, int Tmax,
+                      const int* T, hipStream_t s);
+
+// length regulator (fs2.py:447-455): feats[b][l][:] = x[b][src(l)][:]; optional positional table add
+// into a second output of dtype dt (decoder input): dec[b][l][:] = feats + pe[l]
+void launch_length_regulate(const float* x, int ldx, const int* cum, const int* T, const int* mel_len,
+                            float* feats, int B, int Tmax, int Lmax, int C, hipStream_t s);
+// y[b][l][c] = (T)(x[b][l][c] + (pe ? pe[l][c] : 0))
+void launch_add_pe_cast(const float* x, const float* pe, void* y, int y_dt, int ldy, int B, int Lmax,
+                        const int* L, int C, hipStream_t s);
+
+// InstanceNorm statistics over time for x [b][Lmax][ldx] channels [c0, c0+C): mean/rstd [B][C] (biased, eps)
+void launch_instnorm_stats(const void* x, int x_dt, int ldx, int B, int Lmax, const int* L, int C, float eps,
+                           float* mean, float* rstd, hipStream_t s);
+// y = act(((x-mean)*rstd) * g + b) with g = (one_plus ? 1 : 0) + gamma[b*g_bs + c], b = beta[b*g_bs + c]
+// (gamma NULL -> plain normalisation); written to y[.. ldy] (may be a column slice of a wider buffer)
+void launch_norm_affine_act(const void* x, int x_dt, int ldx, void* y, int y_dt, int ldy, int B, int Lmax,
+                            const int* L, int C, const float* mean, const float* rstd, const float* gamma,
+                            const float* beta, long g_bs, int one_plus, int act, float slope, hipStream_t s);
+
+// mel [b][Lmax][nm] (dtype) -> vocoder input [b][Pmax][ldv] dtype: rows >= mel_len zero up to P[b]
+void launch_mel_pad(const void* mel, int m_dt, int ldm, int Lmax, const int* mel_len, void* v, int v_dt,
+                    int ldv, int Pmax, const int* P, int B, int nm, hipStream_t s);
+void launch_copy_rows_f32(const void* src, int s_dt, int lds, long s_bs, float* dst, long ldd, long d_bs,
+                          int B, int rows_max, const int* rows, int C, hipStream_t s);
+
+// conv_post (C -> 1, k taps) + tanh on the activated final stage [b][Nmax][C]: wav[b][n], n < nlen[b]*hop...
+void launch_conv_post_tanh(const void* x, int x_dt, int ldx, long x_bs, const float* w /*[k][C]*/, float bias,
+                           int ktaps, int C, float* wav, long wav_bs, int B, int Nmax, const int* in_len,
+                           int len_mul, const int* out_len, int out_mul, hipStream_t s);
+
+// ---- speaker encoder ----
+// InstanceNorm1d(80) over time + Conv2d(1->C0, 3x3, pad 1) + ReLU + BN affine -> map [b][F][Tmax][C0]
+void launch_spk_front(const float* mels, int Tmax, const int* lens, int F, const float* mean, const float* rstd,
+                      const float* w /*[9][C0]*/, const float* bias, const float* bn_scale, const float* bn_shift,
+                      int C0, void* out, int o_dt, int B, hipStream_t s);
+// mean over valid (f, t) per (b, c) of map [b][H][Wmax][C]
+void launch_se_pool(const void* x, int x_dt, int B, int H, int Wmax, const int* W, int C, float* mean, hipStream_t s);
+// s = sigmoid(W2 relu(W1 m + b1) + b2) per clip
+void launch_se_fc(const float* mean, const float* w1, const float* b1, const float* w2, const float* b2, int C,
+                  int Cr, float* scale, int B, hipStream_t s);
+// y = relu(x * scale[b][c] + res)
+void launch_se_apply(const void* x, const void* res, void* y, int dt, const float* scale, int B, int H, int Wmax,
+                     const int* W, int C, hipStream_t s);
+// ASP pooling (ResNetSE34V2.py:197-205): x map [b][F][Wmax][C] viewed as [t][f*C+c]; logits [b][Wmax][F*C] f32
+// out [b][2*F*C] = [mu | sg] in (f*C+c) order
+void launch_asp_pool(const void* x, int x_dt, const float* logits, int B, int F, int Wmax, const int* W, int C,
+                     float* out, hipStream_t s);
+void launch_l2norm_rows(float* x, int B, int C, hipStream_t s);
+
+}  // namespace zvx

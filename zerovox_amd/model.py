@@ -1,0 +1,113 @@
+"""Model-level host mirror of the reference's ``ZeroVox`` inference API (model.py:308-351).
+
+``ZeroVox.inference_ex`` / ``inference`` keep the reference's argument meaning and return order; the
+computation happens in libzvx on an MI355X.  There is no CPU path: constructing the model without the
+HIP library or a GPU raises.
+"""
+from __future__ import annotations
+
+import json
+import os
+
+import numpy as np
+import yaml
+
+from . import _lib, config as zcfg, pack, weights as zw
+
+DEFAULT_MELDEC_MODEL_NAME = "zerovox-hifigan-vctk-v2-en-1"      # model.py:84
+
+
+def parse_device(infer_device) -> int:
+    """'cuda' | 'cuda:N' | 'hip:N' | int -> HIP device index.  'cpu' is refused: the product path is GPU-only."""
+    if isinstance(infer_device, int):
+        return infer_device
+    s = str(infer_device)
+    if s == "cpu":
+        raise _lib.ZvxError(_lib.ZVX_E_UNSUPPORTED, "zerovox_amd has no CPU path; use infer_device='cuda[:N]'")
+    if ":" in s:
+        return int(s.split(":")[1])
+    return 0
+
+
+def load_tts_weights(modelpath):
+    """-> (modelcfg, state_dict).  ``synthetic:<styletts|fastspeech2>[:seed]`` or a directory holding
+    ``modelcfg.yaml`` (synthesize.py:295-311) + ``weights.npz`` (tools/convert_checkpoint.py output)."""
+    spec = str(modelpath)
+    if spec.startswith("synthetic:"):
+        parts = spec.split(":")
+        cfg = zcfg.medium_modelcfg(parts[1])
+        return cfg, zw.tts_state_dict(cfg, int(parts[2]) if len(parts) > 2 else 0)
+    with open(os.path.join(spec, "modelcfg.yaml")) as f:
+        cfg = yaml.load(f, Loader=yaml.FullLoader)
+    sd = dict(np.load(os.path.join(spec, "weights.npz")))
+    return cfg, sd
+
+
+def load_meldec_weights(modelspec):
+    """-> (hifigan_cfg, state_dict).  ``synthetic:<v1|v2|v3|tiny|tiny2>[:seed]`` or a directory with
+    ``config.json`` (model.py:90-105) + ``generator.npz``."""
+    spec = str(modelspec)
+    if spec.startswith("synthetic:"):
+        parts = spec.split(":")
+        h = zcfg.hifigan_config(parts[1])
+        return h, zw.hifigan_state_dict(h, int(parts[2]) if len(parts) > 2 else 0)
+    with open(os.path.join(spec, "config.json")) as f:
+        h = json.load(f)
+    return h, dict(np.load(os.path.join(spec, "generator.npz")))
+
+
+class ZeroVox:
+    """GPU-resident model: phoneme encoder, speaker encoder, mel decoder and HiFi-GAN (model.py:206-249)."""
+
+    def __init__(self, modelcfg, tts_sd, meldec_cfg, meldec_sd, infer_device="cuda", precision="bf16", verbose=False):
+        self._modelcfg = modelcfg
+        self._hop_length = modelcfg["audio"]["hop_size"]
+        self._verbose = verbose
+        manifest, blob = pack.pack_model(modelcfg, tts_sd, meldec_cfg, meldec_sd, precision)
+        self._ctx = _lib.Context(manifest, blob, parse_device(infer_device))
+        self._min_mel_len = 689                         # model.py:254 -- stateful, see inference_ex
+        self.hidden = self._ctx.hidden
+
+    @property
+    def ctx(self):
+        return self._ctx
+
+    def _spkemb(self, x):
+        """ResNetSE34V2.forward: x [B, Tr, 80] -> [B, 1, hidden] (ResNetSE34V2.py:176-212)."""
+        x = np.asarray(x, np.float32)
+        lens = np.full(x.shape[0], x.shape[1], np.int32)
+        return self._ctx.spkemb(x, lens)[:, None, :]
+
+    def inference_ex(self, x, style_embed, normalize_before=True, force_duration=False):
+        """model.py:308-347.  x = {"phoneme" [1,T], "puncts" [1,T], "duration" [1,T]|None}; returns
+        (wav[:mel_len*hop], mel_len, log_duration [1,T], mel [n_mels, mel_len]).  Batch-1 like the reference."""
+        phoneme = np.asarray(x["phoneme"], np.int32)
+        puncts = np.asarray(x["puncts"], np.int32)
+        if phoneme.ndim != 2 or phoneme.shape[0] != 1:
+            raise ValueError("inference_ex is batch-1 (model.py:325); use synthesize_batch for batches")
+        T = np.array([phoneme.shape[1]], np.int32)
+        dur = np.asarray(x["duration"], np.int32) if (force_duration and x.get("duration") is not None) else None
+        spk = np.asarray(style_embed, np.float32).reshape(1, -1)
+        mel_len, logd, _, _ = self._ctx.encode(phoneme, puncts, T, spk, dur)
+        ml = int(mel_len[0])
+        if ml < 2:
+            # the reference raises inside InstanceNorm1d / conv stacks for degenerate lengths
+            raise ValueError(f"predicted mel length {ml} is too short to synthesise")
+        mel = self._ctx.decode(1, ml)
+        pad_to = self._min_mel_len                       # model.py:331-335: pad up, or raise the floor
+        if ml > self._min_mel_len:
+            self._min_mel_len = ml
+        wav = self._ctx.vocode(1, mel_len, np.array([pad_to], np.int32))
+        return wav[0, : ml * self._hop_length], ml, logd, np.ascontiguousarray(mel[0, :ml].T)
+
+    def inference(self, x, style_embed, normalize_before=True):
+        wav, mel_len, log_duration, _ = self.inference_ex(x=x, style_embed=style_embed, normalize_before=normalize_before)
+        return wav, mel_len, log_duration
+
+    def synthesize_batch(self, phoneme, puncts, T, style_embed, duration=None, pad_to=None, want_mel=True, Lmax_cap=0):
+        """B independent utterances in one launch sequence; each equals a batch-1 ``inference_ex`` call with
+        ``_min_mel_len == pad_to[b]`` (default: the fresh-model value 689).  Padded [B, Tmax] id arrays."""
+        B = np.asarray(phoneme).shape[0]
+        if pad_to is None:
+            pad_to = np.full(B, 689, np.int32)
+        return self._ctx.synthesize(phoneme, puncts, T, style_embed, duration, pad_to, want_mel, Lmax_cap)
