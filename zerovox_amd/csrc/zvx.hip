@@ -394,6 +394,7 @@ void variance_predictor(zvx_ctx* c, const char* nm, const float* x, int B, int T
 void run_encode(zvx_ctx* c, const int32_t* phoneme, const int32_t* puncts, const int32_t* duration, const int32_t* T,
                 int B, int Tmax, const float* spk) {
     const int H = c->H;
+    c->have_features = false; c->have_mel = false;
     if (B <= 0 || Tmax <= 0) fail(ZVX_E_INVALID, "B and Tmax must be positive");
     if (c->vp_k != 3) fail(ZVX_E_UNSUPPORTED, "vp_kernel_size != 3 changes the sequence length (fs2.py:543 padding=1)");
     c->T_host.assign(T, T + B);
