@@ -1,0 +1,27 @@
+#!/usr/bin/env python3
+"""Summarise a rocprofv3 (rocpd sqlite) kernel trace: per-kernel calls / total / average duration.
+usage: tools/rocpd_summary.py <results.db> [--grids]   (writes the table to stdout; keep it under profiles/)"""
+import sqlite3
+import sys
+
+
+def main():
+    db = sqlite3.connect(sys.argv[1])
+    cur = db.cursor()
+    rows = cur.execute("select name, count(*), sum(duration), avg(duration), min(duration), max(duration) from kernels "
+                       "group by name order by sum(duration) desc").fetchall()
+    tot = sum(r[2] for r in rows) or 1
+    print(f"{'calls':>7} {'total_ms':>10} {'avg_us':>10} {'min_us':>9} {'max_us':>9} {'pct':>6}  kernel")
+    for name, n, s, a, mn, mx in rows:
+        print(f"{n:7d} {s / 1e6:10.3f} {a / 1e3:10.2f} {mn / 1e3:9.2f} {mx / 1e3:9.2f} {100.0 * s / tot:6.2f}  {name[:150]}")
+    print(f"total kernel time {tot / 1e6:.3f} ms over {sum(r[1] for r in rows)} dispatches")
+    if "--grids" in sys.argv:
+        print("\nper (kernel, grid) breakdown:")
+        for name, gx, gy, n, s, a in cur.execute(
+                "select name, grid_x, grid_y, count(*), sum(duration), avg(duration) from kernels group by name, grid_x, grid_y "
+                "order by sum(duration) desc limit 60"):
+            print(f"{n:7d} {s / 1e6:10.3f} {a / 1e3:10.2f}  grid=({gx},{gy})  {name[:110]}")
+
+
+if __name__ == "__main__":
+    main()

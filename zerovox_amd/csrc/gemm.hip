@@ -56,6 +56,71 @@ __device__ __forceinline__ void store4_dyn(void* base, int dt, long idx, const f
     }
 }
 
+// ---- shared epilogue: lane holds, per 32x32 tile and accumulator quad g, 4 consecutive channels of one time row ----
+template <int TM, int TN>
+__device__ __forceinline__ void epilogue(const GemmArgs& a, f32x16 (&acc)[TN][TM], int b, int h, int row_base, int col_base,
+                                         int out_len, bool two_d, int lane) {
+    const long ooff = (long)b * a.o_bs + (long)h * a.o_hs;
+    const long roff = (long)b * a.r_bs + (long)h * a.r_hs;
+    const long aoff = (long)b * a.a_bs;
+#pragma unroll
+    for (int j = 0; j < TM; j++) {
+        const int r = row_base + j * 32 + (lane & 31);
+        bool rok = r < a.M;
+        if (two_d) rok = rok && (r % a.wout) < out_len; else rok = rok && r < out_len;
+        if (!rok) continue;
+        const float brow = (a.bias_mode == 2) ? a.bias[r] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TN; i++) {
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const int n = col_base + i * 32 + 8 * g + 4 * (lane >> 5);
+                if (n >= a.N) continue;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; e++) v[e] = acc[i][j][4 * g + e] * a.alpha + brow;
+                if (a.bias_mode == 1) {
+                    const float4 bb = *(const float4*)(a.bias + n);
+                    v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
+                }
+                if (a.res_mode) {
+                    float rr[4];
+                    load4_dyn(a.res, a.res_dtype, roff + (long)r * a.ldr + n, rr);
+                    if (a.res_mode == 2) {
+#pragma unroll
+                        for (int e = 0; e < 4; e++) rr[e] = rr[e] >= 0.f ? rr[e] : rr[e] * a.res_inv_slope;
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; e++) v[e] += rr[e];
+                }
+                if (a.accum_mode) {
+                    float* ap = a.accum + aoff + (long)r * a.lda + n;
+                    if (a.accum_mode & 1) {
+                        const float4 t = *(const float4*)ap;
+                        v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
+                    }
+                    if (a.accum_mode & 2) *(float4*)ap = make_float4(v[0], v[1], v[2], v[3]);
+                }
+                if (a.out) {
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        float t = v[e] * a.out_scale;
+                        if (a.act == ACT_RELU) t = fmaxf(t, 0.f);
+                        else if (a.act == ACT_LRELU) t = t >= 0.f ? t : t * a.slope;
+                        v[e] = t;
+                    }
+                    if (a.post_scale) {
+                        const float4 ps = *(const float4*)(a.post_scale + n), pt = *(const float4*)(a.post_shift + n);
+                        v[0] = v[0] * ps.x + pt.x; v[1] = v[1] * ps.y + pt.y;
+                        v[2] = v[2] * ps.z + pt.z; v[3] = v[3] * ps.w + pt.w;
+                    }
+                    store4_dyn(a.out, a.out_dtype, ooff + (long)r * a.ldo + n, v);
+                }
+            }
+        }
+    }
+}
+
 template <int DT, int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs a) {
     constexpr int ES = (DT == DT_F32) ? 4 : 2;       // element size
@@ -192,65 +257,400 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs a) {
     }
 
     // ---- epilogue ----
-    const long ooff = (long)b * a.o_bs + (long)h * a.o_hs;
-    const long roff = (long)b * a.r_bs + (long)h * a.r_hs;
-    const long aoff = (long)b * a.a_bs;
+    epilogue<TM, TN>(a, acc, b, h, m0 + wr * (BM / WM), n0 + wc * (BN / WN), out_len, two_d, lane);
+}
+
+// ---- row-major epilogue: accumulators -> per-wave LDS transpose -> every lane owns 8 consecutive channels of a row ----
+// Global traffic of the epilogue (output, residual, f32 accumulator) becomes full-line: a wave instruction
+// touches 8 (NW=64) or 16 (NW=32) rows x 128/64 contiguous bytes instead of 32 rows x 16 bytes.
+template <int TM, int TN>
+__device__ __forceinline__ void epilogue_rows(const GemmArgs& a, f32x16 (&acc)[TN][TM], int b, int row_base, int col_base,
+                                              int out_len, int lane, unsigned char* stage /* >= 32*(TN*32*4+16) bytes, this wave's */) {
+    constexpr int NW = TN * 32;                 // channels handled by this wave
+    constexpr int EP = NW * 4 + 16;             // LDS row pitch in bytes
+    constexpr int LPR = NW / 8;                 // lanes per row
+    constexpr int RPP = 64 / LPR;               // rows per pass
+    const long ooff = (long)b * a.o_bs, roff = (long)b * a.r_bs, aoff = (long)b * a.a_bs;
+    const int c8 = lane % LPR;
+    const int n = col_base + c8 * 8;
+    float bcol[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) bcol[e] = 0.f;
+    if (a.bias_mode == 1 && n < a.N) {
+        const float4 b0 = *(const float4*)(a.bias + n), b1 = *(const float4*)(a.bias + n + 4);
+        bcol[0] = b0.x; bcol[1] = b0.y; bcol[2] = b0.z; bcol[3] = b0.w; bcol[4] = b1.x; bcol[5] = b1.y; bcol[6] = b1.z; bcol[7] = b1.w;
+    }
 #pragma unroll
     for (int j = 0; j < TM; j++) {
-        const int r = m0 + wr * (BM / WM) + j * 32 + (lane & 31);
-        bool rok = r < a.M;
-        if (two_d) rok = rok && (r % a.wout) < out_len; else rok = rok && r < out_len;
-        if (!rok) continue;
-        const float brow = (a.bias_mode == 2) ? a.bias[r] : 0.f;
+        // write this wave's 32 x NW block (MFMA layout: lane = time row, 4 consecutive channels per quad)
 #pragma unroll
-        for (int i = 0; i < TN; i++) {
+        for (int i = 0; i < TN; i++)
 #pragma unroll
-            for (int g = 0; g < 4; g++) {
-                const int n = n0 + wc * (BN / WN) + i * 32 + 8 * g + 4 * (lane >> 5);
-                if (n >= a.N) continue;
-                float v[4];
+            for (int g = 0; g < 4; g++)
+                *(float4*)(stage + (lane & 31) * EP + (i * 32 + 8 * g + 4 * (lane >> 5)) * 4) =
+                    make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+        __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0): the wave's own LDS writes have landed
+        constexpr int NP = 32 / RPP;
+        // phase A: every load of the 32-row block in flight at once (branch-free: invalid lanes read element 0)
+        float v[NP][8], rr[NP][8], aa[NP][8];
+        bool ok[NP]; int rows[NP];
 #pragma unroll
-                for (int e = 0; e < 4; e++) v[e] = acc[i][j][4 * g + e] * a.alpha + brow;
-                if (a.bias_mode == 1) {
-                    const float4 bb = *(const float4*)(a.bias + n);
-                    v[0] += bb.x; v[1] += bb.y; v[2] += bb.z; v[3] += bb.w;
+        for (int p = 0; p < NP; p++) {
+            const int rl = p * RPP + lane / LPR;
+            const int r = row_base + j * 32 + rl;
+            rows[p] = r;
+            ok[p] = r < a.M && r < out_len && n < a.N;
+            const float4 v0 = *(const float4*)(stage + rl * EP + c8 * 32), v1 = *(const float4*)(stage + rl * EP + c8 * 32 + 16);
+            v[p][0] = v0.x; v[p][1] = v0.y; v[p][2] = v0.z; v[p][3] = v0.w; v[p][4] = v1.x; v[p][5] = v1.y; v[p][6] = v1.z; v[p][7] = v1.w;
+            if (a.res_mode) {
+                const long ri = ok[p] ? roff + (long)r * a.ldr + n : 0;
+                if (a.res_dtype == DT_BF16) {
+                    const uint4 t = *(const uint4*)((const unsigned short*)a.res + ri);
+                    rr[p][0] = __uint_as_float(t.x << 16); rr[p][1] = __uint_as_float(t.x & 0xffff0000u);
+                    rr[p][2] = __uint_as_float(t.y << 16); rr[p][3] = __uint_as_float(t.y & 0xffff0000u);
+                    rr[p][4] = __uint_as_float(t.z << 16); rr[p][5] = __uint_as_float(t.z & 0xffff0000u);
+                    rr[p][6] = __uint_as_float(t.w << 16); rr[p][7] = __uint_as_float(t.w & 0xffff0000u);
+                } else {
+                    const float4 t0 = *(const float4*)((const float*)a.res + ri), t1 = *(const float4*)((const float*)a.res + ri + 4);
+                    rr[p][0] = t0.x; rr[p][1] = t0.y; rr[p][2] = t0.z; rr[p][3] = t0.w; rr[p][4] = t1.x; rr[p][5] = t1.y; rr[p][6] = t1.z; rr[p][7] = t1.w;
                 }
-                if (a.res_mode) {
-                    float rr[4];
-                    load4_dyn(a.res, a.res_dtype, roff + (long)r * a.ldr + n, rr);
-                    if (a.res_mode == 2) {
+            }
+            if (a.accum_mode & 1) {
+                const long ai = ok[p] ? aoff + (long)r * a.lda + n : 0;
+                const float4 t0 = *(const float4*)(a.accum + ai), t1 = *(const float4*)(a.accum + ai + 4);
+                aa[p][0] = t0.x; aa[p][1] = t0.y; aa[p][2] = t0.z; aa[p][3] = t0.w; aa[p][4] = t1.x; aa[p][5] = t1.y; aa[p][6] = t1.z; aa[p][7] = t1.w;
+            }
+        }
+        // phase B: arithmetic + full-line stores
 #pragma unroll
-                        for (int e = 0; e < 4; e++) rr[e] = rr[e] >= 0.f ? rr[e] : rr[e] * a.res_inv_slope;
-                    }
+        for (int p = 0; p < NP; p++) {
+            const int r = rows[p];
+            const float brow = (a.bias_mode == 2 && ok[p]) ? a.bias[r] : 0.f;
 #pragma unroll
-                    for (int e = 0; e < 4; e++) v[e] += rr[e];
+            for (int e = 0; e < 8; e++) {
+                float t = v[p][e] * a.alpha + bcol[e] + brow;
+                if (a.res_mode) { float q = rr[p][e]; if (a.res_mode == 2) q = q >= 0.f ? q : q * a.res_inv_slope; t += q; }
+                if (a.accum_mode & 1) t += aa[p][e];
+                v[p][e] = t;
+            }
+            if (!ok[p]) continue;
+            if (a.accum_mode & 2) {
+                float* ap = a.accum + aoff + (long)r * a.lda + n;
+                *(float4*)ap = make_float4(v[p][0], v[p][1], v[p][2], v[p][3]);
+                *(float4*)(ap + 4) = make_float4(v[p][4], v[p][5], v[p][6], v[p][7]);
+            }
+            if (a.out) {
+#pragma unroll
+                for (int e = 0; e < 8; e++) {
+                    float t = v[p][e] * a.out_scale;
+                    if (a.act == ACT_RELU) t = fmaxf(t, 0.f);
+                    else if (a.act == ACT_LRELU) t = t >= 0.f ? t : t * a.slope;
+                    v[p][e] = t;
                 }
-                if (a.accum_mode) {
-                    float* ap = a.accum + aoff + (long)r * a.lda + n;
-                    if (a.accum_mode & 1) {
-                        const float4 t = *(const float4*)ap;
-                        v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
-                    }
-                    if (a.accum_mode & 2) *(float4*)ap = make_float4(v[0], v[1], v[2], v[3]);
-                }
-                if (a.out) {
+                if (a.post_scale) {
 #pragma unroll
-                    for (int e = 0; e < 4; e++) {
-                        float t = v[e] * a.out_scale;
-                        if (a.act == ACT_RELU) t = fmaxf(t, 0.f);
-                        else if (a.act == ACT_LRELU) t = t >= 0.f ? t : t * a.slope;
-                        v[e] = t;
-                    }
-                    if (a.post_scale) {
-                        const float4 ps = *(const float4*)(a.post_scale + n), pt = *(const float4*)(a.post_shift + n);
-                        v[0] = v[0] * ps.x + pt.x; v[1] = v[1] * ps.y + pt.y;
-                        v[2] = v[2] * ps.z + pt.z; v[3] = v[3] * ps.w + pt.w;
-                    }
-                    store4_dyn(a.out, a.out_dtype, ooff + (long)r * a.ldo + n, v);
+                    for (int e = 0; e < 8; e++) v[p][e] = v[p][e] * a.post_scale[n + e] + a.post_shift[n + e];
+                }
+                const long o = ooff + (long)r * a.ldo + n;
+                if (a.out_dtype == DT_F32) {
+                    *(float4*)((float*)a.out + o) = make_float4(v[p][0], v[p][1], v[p][2], v[p][3]);
+                    *(float4*)((float*)a.out + o + 4) = make_float4(v[p][4], v[p][5], v[p][6], v[p][7]);
+                } else {
+                    uint4 t;
+                    t.x = (unsigned)f32_to_bf16(v[p][0]) | ((unsigned)f32_to_bf16(v[p][1]) << 16);
+                    t.y = (unsigned)f32_to_bf16(v[p][2]) | ((unsigned)f32_to_bf16(v[p][3]) << 16);
+                    t.z = (unsigned)f32_to_bf16(v[p][4]) | ((unsigned)f32_to_bf16(v[p][5]) << 16);
+                    t.w = (unsigned)f32_to_bf16(v[p][6]) | ((unsigned)f32_to_bf16(v[p][7]) << 16);
+                    *(uint4*)((unsigned short*)a.out + o) = t;
                 }
             }
         }
+        __builtin_amdgcn_s_waitcnt(0xc07f);      // reads done before the next j overwrites the stage
     }
+}
+
+// ================================================================================================
+// conv-slab kernel: bf16 1-D convolutions / linears against STATIC weights.
+//
+// Each workgroup owns BM time rows x BN channels.  Per 64-channel K-chunk the input slab
+// (BM + halo rows) x 64 ch is staged ONCE into LDS and re-used by every tap (a tap is just a row offset
+// into the slab), instead of being re-staged per tap.  Weights never touch LDS: they are pre-packed at
+// load time into MFMA-fragment order ([channel tile][K-chunk][tap][k16][lane][8 bf16], 1 KiB per
+// fragment) so that a wave streams its own channel tiles with perfectly coalesced 16-byte loads straight
+// into the srcA registers, one tap ahead of the MFMAs.  The main loop has no barrier except the two
+// around each slab refill; several workgroups per CU overlap one block's refill with another's MFMAs.
+// ================================================================================================
+#define SLAB_KC 64
+#define SLAB_PITCH 144      // 128 B of channels + 16 B pad: 16 consecutive rows hit 16 distinct 16-B slots
+
+__global__ void k_pack_w(const unsigned short* w, int ntaps, int N, int K, unsigned short* out, int nkc, long total_frag_lanes) {
+    // out index: ((((nt * nkc + kc) * ntaps + tap) * 4 + k16) * 64 + lane) * 8 + e
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total_frag_lanes) return;
+    const int lane = idx & 63; long t = idx >> 6;
+    const int k16 = t & 3; t >>= 2;
+    const int tap = t % ntaps; t /= ntaps;
+    const int kc = t % nkc; const int nt = t / nkc;
+    const int n = nt * 32 + (lane & 31);
+    const int k0 = kc * SLAB_KC + k16 * 16 + 8 * (lane >> 5);
+    unsigned short v[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+        const int k = k0 + e;
+        v[e] = (n < N && k < K) ? w[((long)tap * N + n) * K + k] : (unsigned short)0;
+    }
+    uint4 o;
+    o.x = v[0] | ((unsigned)v[1] << 16); o.y = v[2] | ((unsigned)v[3] << 16);
+    o.z = v[4] | ((unsigned)v[5] << 16); o.w = v[6] | ((unsigned)v[7] << 16);
+    *(uint4*)(out + idx * 8) = o;
+}
+
+size_t packed_weight_elems(int ntaps, int N, int K) {
+    const int nkc = (K + SLAB_KC - 1) / SLAB_KC, nt = (N + 31) / 32;
+    return (size_t)nt * nkc * ntaps * 4 * 64 * 8;
+}
+void launch_pack_weights(const void* w_bf16, int ntaps, int N, int K, void* out, hipStream_t s) {
+    const int nkc = (K + SLAB_KC - 1) / SLAB_KC, nt = (N + 31) / 32;
+    const long total = (long)nt * nkc * ntaps * 4 * 64;
+    hipLaunchKernelGGL(k_pack_w, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const unsigned short*)w_bf16, ntaps, N, K,
+                       (unsigned short*)out, nkc, total);
+}
+
+template <int BM, int BN, int WM, int WN, bool FULLK, int MINW>
+__global__ __launch_bounds__(256, MINW) void convslab_kernel(const GemmArgs a) {
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int NIT = ((BM + 64) * 8 + 255) / 256;      // staging iterations (halo <= 64 rows)
+    static_assert(WM * WN == 4, "4 waves");
+    extern __shared__ __attribute__((aligned(16))) unsigned char slab[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave % WM, wc = wave / WM;
+    const int ntn = (a.N + BN - 1) / BN;
+    int wg;
+    {
+        const int nwg = gridDim.x, id = blockIdx.x, q = nwg >> 3, r = nwg & 7, xcd = id & 7;
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
+    }
+    const int nt = wg % ntn, mt = wg / ntn;
+    const int m0 = mt * BM, n0 = nt * BN;
+    const int b = blockIdx.y;
+    const int out_len = a.out_len ? a.out_len[b] : a.M;
+    const int in_len = a.in_len ? a.in_len[b] : a.in_len_static;
+    if (m0 >= out_len || m0 >= a.M) return;
+
+    const int HL = a.halo_l, SR = BM + a.halo_l + a.halo_r;
+    const int nkc = (a.K + SLAB_KC - 1) / SLAB_KC, n16 = a.K >> 4, ntaps = a.ntaps;
+    const unsigned short* Xp = (const unsigned short*)a.X + (long)b * a.x_bs;
+
+    f32x16 acc[TN][TM];
+#pragma unroll
+    for (int i = 0; i < TN; i++)
+#pragma unroll
+        for (int j = 0; j < TM; j++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
+
+    // this wave's first 32-channel tile and its packed-weight stream
+    const int nt32 = (n0 + wc * (BN / WN)) >> 5;
+    const int nt32_total = (a.N + 31) >> 5;
+    const uint4* Wq = (const uint4*)a.Wp;
+    const int xrow0 = HL + wr * (BM / WM) + (lane & 31);
+    const int koff = (lane >> 5) * 16;
+    unsigned char* ring = slab + ((SR * SLAB_PITCH + 1023) & ~1023) + wave * (4 * TN * 1024);
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)slab;   // LDS byte address of the window
+    const int dvreg = a.dv[lane & (ZVX_MAX_TAPS - 1)];              // lane t holds tap t's row offset (read back with v_readlane)
+
+    for (int kc = 0; kc < nkc; kc++) {
+        if (kc) __syncthreads();
+        // ---- stage the slab: rows [m0-HL, m0+BM+HR) x 64 channels of chunk kc (all loads in flight, then the stores) ----
+        {
+            uint4 sv[NIT];
+#pragma unroll
+            for (int it = 0; it < NIT; it++) {
+                const int c = tid + it * 256;
+                const int row = c >> 3, q = c & 7;
+                const int g = m0 - HL + row, k = kc * SLAB_KC + q * 8;
+                sv[it] = make_uint4(0, 0, 0, 0);
+                if (!(a.dbg & 4) && c < SR * 8 && g >= 0 && g < in_len && k < a.K) sv[it] = *(const uint4*)(Xp + (long)g * a.ldx + k);
+            }
+#pragma unroll
+            for (int it = 0; it < NIT; it++) {
+                const int c = tid + it * 256;
+                if (c < SR * 8) *(uint4*)(slab + (c >> 3) * SLAB_PITCH + (c & 7) * 16) = sv[it];
+            }
+        }
+        __syncthreads();
+        int nk16 = 4;
+        if (!FULLK) { nk16 = n16 - kc * 4; if (nk16 > 4) nk16 = 4; }
+
+        // ---- weights: per-wave LDS ring filled by LDS-DMA (global_load_lds, 1 KiB fragment per instruction) ----
+        // The packed weight stream of this wave's channel tiles is contiguous over (tap, k16): step st = tap*4+kk
+        // lives at wbase + st KiB and lands in ring slot kk.  DMAs run 3 steps ahead of the MFMAs; the only
+        // synchronisation is this wave's own counted vmcnt (no barrier, no VGPR staging).
+        const uint4* wbase[TN];
+#pragma unroll
+        for (int i = 0; i < TN; i++) {
+            const int t32 = nt32 + i;
+            wbase[i] = Wq + (((long)(t32 < nt32_total ? t32 : 0) * nkc + kc) * ntaps) * 4 * 64 + lane;
+        }
+        const int nsteps = ntaps * 4;
+        auto dma = [&](int st, int slot) {
+            const int sc = st < nsteps ? st : nsteps - 1;               // tail: harmless re-load, keeps the vmcnt count uniform
+#pragma unroll
+            for (int i = 0; i < TN; i++)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wbase[i] + (long)sc * 64),
+                                                 (__attribute__((address_space(3))) void*)(ring + (slot * TN + i) * 1024), 16, 0, 0);
+        };
+        // LDS reads of the main loop are inline asm: hipcc would otherwise drain every pending LDS-DMA (vmcnt(0))
+        // in front of each ds_read.  Fragments of step s+1 are read while the MFMAs of step s run (sets A/B).
+        uint4 xA[TM], wA[TN], xB[TM], wB[TN];
+        const unsigned ring_rd = (unsigned)(size_t)(ring - slab) + lane * 16;     // byte offset inside the dynamic LDS window
+        auto rd = [&](uint4 (&xf)[TM], uint4 (&wf)[TN], int slot, unsigned rowoff, int kk) {
+#pragma unroll
+            for (int i = 0; i < TN; i++)
+                asm volatile("ds_read_b128 %0, %1" : "=v"(wf[i]) : "v"(lds_base + ring_rd + (slot * TN + i) * 1024));
+#pragma unroll
+            for (int j = 0; j < TM; j++)
+                asm volatile("ds_read_b128 %0, %1" : "=v"(xf[j]) : "v"(lds_base + rowoff + j * 32 * SLAB_PITCH + kk * 32));
+        };
+        auto mma = [&](uint4 (&xf)[TM], uint4 (&wf)[TN]) {
+#pragma unroll
+            for (int i = 0; i < TN; i++)
+#pragma unroll
+                for (int j = 0; j < TM; j++)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[i]),
+                                                                       __builtin_bit_cast(bf16x8, xf[j]), acc[i][j], 0, 0, 0);
+        };
+        auto rowoff_of = [&](int tap) {
+            const int d = __builtin_amdgcn_readlane(dvreg, tap < ntaps ? tap : ntaps - 1);
+            return (unsigned)((xrow0 + d) * SLAB_PITCH + koff);
+        };
+        if (a.dbg & 2) continue;
+        dma(0, 0); dma(1, 1); dma(2, 2);
+        if (TN == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        unsigned rowoff = rowoff_of(0);
+        rd(xA, wA, 0, rowoff, 0);
+        for (int tap = 0; tap < ntaps; tap++) {
+            const unsigned rowoff_next = rowoff_of(tap + 1);
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++) {
+                dma(tap * 4 + kk + 3, (kk + 3) & 3);
+                // fragment of step s+1 must have landed: only the DMAs of steps s+2, s+3 may stay in flight
+                if (TN == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                if (kk & 1) rd(xA, wA, (kk + 1) & 3, kk == 3 ? rowoff_next : rowoff, (kk + 1) & 3);
+                else        rd(xB, wB, (kk + 1) & 3, rowoff, kk + 1);
+                // wait for THIS step's set only: the TM+TN reads just issued may remain outstanding
+                if (TM + TN == 6) asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+                else if (TM + TN == 5) asm volatile("s_waitcnt lgkmcnt(5)" ::: "memory");
+                else if (TM + TN == 3) asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");
+                else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                if (FULLK || kk < nk16) { if (kk & 1) mma(xB, wB); else mma(xA, wA); }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            rowoff = rowoff_next;
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // drain tail DMAs / reads before ring and slab are reused
+    }
+    if (a.dbg & 1) { if (acc[0][0][0] == 123.456f) ((float*)a.out)[0] = 1.f; return; }
+    __syncthreads();                             // every wave is done with the slab: its LDS becomes the transpose stage
+    epilogue_rows<TM, TN>(a, acc, b, m0 + wr * (BM / WM), n0 + wc * (BN / WN), out_len, lane, slab + wave * (32 * (TN * 32 * 4 + 16)));
+}
+
+// ================================================================================================
+// conv-reg kernel: square bf16 convolutions with few channels (C = 32 / 64: HiFi-GAN stages 3-4).
+// These layers are HBM-bound and their whole weight set is small, so each wave keeps the weight fragments
+// of its 32 output channels for ALL taps in registers (NT*C/16 fragments, loaded once, coalesced, from the
+// packed stream) and the main loop is nothing but ds_read_b128 of the LDS slab + MFMA: no weight traffic,
+// no waits on global memory, no barrier between the slab fill and the epilogue.
+// ================================================================================================
+template <int C, int NT, int BM, int WM, int WN, int MINW>
+__global__ __launch_bounds__(256, MINW) void convreg_kernel(const GemmArgs a) {
+    constexpr int TM = BM / WM / 32;
+    constexpr int KS = C / 16;                           // k16 steps per tap
+    constexpr int PITCH_ = C * 2 + 16;                   // LDS row pitch (80 B / 144 B: conflict-free b128 reads)
+    constexpr int CPR = C / 8;                           // 16-byte chunks per row
+    constexpr int NIT = ((BM + 64) * CPR + 255) / 256;
+    static_assert(WM * WN == 4 && WN * 32 == C, "wave layout");
+    extern __shared__ __attribute__((aligned(16))) unsigned char slab[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave % WM, wc = wave / WM;
+    int wg;
+    {
+        const int nwg = gridDim.x, id = blockIdx.x, q = nwg >> 3, r = nwg & 7, xcd = id & 7;
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
+    }
+    const int m0 = wg * BM, b = blockIdx.y;
+    const int out_len = a.out_len ? a.out_len[b] : a.M;
+    const int in_len = a.in_len ? a.in_len[b] : a.in_len_static;
+    if (m0 >= out_len || m0 >= a.M) return;
+    const int HL = a.halo_l, SR = BM + a.halo_l + a.halo_r;
+    const unsigned short* Xp = (const unsigned short*)a.X + (long)b * a.x_bs;
+
+    // ---- all weight fragments of this wave's 32 output channels -> registers (packed stream: [nt32][tap][4 k16 slots]) ----
+    uint4 w[NT][KS];
+    {
+        const uint4* Wq = (const uint4*)a.Wp + ((long)wc * NT * 4) * 64 + lane;
+#pragma unroll
+        for (int t = 0; t < NT; t++)
+#pragma unroll
+            for (int kk = 0; kk < KS; kk++) w[t][kk] = Wq[(t * 4 + kk) * 64];
+    }
+    // ---- slab: rows [m0-HL, m0+BM+HR) x C channels, all loads in flight, then the LDS stores ----
+    {
+        uint4 sv[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; it++) {
+            const int c = tid + it * 256;
+            const int row = c / CPR, q = c % CPR;
+            const int g = m0 - HL + row;
+            sv[it] = make_uint4(0, 0, 0, 0);
+            if (c < SR * CPR && g >= 0 && g < in_len) sv[it] = *(const uint4*)(Xp + (long)g * a.ldx + q * 8);
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; it++) {
+            const int c = tid + it * 256;
+            if (c < SR * CPR) *(uint4*)(slab + (c / CPR) * PITCH_ + (c % CPR) * 16) = sv[it];
+        }
+    }
+    __syncthreads();
+
+    f32x16 acc[1][TM];
+#pragma unroll
+    for (int j = 0; j < TM; j++)
+#pragma unroll
+        for (int e = 0; e < 16; e++) acc[0][j][e] = 0.f;
+    const int xrow0 = HL + wr * (BM / WM) + (lane & 31);
+    const int koff = (lane >> 5) * 16;
+#pragma unroll
+    for (int t = 0; t < NT; t++) {
+        const unsigned char* rowp = slab + (xrow0 + a.dv[t]) * PITCH_ + koff;
+#pragma unroll
+        for (int kk = 0; kk < KS; kk++)
+#pragma unroll
+            for (int j = 0; j < TM; j++) {
+                const uint4 xf = *(const uint4*)(rowp + j * 32 * PITCH_ + kk * 32);
+                acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w[t][kk]), __builtin_bit_cast(bf16x8, xf),
+                                                                   acc[0][j], 0, 0, 0);
+            }
+    }
+    __syncthreads();
+    epilogue_rows<TM, 1>(a, acc, b, m0 + wr * (BM / WM), wc * 32, out_len, lane, slab + wave * (32 * (32 * 4 + 16)));
+}
+
+template <int C, int BM, int WM, int WN, int MINW>
+static bool launch_convreg_c(const GemmArgs& a, hipStream_t stream) {
+    dim3 grid((a.M + BM - 1) / BM, a.nbatch);
+    size_t lds = (size_t)(BM + a.halo_l + a.halo_r) * (C * 2 + 16);
+    const size_t stage = (size_t)4 * 32 * (32 * 4 + 16);
+    if (lds < stage) lds = stage;
+    switch (a.ntaps) {
+        case 3: hipLaunchKernelGGL((convreg_kernel<C, 3, BM, WM, WN, MINW>), grid, dim3(256), lds, stream, a); return true;
+        case 7: hipLaunchKernelGGL((convreg_kernel<C, 7, BM, WM, WN, MINW>), grid, dim3(256), lds, stream, a); return true;
+        case 11: hipLaunchKernelGGL((convreg_kernel<C, 11, BM, WM, WN, MINW>), grid, dim3(256), lds, stream, a); return true;
+    }
+    return false;
 }
 
 struct Variant { const char* name; int dt, bm, bn; };
@@ -258,21 +658,83 @@ static const Variant kVariants[] = {
     {"gemm_bf16_128x128", DT_BF16, 128, 128}, {"gemm_bf16_256x64", DT_BF16, 256, 64},
     {"gemm_bf16_256x32", DT_BF16, 256, 32},   {"gemm_f32_128x128", DT_F32, 128, 128},
     {"gemm_f32_256x64", DT_F32, 256, 64},     {"gemm_f32_256x32", DT_F32, 256, 32},
+    {"convslab_bf16_128x256", DT_BF16, 128, 256}, {"convslab_bf16_256x128", DT_BF16, 256, 128},
+    {"convslab_bf16_256x64", DT_BF16, 256, 64},   {"convslab_bf16_256x32", DT_BF16, 256, 32},
+    {"convslab_bf16_64x256", DT_BF16, 64, 256},   {"convslab_bf16_128x128", DT_BF16, 128, 128},
+    {"convslab_bf16_128x64", DT_BF16, 128, 64},   {"convslab_bf16_128x32", DT_BF16, 128, 32},
+    {"convreg_bf16_c32", DT_BF16, 512, 32},       {"convreg_bf16_c64", DT_BF16, 256, 64},
 };
 const char* gemm_variant_name(int id) { return kVariants[id].name; }
 int gemm_num_variants() { return (int)(sizeof(kVariants) / sizeof(kVariants[0])); }
+
+template <int BM, int BN, int WM, int WN, int MINW>
+static void launch_slab_variant(const GemmArgs& a, dim3 grid, size_t lds, hipStream_t stream) {
+    if (a.K % SLAB_KC == 0) hipLaunchKernelGGL((convslab_kernel<BM, BN, WM, WN, true, MINW>), grid, dim3(256), lds, stream, a);
+    else hipLaunchKernelGGL((convslab_kernel<BM, BN, WM, WN, false, MINW>), grid, dim3(256), lds, stream, a);
+}
+
+static int launch_convslab(GemmArgs a, hipStream_t stream) {
+    int hl = 0, hr = 0;
+    for (int i = 0; i < a.ntaps; i++) { hl = a.dv[i] < -hl ? -a.dv[i] : hl; hr = a.dv[i] > hr ? a.dv[i] : hr; }
+    a.halo_l = hl; a.halo_r = hr;
+    static const char* noreg = getenv("ZVX_NO_CONVREG");
+    if (!noreg && a.N == a.K && (a.ntaps == 3 || a.ntaps == 7 || a.ntaps == 11)) {
+        if (a.N == 32 && launch_convreg_c<32, 512, 4, 1, 2>(a, stream)) return 14;
+        if (a.N == 64 && launch_convreg_c<64, 256, 2, 2, 2>(a, stream)) return 15;
+    }
+    // tile choice: padded N weighted by the tile's MFMA efficiency
+    static const int bns[4] = {256, 128, 64, 32};
+    static const double eff[4] = {1.0, 1.0, 0.7, 0.4};
+    int best = 0; double best_cost = -1;
+    for (int i = 0; i < 4; i++) {
+        const double cost = (double)((a.N + bns[i] - 1) / bns[i]) * bns[i] / eff[i];
+        if (best_cost < 0 || cost < best_cost - 1e-9) { best_cost = cost; best = i; }
+    }
+    static const char* set_env = getenv("ZVX_SLAB_SET");
+    const bool small = set_env && set_env[0] == 's';
+    static const int bms_large[4] = {128, 256, 256, 256}, bms_small[4] = {64, 128, 128, 128};
+    const int bn = bns[best], bm = small ? bms_small[best] : bms_large[best];
+    const int ntn = (a.N + bn - 1) / bn, ntm = (a.M + bm - 1) / bm;
+    dim3 grid(ntn * ntm, a.nbatch);
+    const int tn = (bn >= 128) ? 2 : 1;
+    size_t lds = (((size_t)(bm + hl + hr) * SLAB_PITCH + 1023) & ~(size_t)1023) + (size_t)4 * 4 * tn * 1024;
+    const size_t stage = (size_t)4 * 32 * (tn * 128 + 16);
+    if (lds < stage) lds = stage;
+    if (!small) {
+        switch (best) {
+            case 0: launch_slab_variant<128, 256, 1, 4, 2>(a, grid, lds, stream); break;
+            case 1: launch_slab_variant<256, 128, 2, 2, 2>(a, grid, lds, stream); break;
+            case 2: launch_slab_variant<256, 64, 2, 2, 2>(a, grid, lds, stream); break;
+            case 3: launch_slab_variant<256, 32, 4, 1, 2>(a, grid, lds, stream); break;
+        }
+        return 6 + best;
+    }
+    switch (best) {
+        case 0: launch_slab_variant<64, 256, 1, 4, 3>(a, grid, lds, stream); break;
+        case 1: launch_slab_variant<128, 128, 2, 2, 3>(a, grid, lds, stream); break;
+        case 2: launch_slab_variant<128, 64, 2, 2, 4>(a, grid, lds, stream); break;
+        case 3: launch_slab_variant<128, 32, 4, 1, 4>(a, grid, lds, stream); break;
+    }
+    return 10 + best;
+}
 
 int launch_gemm(const GemmArgs& a, hipStream_t stream) {
     if (a.N <= 0 || a.M <= 0 || a.nbatch <= 0) return -1;
     if (a.ntaps < 1 || a.ntaps > ZVX_MAX_TAPS) return -2;
     // N not a multiple of 4: the last 4-wide store spills into [N, roundup4(N)) of the row (ldo must cover it)
     if (a.N % 4 && (a.bias_mode == 1 || a.res_mode || a.accum_mode || a.post_scale || a.ldo < ((a.N + 3) & ~3))) return -2;
-    // tile choice: least padded N, ties -> wider BN
+    if (a.Wp && a.dtype == DT_BF16 && a.wout <= 0 && a.nheads == 1 && a.w_bs == 0 && !a.k_len && a.K % 16 == 0 && a.N % 8 == 0 && a.ldo % 8 == 0) {
+        int lo = 0, hi = 0;
+        for (int i = 0; i < a.ntaps; i++) { if (a.dv[i] < lo) lo = a.dv[i]; if (a.dv[i] > hi) hi = a.dv[i]; }
+        if (hi - lo <= 64 && hi >= 0 && lo <= 0) return launch_convslab(a, stream);
+    }
+    // tile choice: padded N weighted by the tile's MFMA efficiency, ties -> wider BN
     static const int bns[3] = {128, 64, 32};
-    int best = 0; long best_pad = -1;
+    static const double eff[3] = {1.0, 0.75, 0.45};
+    int best = 0; double best_cost = -1;
     for (int i = 0; i < 3; i++) {
-        long pad = (long)((a.N + bns[i] - 1) / bns[i]) * bns[i];
-        if (best_pad < 0 || pad < best_pad) { best_pad = pad; best = i; }
+        const double cost = (double)((a.N + bns[i] - 1) / bns[i]) * bns[i] / eff[i];
+        if (best_cost < 0 || cost < best_cost - 1e-9) { best_cost = cost; best = i; }
     }
     const int bn = bns[best], bm = (bn == 128) ? 128 : 256;
     const int ntn = (a.N + bn - 1) / bn, ntm = (a.M + bm - 1) / bm;

@@ -59,6 +59,7 @@ struct zvx_ctx {
     std::map<std::string, Tensor> tensors;
     std::vector<float> host_blob;
     std::map<std::string, DevBuf> bufs;
+    std::map<const void*, const void*> packed;   // bf16 weight tensor -> its MFMA-fragment-order copy (conv-slab kernel)
     int dt = DT_BF16;               // activation / weight dtype of the bf16-able stages
     // config
     int H = 0, emb_dim = 0, punct_dim = 0, n_phone_rows = 0, n_punct_rows = 0, max_txt_len = 0, max_mel_len = 0;
@@ -132,6 +133,8 @@ struct zvx_ctx {
 
     void gemm(GemmArgs& a) {
         if (a.flops <= 0) a.flops = 2.0 * (double)a.M * a.nbatch * a.nheads * (double)a.N * (double)a.K * a.ntaps;
+        { static const char* e = getenv("ZVX_DBG"); a.dbg = e ? atoi(e) : 0; }
+        if (!a.Wp && a.dtype == DT_BF16) { auto it = packed.find(a.W); if (it != packed.end()) a.Wp = it->second; }
         GemmEvent ev{};
         const bool prof = profile >= 2;
         if (prof) { ev.a = new_event(); ev.b = new_event(); HIPCHK(hipEventRecord(ev.a, stream)); }
@@ -176,7 +179,7 @@ GemmArgs gemm_base(int dtype) {
 }
 void set_taps_1d(GemmArgs& a, int k, int dilation) {
     a.ntaps = k;
-    for (int i = 0; i < k; i++) { a.du[i] = 0; a.dv[i] = (short)((i - (k - 1) / 2) * dilation); }
+    for (int i = 0; i < k; i++) { a.du[i] = 0; a.dv[i] = (int)((i - (k - 1) / 2) * dilation); }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -230,6 +233,25 @@ void upload_weights(zvx_ctx* c) {
         t.host = c->host_blob.data() + t.off;
         launch_cast(staging + t.off, DT_F32, t.dev, t.dtype, t.numel, c->stream);
         off += (t.numel * dtype_size(t.dtype) + 255) & ~(size_t)255;
+    }
+    // fragment-order copies of every bf16 contraction weight [taps][N][K] with K % 16 == 0
+    size_t ptotal = 0;
+    for (auto& kv : c->tensors) {
+        Tensor& t = kv.second;
+        if (t.kind == 'w' && t.dtype == DT_BF16 && t.dims.size() == 3 && t.dim(2) % 16 == 0)
+            ptotal += (packed_weight_elems(t.dim(0), t.dim(1), t.dim(2)) * 2 + 255) & ~(size_t)255;
+    }
+    if (ptotal) {
+        char* parena = (char*)c->buf("weights_packed", ptotal);
+        size_t poff = 0;
+        for (auto& kv : c->tensors) {
+            Tensor& t = kv.second;
+            if (t.kind == 'w' && t.dtype == DT_BF16 && t.dims.size() == 3 && t.dim(2) % 16 == 0) {
+                launch_pack_weights(t.dev, t.dim(0), t.dim(1), t.dim(2), parena + poff, c->stream);
+                c->packed[t.dev] = parena + poff;
+                poff += (packed_weight_elems(t.dim(0), t.dim(1), t.dim(2)) * 2 + 255) & ~(size_t)255;
+            }
+        }
     }
     HIPCHK(hipStreamSynchronize(c->stream));
     DevBuf& st = c->bufs["weights_staging"];
@@ -382,7 +404,7 @@ void variance_predictor(zvx_ctx* c, const char* nm, const float* x, int B, int T
         a.M = Tmax; a.N = Fv; a.K = Fv; a.nbatch = B; a.in_len = T_dev; a.out_len = T_dev;
         // fs2.py:543 hard-codes padding=1: taps are k - 1 for k in [0, vp_k)
         a.ntaps = c->vp_k;
-        for (int k = 0; k < c->vp_k; k++) { a.du[k] = 0; a.dv[k] = (short)(k - 1); }
+        for (int k = 0; k < c->vp_k; k++) { a.du[k] = 0; a.dv[k] = (int)(k - 1); }
         a.bias = c->pf(p + ".b2"); a.bias_mode = 1; a.act = ACT_RELU;
         a.out = h2; a.o_bs = (long)Tmax * Fv; a.ldo = Fv;
         c->gemm(a);
@@ -780,7 +802,7 @@ void run_spkemb(zvx_ctx* c, const float* ref_mels, const int32_t* lens, int B, i
                 a.M = Hout * Wout; a.N = planes; a.K = cin; a.nbatch = B; a.in_len = inlen; a.out_len = wout_d;
                 a.stride = st; a.wout = Wout; a.hin = hin; a.win = win;
                 a.ntaps = ksz * ksz;
-                for (int i = 0; i < ksz; i++) for (int j = 0; j < ksz; j++) { a.du[i * ksz + j] = (short)(i - ksz / 2); a.dv[i * ksz + j] = (short)(j - ksz / 2); }
+                for (int i = 0; i < ksz; i++) for (int j = 0; j < ksz; j++) { a.du[i * ksz + j] = (int)(i - ksz / 2); a.dv[i * ksz + j] = (int)(j - ksz / 2); }
                 if (bias) { a.bias = bias; a.bias_mode = 1; }
                 a.act = act; a.post_scale = ps; a.post_shift = pt;
                 a.out = out; a.o_bs = (long)Hout * Wout * planes; a.ldo = planes;
@@ -813,7 +835,7 @@ void run_spkemb(zvx_ctx* c, const float* ref_mels, const int32_t* lens, int B, i
         a.X = x; a.x_bs = (long)Fp * Wp * C4; a.ldx = C4; a.W = c->t("spk.att1_w").dev; a.ldw = C4; a.w_ts = (long)128 * C4;
         a.M = Wp; a.N = 128; a.K = C4; a.nbatch = B; a.in_len = w3_d; a.out_len = w3_d;
         a.wout = Wp; a.hin = Fp; a.win = Wp; a.stride = 1;
-        a.ntaps = Fp; for (int f = 0; f < Fp; f++) { a.du[f] = (short)f; a.dv[f] = 0; }
+        a.ntaps = Fp; for (int f = 0; f < Fp; f++) { a.du[f] = (int)f; a.dv[f] = 0; }
         a.bias = c->pf("spk.att1_b"); a.bias_mode = 1; a.act = ACT_RELU; a.post_scale = c->pf("spk.att_bn_s"); a.post_shift = c->pf("spk.att_bn_t");
         a.out = ah; a.o_bs = (long)Wp * 128; a.ldo = 128;
         c->gemm(a);

@@ -32,6 +32,9 @@ struct GemmArgs {
     // operands
     const void* X; long x_bs, x_hs; int ldx;
     const void* W; long w_bs, w_hs, w_ts; int ldw;
+    const void* Wp;            // optional: W pre-packed in MFMA-fragment order (launch_pack_weights) -> conv-slab kernel
+    int halo_l, halo_r;        // filled by the launcher
+    int dbg;                   // ablation switches (development only): 1 skip epilogue, 2 skip main loop, 4 skip slab loads
     int dtype;                 // DType of X and W (same)
     int M, N, K;               // M = max rows per z, N cols, K per tap (multiple of 8 elements bf16 / 4 f32)
     int nbatch, nheads;
@@ -40,7 +43,7 @@ struct GemmArgs {
     const int* k_len;          // [nbatch] per-batch K (rounded up to 8 internally); NULL -> K
     int in_len_static;
     // row map
-    int ntaps; short du[ZVX_MAX_TAPS], dv[ZVX_MAX_TAPS];
+    int ntaps; int du[ZVX_MAX_TAPS], dv[ZVX_MAX_TAPS];   // int (not short): uniform-indexed kernarg reads become s_load
     int stride, wout, hin, win; // wout <= 0 -> 1-D (u = 0, v = r)
     // epilogue: v = alpha*acc + bias; v += res; v += accum; [accum = v]; v *= out_scale; v = act(v);
     //           v = v*post_scale[n] + post_shift[n]; out = (T)v
@@ -59,6 +62,9 @@ struct GemmArgs {
 
 // Returns the kernel-variant id used (index into gemm_variant_name) or <0 on error.
 int launch_gemm(const GemmArgs& a, hipStream_t stream);
+// fragment-order packing of a bf16 weight [ntaps][N][K] for the conv-slab kernel
+size_t packed_weight_elems(int ntaps, int N, int K);
+void launch_pack_weights(const void* w_bf16, int ntaps, int N, int K, void* out, hipStream_t s);
 const char* gemm_variant_name(int id);
 int gemm_num_variants();
 
