@@ -33,16 +33,16 @@ def cpu_baseline(cfg, sd, hcfg, hsd, T, pad_to):
     this box's host cores.  Bounded sample: ~10-30 s of CPU work."""
     from oracle import zvx_oracle as O            # checker / baseline only -- never on the product path
     from zerovox_amd import synthetic
-    try:
-        from threadpoolctl import threadpool_info
-        cores = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
-    except Exception:
-        cores = os.cpu_count() or 1
+    from threadpoolctl import threadpool_limits
+    # OpenBLAS stops scaling on these skinny conv GEMMs: measured on the 256-thread GPU box, 8-16 threads are
+    # fastest and 64+ are 1.6x slower (tools/cpu_threads_probe.py), so the baseline is pinned to 16 threads.
+    cores = min(16, os.cpu_count() or 1)
     ph, pu, spk, dur = synthetic.utterance(T, 0, "const7")
-    O.hifigan_generator(np.zeros((80, 8), np.float32), hsd, hcfg)      # BLAS thread-pool warm-up
-    t0 = time.time()
-    out = O.inference_ex(sd, hsd, cfg, hcfg, ph, pu, spk, duration=dur, pad_to=pad_to)
-    dt = time.time() - t0
+    with threadpool_limits(limits=cores):
+        O.hifigan_generator(np.zeros((80, 8), np.float32), hsd, hcfg)      # BLAS thread-pool warm-up
+        t0 = time.time()
+        out = O.inference_ex(sd, hsd, cfg, hcfg, ph, pu, spk, duration=dur, pad_to=pad_to)
+        dt = time.time() - t0
     return {"value": len(out["wav"]) / dt, "unit": "samples/s", "cores": int(cores), "kind": "port",
             "sample": f"1 utterance of the workload ({T} phonemes -> {out['mel_len']} frames -> {len(out['wav'])} "
                       f"samples) through oracle/zvx_oracle.py (NumPy/BLAS fp32) in {dt:.1f} s",
@@ -155,8 +155,14 @@ def main():
             avg_ms = dom["ms"] / dom["launches"]
             achieved = dom["flops"] / dom["launches"] / (avg_ms * 1e-3) / 1e12
             peak = MFMA_PEAK[args.precision]
+            traffic = None
+            try:    # per-launch HBM bytes of this kernel from the committed rocprofv3 PMC passes of the same command
+                tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+                traffic = tj.get(dom["name"], {}).get("hbm_bytes_per_launch")
+            except Exception:
+                pass
             res["roofline"] = {"bound": "mfma", "kernel": dom["name"], "achieved": achieved, "peak": peak,
-                               "unit": "TFLOP/s", "frac": achieved / peak, "traffic": None,
+                               "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
                                "launches": dom["launches"], "avg_launch_ms": avg_ms,
                                "flops_per_launch": dom["flops"] / dom["launches"],
                                "alg_bytes_per_launch": dom["bytes"] / dom["launches"],

@@ -23,5 +23,23 @@ def main():
             print(f"{n:7d} {s / 1e6:10.3f} {a / 1e3:10.2f}  grid=({gx},{gy})  {name[:110]}")
 
 
+
+
+def pmc_summary(path):
+    """Per-kernel averages of every PMC counter in a rocprofv3 --pmc results db."""
+    db = sqlite3.connect(path)
+    cur = db.cursor()
+    rows = cur.execute("select kernel_name, counter_name, count(*), sum(value), avg(value), avg(duration) from counters_collection "
+                       "group by kernel_name, counter_name order by sum(value) desc").fetchall()
+    print(f"{'launches':>8} {'sum':>16} {'avg/launch':>14} {'avg_us':>9}  counter  kernel")
+    for kn, cn, n, sm, av, du in rows:
+        if sm and sm > 0:
+            print(f"{n:8d} {sm:16.1f} {av:14.2f} {du / 1e3:9.2f}  {cn:28s} {kn[:110]}")
+    return rows
+
+
 if __name__ == "__main__":
-    main()
+    if "--pmc" in sys.argv:
+        pmc_summary(sys.argv[1])
+    else:
+        main()

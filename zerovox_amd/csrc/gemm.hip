@@ -653,6 +653,165 @@ static bool launch_convreg_c(const GemmArgs& a, hipStream_t stream) {
     return false;
 }
 
+// ================================================================================================
+// resfuse kernel: one HiFi-GAN ResBlock1 iteration (hifigan.py:51-55) in a single launch for C = 32 / 64:
+//     xt = lrelu(conv1_dilated(lrelu(x)) + b1)  -> stays in LDS (bf16)  ->  x' = conv2(xt) + b2 + x
+// x arrives in the activated domain (lrelu(x)); the tile's conv1 output (BM rows incl. conv2's halo) never
+// leaves the CU, which removes 3 of the 5 HBM passes of the unfused pair.  Weights of both convs live in
+// registers (conv2's are fetched while conv1's results are written to LDS).
+// ================================================================================================
+template <int C, int NT, int BM, int WM, int WN, int MINW>
+__global__ __launch_bounds__(256, MINW) void resfuse_kernel(const GemmArgs a) {
+    constexpr int TM = BM / WM / 32;
+    constexpr int KS = C / 16;
+    constexpr int PITCH_ = C * 2 + 16;
+    constexpr int CPR = C / 8;
+    constexpr int H2 = (NT - 1) / 2;                      // conv2 halo (dilation 1)
+    constexpr int BMO = BM - 2 * H2;                      // output rows per tile
+    constexpr int NIT = ((BM + 64) * CPR + 255) / 256;
+    static_assert(WM * WN == 4 && WN * 32 == C, "wave layout");
+    extern __shared__ __attribute__((aligned(16))) unsigned char slab[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave % WM, wc = wave / WM;
+    int wg;
+    {
+        const int nwg = gridDim.x, id = blockIdx.x, q = nwg >> 3, r = nwg & 7, xcd = id & 7;
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
+    }
+    const int m0 = wg * BMO, b = blockIdx.y;
+    const int out_len = a.out_len ? a.out_len[b] : a.M;
+    const int in_len = a.in_len ? a.in_len[b] : a.in_len_static;
+    if (m0 >= out_len || m0 >= a.M) return;
+    const int H1 = a.halo_l;                              // conv1 halo = dilation*(NT-1)/2 (symmetric)
+    const int SR = BM + 2 * H1;
+    unsigned char* t1 = slab + ((SR * PITCH_ + 15) & ~15);
+    const unsigned short* Xp = (const unsigned short*)a.X + (long)b * a.x_bs;
+
+    uint4 w[NT][KS];
+    {
+        const uint4* Wq = (const uint4*)a.Wp2 + ((long)wc * NT * 4) * 64 + lane;
+#pragma unroll
+        for (int t = 0; t < NT; t++)
+#pragma unroll
+            for (int kk = 0; kk < KS; kk++) w[t][kk] = Wq[(t * 4 + kk) * 64];
+    }
+    {   // slab rows s <-> global row m0 - H2 - H1 + s
+        uint4 sv[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; it++) {
+            const int c = tid + it * 256;
+            const int row = c / CPR, q = c % CPR;
+            const int g = m0 - H2 - H1 + row;
+            sv[it] = make_uint4(0, 0, 0, 0);
+            if (c < SR * CPR && g >= 0 && g < in_len) sv[it] = *(const uint4*)(Xp + (long)g * a.ldx + q * 8);
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; it++) {
+            const int c = tid + it * 256;
+            if (c < SR * CPR) *(uint4*)(slab + (c / CPR) * PITCH_ + (c % CPR) * 16) = sv[it];
+        }
+    }
+    __syncthreads();
+
+    f32x16 acc[1][TM];
+    const int koff = (lane >> 5) * 16;
+    const int wrow = wr * (BM / WM);
+    // ---- conv1 (dilated): T1 row i <-> global row m0 - H2 + i, reads slab rows i + H1 + dv1[t] ----
+#pragma unroll
+    for (int j = 0; j < TM; j++)
+#pragma unroll
+        for (int e = 0; e < 16; e++) acc[0][j][e] = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT; t++) {
+        const unsigned char* rowp = slab + (wrow + (lane & 31) + H1 + a.dv1[t]) * PITCH_ + koff;
+#pragma unroll
+        for (int kk = 0; kk < KS; kk++)
+#pragma unroll
+            for (int j = 0; j < TM; j++) {
+                const uint4 xf = *(const uint4*)(rowp + j * 32 * PITCH_ + kk * 32);
+                acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w[t][kk]), __builtin_bit_cast(bf16x8, xf),
+                                                                   acc[0][j], 0, 0, 0);
+            }
+    }
+    // conv2's weights replace conv1's in the same registers while T1 is written
+    {
+        const uint4* Wq = (const uint4*)a.Wp + ((long)wc * NT * 4) * 64 + lane;
+#pragma unroll
+        for (int t = 0; t < NT; t++)
+#pragma unroll
+            for (int kk = 0; kk < KS; kk++) w[t][kk] = Wq[(t * 4 + kk) * 64];
+    }
+    // ---- T1 = lrelu(acc + b1) as bf16, zero outside the sequence (conv2 zero-pads ITS input, hifigan.py:39-44) ----
+#pragma unroll
+    for (int j = 0; j < TM; j++) {
+        const int i = wrow + j * 32 + (lane & 31);
+        const int g = m0 - H2 + i;
+        const bool inside = g >= 0 && g < in_len;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int co = wc * 32 + 8 * q + 4 * (lane >> 5);
+            const float4 bb = *(const float4*)(a.bias1 + co);
+            float v[4] = {acc[0][j][4 * q] + bb.x, acc[0][j][4 * q + 1] + bb.y, acc[0][j][4 * q + 2] + bb.z, acc[0][j][4 * q + 3] + bb.w};
+#pragma unroll
+            for (int e = 0; e < 4; e++) { v[e] = v[e] >= 0.f ? v[e] : v[e] * a.slope1; if (!inside) v[e] = 0.f; }
+            uint2 pk;
+            pk.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
+            pk.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+            *(uint2*)(t1 + i * PITCH_ + co * 2) = pk;
+        }
+    }
+    __syncthreads();
+    // ---- conv2 (dilation 1): output row j <-> global m0 + j, reads T1 rows j + H2 + dv[t] ----
+#pragma unroll
+    for (int j = 0; j < TM; j++)
+#pragma unroll
+        for (int e = 0; e < 16; e++) acc[0][j][e] = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT; t++) {
+        const unsigned char* rowp = t1 + (wrow + (lane & 31) + H2 + a.dv[t]) * PITCH_ + koff;
+#pragma unroll
+        for (int kk = 0; kk < KS; kk++)
+#pragma unroll
+            for (int j = 0; j < TM; j++) {
+                const uint4 xf = *(const uint4*)(rowp + j * 32 * PITCH_ + kk * 32);
+                acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w[t][kk]), __builtin_bit_cast(bf16x8, xf),
+                                                                   acc[0][j], 0, 0, 0);
+            }
+    }
+    __syncthreads();                                       // slab + T1 are dead: the slab area becomes the transpose stage
+    const int lim = (m0 + BMO < out_len) ? m0 + BMO : out_len;
+    epilogue_rows<TM, 1>(a, acc, b, m0 + wrow, wc * 32, lim, lane, slab + wave * (32 * (32 * 4 + 16)));
+}
+
+template <int C, int BM, int WM, int WN, int MINW>
+static bool launch_resfuse_c(const GemmArgs& a, hipStream_t stream) {
+    const int h2 = (a.ntaps - 1) / 2, bmo = BM - 2 * h2;
+    dim3 grid((a.M + bmo - 1) / bmo, a.nbatch);
+    const size_t pitch = C * 2 + 16;
+    size_t lds = (((size_t)(BM + 2 * a.halo_l) * pitch + 15) & ~(size_t)15) + (size_t)(BM + 2 * h2 + 32) * pitch;
+    switch (a.ntaps) {
+        case 3: hipLaunchKernelGGL((resfuse_kernel<C, 3, BM, WM, WN, MINW>), grid, dim3(256), lds, stream, a); return true;
+        case 7: hipLaunchKernelGGL((resfuse_kernel<C, 7, BM, WM, WN, MINW>), grid, dim3(256), lds, stream, a); return true;
+        case 11: hipLaunchKernelGGL((resfuse_kernel<C, 11, BM, WM, WN, MINW>), grid, dim3(256), lds, stream, a); return true;
+    }
+    return false;
+}
+
+// Fused ResBlock1 pair; returns the variant id or -1 when the shape is not covered (caller then issues the two convs).
+int launch_resfuse(GemmArgs a, hipStream_t stream) {
+    if (a.dtype != DT_BF16 || !a.Wp || !a.Wp2 || a.N != a.K || a.nheads != 1 || a.wout > 0) return -1;
+    if (!(a.ntaps == 3 || a.ntaps == 7 || a.ntaps == 11)) return -1;
+    int h1 = 0;
+    for (int i = 0; i < a.ntaps; i++) { const int d = a.dv1[i] < 0 ? -a.dv1[i] : a.dv1[i]; if (d > h1) h1 = d; }
+    if (h1 > 32) return -1;
+    a.halo_l = a.halo_r = h1;
+    a.fused = 1;
+    if (a.N == 32 && launch_resfuse_c<32, 256, 4, 1, 2>(a, stream)) return 16;
+    if (a.N == 64 && launch_resfuse_c<64, 128, 2, 2, 2>(a, stream)) return 17;
+    return -1;
+}
+
 struct Variant { const char* name; int dt, bm, bn; };
 static const Variant kVariants[] = {
     {"gemm_bf16_128x128", DT_BF16, 128, 128}, {"gemm_bf16_256x64", DT_BF16, 256, 64},
@@ -663,6 +822,7 @@ static const Variant kVariants[] = {
     {"convslab_bf16_64x256", DT_BF16, 64, 256},   {"convslab_bf16_128x128", DT_BF16, 128, 128},
     {"convslab_bf16_128x64", DT_BF16, 128, 64},   {"convslab_bf16_128x32", DT_BF16, 128, 32},
     {"convreg_bf16_c32", DT_BF16, 512, 32},       {"convreg_bf16_c64", DT_BF16, 256, 64},
+    {"resfuse_bf16_c32", DT_BF16, 256, 32},       {"resfuse_bf16_c64", DT_BF16, 128, 64},
 };
 const char* gemm_variant_name(int id) { return kVariants[id].name; }
 int gemm_num_variants() { return (int)(sizeof(kVariants) / sizeof(kVariants[0])); }

@@ -212,33 +212,53 @@ void launch_add_pe_cast(const float* x, const float* pe, void* y, int y_dt, int 
 }
 
 // ---------------------------------------------------------------- per-(utterance, channel) statistics over valid rows
-// x [b][H*Wmax][ldx]; row r valid iff (r % Wmax) < W[b].  4 row-groups x 64 channels per block, two passes.
-__global__ void k_colstats(const void* x, int xdt, int ldx, int H, int Wmax, const int* W, int C, float eps, float* mean, float* rstd) {
-    __shared__ float red[4][64];
-    const int b = blockIdx.y, c = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
+// x [b][H*Wmax][ldx]; row r valid iff (r % Wmax) < W[b].  Block = 32 row-groups x 8 lanes, each lane owns 8
+// consecutive channels (one 16-byte load per row for bf16); single pass with a per-channel shift (the first
+// valid row) so that sum / sum-of-squares do not cancel; LDS tree over the row-groups.
+__global__ __launch_bounds__(256) void k_colstats(const void* x, int xdt, int ldx, int H, int Wmax, const int* W, int C, float eps,
+                                                  float* mean, float* rstd) {
+    __shared__ float red[2][32][65];
+    const int b = blockIdx.y, cl = (threadIdx.x & 7) * 8, c0 = blockIdx.x * 64 + cl, g = threadIdx.x >> 3;
     const int Wb = W[b];
     const long base = (long)b * H * Wmax * ldx;
-    const bool cok = c < C;
-    float s = 0.f;
-    for (int hh = 0; hh < H; hh++)
-        for (int w = g; w < Wb; w += 4) if (cok) s += ld(x, xdt, base + ((long)hh * Wmax + w) * ldx + c);
-    red[g][threadIdx.x & 63] = s;
-    __syncthreads();
-    const float cnt = (float)H * (float)Wb;
-    const float mu = (red[0][threadIdx.x & 63] + red[1][threadIdx.x & 63] + red[2][threadIdx.x & 63] + red[3][threadIdx.x & 63]) / cnt;
-    __syncthreads();
-    float q = 0.f;
-    if (rstd) {
+    float s1[8], s2[8], sh[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) { s1[e] = 0.f; s2[e] = 0.f; sh[e] = 0.f; }
+    const bool cok = c0 < C;                                  // C % 8 == 0 for every caller
+    auto load8 = [&](long off, float v[8]) {
+        if (xdt == DT_BF16) {
+            const uint4 t = *(const uint4*)((const unsigned short*)x + off);
+            v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u);
+            v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
+            v[4] = __uint_as_float(t.z << 16); v[5] = __uint_as_float(t.z & 0xffff0000u);
+            v[6] = __uint_as_float(t.w << 16); v[7] = __uint_as_float(t.w & 0xffff0000u);
+        } else {
+            const float4 t0 = *(const float4*)((const float*)x + off), t1 = *(const float4*)((const float*)x + off + 4);
+            v[0] = t0.x; v[1] = t0.y; v[2] = t0.z; v[3] = t0.w; v[4] = t1.x; v[5] = t1.y; v[6] = t1.z; v[7] = t1.w;
+        }
+    };
+    if (cok && Wb > 0) load8(base + c0, sh);                  // shift = row 0 of this utterance (valid: Wb > 0)
+    if (cok)
         for (int hh = 0; hh < H; hh++)
-            for (int w = g; w < Wb; w += 4) if (cok) { float d = ld(x, xdt, base + ((long)hh * Wmax + w) * ldx + c) - mu; q += d * d; }
-        red[g][threadIdx.x & 63] = q;
-        __syncthreads();
-    }
-    if (g == 0 && cok) {
-        mean[(long)b * C + c] = mu;
-        if (rstd) {
-            const float var = (red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]) / cnt;
-            rstd[(long)b * C + c] = 1.0f / sqrtf(var + eps);          // InstanceNorm1d: biased var, eps 1e-5
+            for (int w = g; w < Wb; w += 32) {
+                float v[8];
+                load8(base + ((long)hh * Wmax + w) * ldx + c0, v);
+#pragma unroll
+                for (int e = 0; e < 8; e++) { const float d = v[e] - sh[e]; s1[e] += d; s2[e] += d * d; }
+            }
+#pragma unroll
+    for (int e = 0; e < 8; e++) { red[0][g][cl + e] = s1[e]; red[1][g][cl + e] = s2[e]; }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int c = blockIdx.x * 64 + threadIdx.x;
+        float a1 = 0.f, a2 = 0.f;
+        for (int i = 0; i < 32; i++) { a1 += red[0][i][threadIdx.x]; a2 += red[1][i][threadIdx.x]; }
+        if (c < C) {
+            const float cnt = (float)H * (float)Wb;
+            const float shift = ld(x, xdt, base + c);
+            const float m1 = a1 / cnt;
+            mean[(long)b * C + c] = shift + m1;
+            if (rstd) rstd[(long)b * C + c] = 1.0f / sqrtf(fmaxf(a2 / cnt - m1 * m1, 0.f) + eps);   // biased var (InstanceNorm1d)
         }
     }
 }

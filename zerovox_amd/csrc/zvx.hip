@@ -138,7 +138,7 @@ struct zvx_ctx {
         GemmEvent ev{};
         const bool prof = profile >= 2;
         if (prof) { ev.a = new_event(); ev.b = new_event(); HIPCHK(hipEventRecord(ev.a, stream)); }
-        int id = launch_gemm(a, stream);
+        int id = a.fused ? launch_resfuse(a, stream) : launch_gemm(a, stream);
         if (id < 0) fail(ZVX_E_INVALID, "launch_gemm rejected shape M=%d N=%d K=%d taps=%d", a.M, a.N, a.K, a.ntaps);
         if (prof) {
             HIPCHK(hipEventRecord(ev.b, stream));
@@ -706,9 +706,24 @@ void run_vocoder(zvx_ctx* c, const float* mel, int ldm, int Lmel_max, const int*
                 GemmArgs a = gemm_base(dt);
                 a.M = rows; a.N = Cout; a.K = Cout; a.nbatch = B; a.in_len = len; a.out_len = len; a.ldw = Cout; a.w_ts = (long)Cout * Cout;
                 a.x_bs = (long)rows * Cout; a.ldx = Cout; a.o_bs = (long)rows * Cout; a.ldo = Cout;
+                bool fuse = false;
                 if (c->voc_resblock == 1) {
+                    const Tensor& w1 = c->t(rb + ".c1_" + std::to_string(t) + "_w");
+                    const Tensor& w2 = c->t(rb + ".c2_" + std::to_string(t) + "_w");
+                    static const char* nofuse = getenv("ZVX_NO_RESFUSE");
+                    fuse = !nofuse && dt == DT_BF16 && (Cout == 32 || Cout == 64) && (k == 3 || k == 7 || k == 11) && dil[t] * (k - 1) / 2 <= 32 &&
+                           c->packed.count(w1.dev) && c->packed.count(w2.dev);
+                    if (fuse) {
+                        // one launch: xt = lrelu(c1(x_act)+b1) stays in LDS; x' = c2(xt) + b2 + x      hifigan.py:51-55
+                        a.X = cur; a.W = w2.dev; a.Wp = c->packed[w2.dev]; a.Wp2 = c->packed[w1.dev];
+                        a.bias1 = c->pf(rb + ".c1_" + std::to_string(t) + "_b"); a.slope1 = 0.1f; a.fused = 1;
+                        set_taps_1d(a, k, 1);
+                        for (int i = 0; i < k; i++) a.dv1[i] = (i - (k - 1) / 2) * dil[t];
+                        a.bias = c->pf(rb + ".c2_" + std::to_string(t) + "_b");
+                        a.flops = 2.0 * 2.0 * B * (double)rows * Cout * Cout * k;
+                    } else {
                     // xt = c1(lrelu(x)); stored as lrelu(xt)                       hifigan.py:51-53
-                    a.X = cur; a.W = c->t(rb + ".c1_" + std::to_string(t) + "_w").dev;
+                    a.X = cur; a.W = w1.dev;
                     set_taps_1d(a, k, dil[t]);
                     a.bias = c->pf(rb + ".c1_" + std::to_string(t) + "_b"); a.bias_mode = 1; a.act = ACT_LRELU; a.slope = 0.1f;
                     a.out = T1;
@@ -717,9 +732,10 @@ void run_vocoder(zvx_ctx* c, const float* mel, int ldm, int Lmel_max, const int*
                     a = gemm_base(dt);
                     a.M = rows; a.N = Cout; a.K = Cout; a.nbatch = B; a.in_len = len; a.out_len = len; a.ldw = Cout; a.w_ts = (long)Cout * Cout;
                     a.x_bs = (long)rows * Cout; a.ldx = Cout; a.o_bs = (long)rows * Cout; a.ldo = Cout;
-                    a.X = T1; a.W = c->t(rb + ".c2_" + std::to_string(t) + "_w").dev;
+                    a.X = T1; a.W = w2.dev;
                     set_taps_1d(a, k, 1);
                     a.bias = c->pf(rb + ".c2_" + std::to_string(t) + "_b");
+                    }
                 } else {
                     // x = c(lrelu(x)) + x                                          hifigan.py:78-81
                     a.X = cur; a.W = c->t(rb + ".c_" + std::to_string(t) + "_w").dev;

@@ -34,6 +34,8 @@ struct GemmArgs {
     const void* W; long w_bs, w_hs, w_ts; int ldw;
     const void* Wp;            // optional: W pre-packed in MFMA-fragment order (launch_pack_weights) -> conv-slab kernel
     int halo_l, halo_r;        // filled by the launcher
+    // fused ResBlock1 pair (resfuse kernel): out = epilogue(conv2(lrelu(conv1(X) + bias1)) + bias + inverse_lrelu(X))
+    const void* Wp2; const float* bias1; int dv1[ZVX_MAX_TAPS]; int fused; float slope1;   // conv1: Wp2/bias1/dv1 (dilated); conv2: Wp/bias/dv
     int dbg;                   // ablation switches (development only): 1 skip epilogue, 2 skip main loop, 4 skip slab loads
     int dtype;                 // DType of X and W (same)
     int M, N, K;               // M = max rows per z, N cols, K per tap (multiple of 8 elements bf16 / 4 f32)
@@ -62,6 +64,8 @@ struct GemmArgs {
 
 // Returns the kernel-variant id used (index into gemm_variant_name) or <0 on error.
 int launch_gemm(const GemmArgs& a, hipStream_t stream);
+// fused HiFi-GAN ResBlock1 pair (conv1 -> lrelu -> conv2 -> + x) for C = 32 / 64 bf16; -1 if the shape is not covered
+int launch_resfuse(GemmArgs a, hipStream_t stream);
 // fragment-order packing of a bf16 weight [ntaps][N][K] for the conv-slab kernel
 size_t packed_weight_elems(int ntaps, int N, int K);
 void launch_pack_weights(const void* w_bf16, int ntaps, int N, int K, void* out, hipStream_t s);
