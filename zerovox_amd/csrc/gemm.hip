@@ -20,6 +20,7 @@ namespace zvx {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;   // native vector: usable as a tied ("+v") inline-asm operand
 
 #define PITCH 80      // bytes per LDS row: 64 B of K + 16 B pad
 #define KBYTES 64
@@ -263,9 +264,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs a) {
 // ---- row-major epilogue: accumulators -> per-wave LDS transpose -> every lane owns 8 consecutive channels of a row ----
 // Global traffic of the epilogue (output, residual, f32 accumulator) becomes full-line: a wave instruction
 // touches 8 (NW=64) or 16 (NW=32) rows x 128/64 contiguous bytes instead of 32 rows x 16 bytes.
-template <int TM, int TN>
+template <int TM, int TN, bool RES_LDS = false>
 __device__ __forceinline__ void epilogue_rows(const GemmArgs& a, f32x16 (&acc)[TN][TM], int b, int row_base, int col_base,
-                                              int out_len, int lane, unsigned char* stage /* >= 32*(TN*32*4+16) bytes, this wave's */) {
+                                              int out_len, int lane, unsigned char* stage /* >= 32*(TN*32*4+16) bytes, this wave's */,
+                                              const unsigned char* res_lds = nullptr /* RES_LDS: LDS row of output row `row_base` */,
+                                              int res_pitch = 0) {
     constexpr int NW = TN * 32;                 // channels handled by this wave
     constexpr int EP = NW * 4 + 16;             // LDS row pitch in bytes
     constexpr int LPR = NW / 8;                 // lanes per row
@@ -302,7 +305,14 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs& a, f32x16 (&acc)[T
             ok[p] = r < a.M && r < out_len && n < a.N;
             const float4 v0 = *(const float4*)(stage + rl * EP + c8 * 32), v1 = *(const float4*)(stage + rl * EP + c8 * 32 + 16);
             v[p][0] = v0.x; v[p][1] = v0.y; v[p][2] = v0.z; v[p][3] = v0.w; v[p][4] = v1.x; v[p][5] = v1.y; v[p][6] = v1.z; v[p][7] = v1.w;
-            if (a.res_mode) {
+            if (RES_LDS) {
+                // residual = this tile's own (activated) input rows, still resident in the LDS slab
+                const uint4 t = *(const uint4*)(res_lds + (j * 32 + rl) * res_pitch + (col_base + c8 * 8) * 2);
+                rr[p][0] = __uint_as_float(t.x << 16); rr[p][1] = __uint_as_float(t.x & 0xffff0000u);
+                rr[p][2] = __uint_as_float(t.y << 16); rr[p][3] = __uint_as_float(t.y & 0xffff0000u);
+                rr[p][4] = __uint_as_float(t.z << 16); rr[p][5] = __uint_as_float(t.z & 0xffff0000u);
+                rr[p][6] = __uint_as_float(t.w << 16); rr[p][7] = __uint_as_float(t.w & 0xffff0000u);
+            } else if (a.res_mode) {
                 const long ri = ok[p] ? roff + (long)r * a.ldr + n : 0;
                 if (a.res_dtype == DT_BF16) {
                     const uint4 t = *(const uint4*)((const unsigned short*)a.res + ri);
@@ -688,14 +698,20 @@ __global__ __launch_bounds__(256, MINW) void resfuse_kernel(const GemmArgs a) {
     unsigned char* t1 = slab + ((SR * PITCH_ + 15) & ~15);
     const unsigned short* Xp = (const unsigned short*)a.X + (long)b * a.x_bs;
 
+    // conv1's weight fragments -> registers; conv2's go to a second register set when both fit (NT*KS <= 24),
+    // otherwise they replace conv1's tap by tap inside the conv1 loop (each right after that tap's last MFMA).
+    constexpr bool TWO_SETS = (NT * KS <= 24);
     uint4 w[NT][KS];
-    {
-        const uint4* Wq = (const uint4*)a.Wp2 + ((long)wc * NT * 4) * 64 + lane;
+    uint4 w2[TWO_SETS ? NT : 1][TWO_SETS ? KS : 1];
+    const uint4* W1q = (const uint4*)a.Wp2 + ((long)wc * NT * 4) * 64 + lane;
+    const uint4* W2q = (const uint4*)a.Wp + ((long)wc * NT * 4) * 64 + lane;
 #pragma unroll
-        for (int t = 0; t < NT; t++)
+    for (int t = 0; t < NT; t++)
 #pragma unroll
-            for (int kk = 0; kk < KS; kk++) w[t][kk] = Wq[(t * 4 + kk) * 64];
-    }
+        for (int kk = 0; kk < KS; kk++) {
+            w[t][kk] = W1q[(t * 4 + kk) * 64];
+            if (TWO_SETS) w2[t][kk] = W2q[(t * 4 + kk) * 64];
+        }
     {   // slab rows s <-> global row m0 - H2 - H1 + s
         uint4 sv[NIT];
 #pragma unroll
@@ -726,21 +742,15 @@ __global__ __launch_bounds__(256, MINW) void resfuse_kernel(const GemmArgs a) {
     for (int t = 0; t < NT; t++) {
         const unsigned char* rowp = slab + (wrow + (lane & 31) + H1 + a.dv1[t]) * PITCH_ + koff;
 #pragma unroll
-        for (int kk = 0; kk < KS; kk++)
+        for (int kk = 0; kk < KS; kk++) {
 #pragma unroll
             for (int j = 0; j < TM; j++) {
                 const uint4 xf = *(const uint4*)(rowp + j * 32 * PITCH_ + kk * 32);
                 acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w[t][kk]), __builtin_bit_cast(bf16x8, xf),
                                                                    acc[0][j], 0, 0, 0);
             }
-    }
-    // conv2's weights replace conv1's in the same registers while T1 is written
-    {
-        const uint4* Wq = (const uint4*)a.Wp + ((long)wc * NT * 4) * 64 + lane;
-#pragma unroll
-        for (int t = 0; t < NT; t++)
-#pragma unroll
-            for (int kk = 0; kk < KS; kk++) w[t][kk] = Wq[(t * 4 + kk) * 64];
+            if (!TWO_SETS) w[t][kk] = W2q[(t * 4 + kk) * 64];        // conv2's fragment takes the freed register
+        }
     }
     // ---- T1 = lrelu(acc + b1) as bf16, zero outside the sequence (conv2 zero-pads ITS input, hifigan.py:39-44) ----
 #pragma unroll
@@ -775,13 +785,15 @@ __global__ __launch_bounds__(256, MINW) void resfuse_kernel(const GemmArgs a) {
 #pragma unroll
             for (int j = 0; j < TM; j++) {
                 const uint4 xf = *(const uint4*)(rowp + j * 32 * PITCH_ + kk * 32);
-                acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w[t][kk]), __builtin_bit_cast(bf16x8, xf),
-                                                                   acc[0][j], 0, 0, 0);
+                acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, TWO_SETS ? w2[TWO_SETS ? t : 0][TWO_SETS ? kk : 0] : w[t][kk]),
+                                                                   __builtin_bit_cast(bf16x8, xf), acc[0][j], 0, 0, 0);
             }
     }
-    __syncthreads();                                       // slab + T1 are dead: the slab area becomes the transpose stage
+    __syncthreads();                                       // T1 is dead: its area becomes the transpose stage
     const int lim = (m0 + BMO < out_len) ? m0 + BMO : out_len;
-    epilogue_rows<TM, 1>(a, acc, b, m0 + wrow, wc * 32, lim, lane, slab + wave * (32 * (32 * 4 + 16)));
+    // residual x = inverse-lrelu of the slab rows of this tile (output row j <-> slab row j + H2 + H1): no global re-read
+    epilogue_rows<TM, 1, true>(a, acc, b, m0 + wrow, wc * 32, lim, lane, t1 + wave * (32 * (32 * 4 + 16)),
+                               slab + (wrow + H2 + H1) * PITCH_, PITCH_);
 }
 
 template <int C, int BM, int WM, int WN, int MINW>
