@@ -1,0 +1,39 @@
+"""Checkpoint converter round trip on a synthetic Lightning-style checkpoint (no real weights exist offline)."""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+import yaml
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+from zerovox_amd import config as zcfg, weights as zw
+from zerovox_amd.model import load_meldec_weights, load_tts_weights
+
+
+def test_convert_roundtrip(tmp_path):
+    import convert_checkpoint as cc
+    cfg = zcfg.medium_modelcfg("styletts")
+    h = zcfg.hifigan_config("tiny")
+    sd, hsd = zw.tts_state_dict(cfg, 3), zw.hifigan_state_dict(h, 3)
+    state = {k: torch.from_numpy(np.array(v)) for k, v in sd.items()}
+    state.update({"_meldec." + k: torch.from_numpy(np.array(v)) for k, v in hsd.items()})    # vocoder baked in
+    ck = tmp_path / "checkpoint.pkl"
+    torch.save({"state_dict": state, "hyper_parameters": {"lr": 1e-4}}, ck)
+    mc = tmp_path / "modelcfg.yaml"
+    yaml.safe_dump(cfg, open(mc, "w"))
+    n_tts, n_voc = cc.convert_tts(str(ck), str(mc), str(tmp_path / "out"))
+    assert n_tts == len(sd) and n_voc == len(hsd)
+    cfg2, sd2 = load_tts_weights(str(tmp_path / "out"))
+    assert cfg2["model"]["decoder"]["kind"] == "styletts" and set(sd2) == set(sd)
+    assert all(np.array_equal(sd2[k], sd[k]) for k in sd)
+    gk = tmp_path / "generator.ckpt"
+    torch.save({"generator": {k: torch.from_numpy(np.array(v)) for k, v in hsd.items()}}, gk)
+    cj = tmp_path / "config.json"
+    json.dump(h, open(cj, "w"))
+    assert cc.convert_vocoder(str(gk), str(cj), str(tmp_path / "voc")) == len(hsd)
+    h2, hsd2 = load_meldec_weights(str(tmp_path / "voc"))
+    assert h2 == h and all(np.array_equal(hsd2[k], hsd[k]) for k in hsd)

@@ -835,6 +835,7 @@ static const Variant kVariants[] = {
     {"convslab_bf16_128x64", DT_BF16, 128, 64},   {"convslab_bf16_128x32", DT_BF16, 128, 32},
     {"convreg_bf16_c32", DT_BF16, 512, 32},       {"convreg_bf16_c64", DT_BF16, 256, 64},
     {"resfuse_bf16_c32", DT_BF16, 256, 32},       {"resfuse_bf16_c64", DT_BF16, 128, 64},
+    {"gemm_bf16_64x64", DT_BF16, 64, 64},         {"gemm_f32_64x64", DT_F32, 64, 64},
 };
 const char* gemm_variant_name(int id) { return kVariants[id].name; }
 int gemm_num_variants() { return (int)(sizeof(kVariants) / sizeof(kVariants[0])); }
@@ -908,8 +909,16 @@ int launch_gemm(const GemmArgs& a, hipStream_t stream) {
         const double cost = (double)((a.N + bns[i] - 1) / bns[i]) * bns[i] / eff[i];
         if (best_cost < 0 || cost < best_cost - 1e-9) { best_cost = cost; best = i; }
     }
-    const int bn = bns[best], bm = (bn == 128) ? 128 : 256;
-    const int ntn = (a.N + bn - 1) / bn, ntm = (a.M + bm - 1) / bm;
+    int bn = bns[best], bm = (bn == 128) ? 128 : 256;
+    int ntn = (a.N + bn - 1) / bn, ntm = (a.M + bm - 1) / bm;
+    // small problems (e.g. the f32 phoneme encoder: 128 rows per utterance): a 64x64 tile fills the 256 CUs
+    if ((long)ntn * ntm * a.nbatch * a.nheads < 512 && a.N >= 64) {
+        bm = bn = 64; ntn = (a.N + 63) / 64; ntm = (a.M + 63) / 64;
+        dim3 grid(ntn * ntm, a.nbatch * a.nheads), block(256);
+        if (a.dtype == DT_BF16) { hipLaunchKernelGGL((gemm_kernel<DT_BF16, 64, 64, 2, 2>), grid, block, 0, stream, a); return 18; }
+        hipLaunchKernelGGL((gemm_kernel<DT_F32, 64, 64, 2, 2>), grid, block, 0, stream, a);
+        return 19;
+    }
     dim3 grid(ntn * ntm, a.nbatch * a.nheads), block(256);
     const int base = (a.dtype == DT_BF16) ? 0 : 3;
     const int id = base + best;

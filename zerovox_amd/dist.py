@@ -29,8 +29,15 @@ def gather_waveforms(local_wav, local_len, dst=0, group=None):
         lens = [torch.empty_like(local_len) for _ in range(world)]
     else:
         wavs = lens = None
-    dist.gather(local_wav, wavs, dst=dst, group=group)
-    dist.gather(local_len, lens, dst=dst, group=group)
+    try:
+        dist.gather(local_wav, wavs, dst=dst, group=group)
+        dist.gather(local_len, lens, dst=dst, group=group)
+    except (RuntimeError, NotImplementedError):
+        # a backend without gather: fall back to all_gather (every rank receives all rows, only dst keeps them)
+        wavs = [torch.empty_like(local_wav) for _ in range(world)]
+        lens = [torch.empty_like(local_len) for _ in range(world)]
+        dist.all_gather(wavs, local_wav, group=group)
+        dist.all_gather(lens, local_len, group=group)
     if rank == dst:
         return torch.cat(wavs, 0), torch.cat(lens, 0)
     return None, None
