@@ -312,7 +312,7 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs& a, f32x16 (&acc)[T
                 rr[p][2] = __uint_as_float(t.y << 16); rr[p][3] = __uint_as_float(t.y & 0xffff0000u);
                 rr[p][4] = __uint_as_float(t.z << 16); rr[p][5] = __uint_as_float(t.z & 0xffff0000u);
                 rr[p][6] = __uint_as_float(t.w << 16); rr[p][7] = __uint_as_float(t.w & 0xffff0000u);
-            } else if (a.res_mode) {
+            } else if (a.res_mode && !(a.dbg & 32)) {
                 const long ri = ok[p] ? roff + (long)r * a.ldr + n : 0;
                 if (a.res_dtype == DT_BF16) {
                     const uint4 t = *(const uint4*)((const unsigned short*)a.res + ri);
@@ -343,7 +343,7 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs& a, f32x16 (&acc)[T
                 if (a.accum_mode & 1) t += aa[p][e];
                 v[p][e] = t;
             }
-            if (!ok[p]) continue;
+            if (!ok[p] || (a.dbg & 64)) continue;
             if (a.accum_mode & 2) {
                 float* ap = a.accum + aoff + (long)r * a.lda + n;
                 *(float4*)ap = make_float4(v[p][0], v[p][1], v[p][2], v[p][3]);
@@ -831,8 +831,7 @@ static const Variant kVariants[] = {
     {"gemm_f32_256x64", DT_F32, 256, 64},     {"gemm_f32_256x32", DT_F32, 256, 32},
     {"convslab_bf16_128x256", DT_BF16, 128, 256}, {"convslab_bf16_256x128", DT_BF16, 256, 128},
     {"convslab_bf16_256x64", DT_BF16, 256, 64},   {"convslab_bf16_256x32", DT_BF16, 256, 32},
-    {"convslab_bf16_64x256", DT_BF16, 64, 256},   {"convslab_bf16_128x128", DT_BF16, 128, 128},
-    {"convslab_bf16_128x64", DT_BF16, 128, 64},   {"convslab_bf16_128x32", DT_BF16, 128, 32},
+    {"(unused)", DT_BF16, 0, 0}, {"(unused)", DT_BF16, 0, 0}, {"(unused)", DT_BF16, 0, 0}, {"(unused)", DT_BF16, 0, 0},
     {"convreg_bf16_c32", DT_BF16, 512, 32},       {"convreg_bf16_c64", DT_BF16, 256, 64},
     {"resfuse_bf16_c32", DT_BF16, 256, 32},       {"resfuse_bf16_c64", DT_BF16, 128, 64},
     {"gemm_bf16_64x64", DT_BF16, 64, 64},         {"gemm_f32_64x64", DT_F32, 64, 64},
@@ -857,38 +856,27 @@ static int launch_convslab(GemmArgs a, hipStream_t stream) {
     }
     // tile choice: padded N weighted by the tile's MFMA efficiency
     static const int bns[4] = {256, 128, 64, 32};
-    static const double eff[4] = {1.0, 1.0, 0.7, 0.4};
+    static const double eff[4] = {0.95, 1.0, 0.7, 0.4};
     int best = 0; double best_cost = -1;
     for (int i = 0; i < 4; i++) {
         const double cost = (double)((a.N + bns[i] - 1) / bns[i]) * bns[i] / eff[i];
         if (best_cost < 0 || cost < best_cost - 1e-9) { best_cost = cost; best = i; }
     }
-    static const char* set_env = getenv("ZVX_SLAB_SET");
-    const bool small = set_env && set_env[0] == 's';
-    static const int bms_large[4] = {128, 256, 256, 256}, bms_small[4] = {64, 128, 128, 128};
-    const int bn = bns[best], bm = small ? bms_small[best] : bms_large[best];
+    static const int bms[4] = {128, 256, 256, 256};
+    const int bn = bns[best], bm = bms[best];
     const int ntn = (a.N + bn - 1) / bn, ntm = (a.M + bm - 1) / bm;
     dim3 grid(ntn * ntm, a.nbatch);
     const int tn = (bn >= 128) ? 2 : 1;
     size_t lds = (((size_t)(bm + hl + hr) * SLAB_PITCH + 1023) & ~(size_t)1023) + (size_t)4 * 4 * tn * 1024;
     const size_t stage = (size_t)4 * 32 * (tn * 128 + 16);
     if (lds < stage) lds = stage;
-    if (!small) {
-        switch (best) {
-            case 0: launch_slab_variant<128, 256, 1, 4, 2>(a, grid, lds, stream); break;
-            case 1: launch_slab_variant<256, 128, 2, 2, 2>(a, grid, lds, stream); break;
-            case 2: launch_slab_variant<256, 64, 2, 2, 2>(a, grid, lds, stream); break;
-            case 3: launch_slab_variant<256, 32, 4, 1, 2>(a, grid, lds, stream); break;
-        }
-        return 6 + best;
-    }
     switch (best) {
-        case 0: launch_slab_variant<64, 256, 1, 4, 3>(a, grid, lds, stream); break;
-        case 1: launch_slab_variant<128, 128, 2, 2, 3>(a, grid, lds, stream); break;
-        case 2: launch_slab_variant<128, 64, 2, 2, 4>(a, grid, lds, stream); break;
-        case 3: launch_slab_variant<128, 32, 4, 1, 4>(a, grid, lds, stream); break;
+        case 0: launch_slab_variant<128, 256, 1, 4, 2>(a, grid, lds, stream); break;
+        case 1: launch_slab_variant<256, 128, 2, 2, 2>(a, grid, lds, stream); break;
+        case 2: launch_slab_variant<256, 64, 2, 2, 2>(a, grid, lds, stream); break;
+        case 3: launch_slab_variant<256, 32, 4, 1, 2>(a, grid, lds, stream); break;
     }
-    return 10 + best;
+    return 6 + best;
 }
 
 int launch_gemm(const GemmArgs& a, hipStream_t stream) {

@@ -45,7 +45,7 @@ struct Tensor {
     int dim(int i) const { return dims.at(i); }
 };
 
-struct DevBuf { void* p = nullptr; size_t cap = 0; };
+struct DevBuf { void* p = nullptr; void* base = nullptr; size_t cap = 0; };
 
 struct GemmEvent { hipEvent_t a, b; int variant; double flops, bytes; };
 
@@ -105,10 +105,12 @@ struct zvx_ctx {
     void* buf(const std::string& name, size_t bytes) {
         DevBuf& d = bufs[name];
         if (bytes > d.cap) {
-            if (d.p) { HIPCHK(hipStreamSynchronize(stream)); HIPCHK(hipFree(d.p)); d.p = nullptr; }
+            if (d.base) { HIPCHK(hipStreamSynchronize(stream)); HIPCHK(hipFree(d.base)); d.base = nullptr; d.p = nullptr; }
+            const size_t skew = 0;
             size_t cap = bytes + bytes / 8 + 256;
-            HIPCHK(hipMalloc(&d.p, cap));
-            HIPCHK(hipMemsetAsync(d.p, 0, cap, stream));
+            HIPCHK(hipMalloc(&d.base, cap + skew));
+            HIPCHK(hipMemsetAsync(d.base, 0, cap + skew, stream));
+            d.p = (char*)d.base + skew;
             d.cap = cap;
         }
         return d.p;
@@ -255,7 +257,7 @@ void upload_weights(zvx_ctx* c) {
     }
     HIPCHK(hipStreamSynchronize(c->stream));
     DevBuf& st = c->bufs["weights_staging"];
-    HIPCHK(hipFree(st.p)); st.p = nullptr; st.cap = 0;
+    HIPCHK(hipFree(st.base)); st.base = nullptr; st.p = nullptr; st.cap = 0;
 }
 
 void read_config(zvx_ctx* c) {
@@ -963,7 +965,7 @@ void zvx_destroy(zvx_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    for (auto& kv : c->bufs) if (kv.second.p) (void)hipFree(kv.second.p);
+    for (auto& kv : c->bufs) if (kv.second.base) (void)hipFree(kv.second.base);
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
     if (c->stream) {
         for (int s = 0; s < ZVX_T_COUNT; s++) { (void)hipEventDestroy(c->stage_ev[s][0]); (void)hipEventDestroy(c->stage_ev[s][1]); }
