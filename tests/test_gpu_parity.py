@@ -265,3 +265,80 @@ def test_host_api_tts_ex_roundtrip():
     assert synth.model._min_mel_len == 689
     w0, p0, l0 = synth.tts("?!", spk[None, None])
     assert l0 == 0 and w0.shape == (1, 1)
+
+
+# ------------------------------------------------------------------------------------------------
+# edge cases of the reference path
+# ------------------------------------------------------------------------------------------------
+def test_long_sequences_use_recomputed_position_tables():
+    """T > max_txt_len (512) and L > max_mel_len (1750): the reference recomputes the sinusoid table on the fly
+    (fs2.py:383-388, 287-294)."""
+    ctx = ctx_for("fastspeech2", "tiny", "f32")
+    cfg, sd = tts_sd("fastspeech2")
+    T = 520
+    ph, pu, spk, _ = synthetic.utterance(T, 90, None)
+    dur = np.full(T, 4, np.int32)                                       # L = 2080 > 1750
+    mel_len, logd, _, _ = ctx.encode(ph[None], pu[None], np.array([T], np.int32), spk[None], dur[None])
+    assert int(mel_len[0]) == 2080
+    ref = O.fs2_encoder(ph, pu, spk, sd, cfg, dur)
+    check_f32(ctx.fetch("encoder_out", (1, T, 528))[0], ref["encoder_out"], "encoder_out T>512")
+    mel = ctx.decode(1, 2080)
+    check_f32(mel[0], O.fs2_decoder(ref["features"], spk, sd, cfg), "mel L>1750", 5e-4)
+
+
+@pytest.mark.parametrize("prec", ["f32", "bf16"])
+def test_tiny_utterances(prec):
+    """1-phoneme / 2-frame utterances next to a normal one (the shortest lengths the conv stacks accept).
+    FS2 decoder only: with the StyleTTS decoder a 2..5-frame utterance consists of repeated identical rows, its
+    InstanceNorm variance is ~0 and the reference's own fp32 result is noise there (the oracle in fp32 vs fp64 differs by
+    2.0 at L=2 and 4e-3 at L=5, but 1.6e-5 at L=11) -- nothing to be exact against."""
+    ctx = ctx_for("fastspeech2", "tiny", prec)
+    cfg, sd = tts_sd("fastspeech2")
+    h, hsd = voc_sd("tiny")
+    Ts = [1, 9]
+    ph = np.zeros((2, 9), np.int32); pu = np.zeros((2, 9), np.int32); dur = np.zeros((2, 9), np.int32); spk = np.zeros((2, 528), np.float32)
+    for b, T in enumerate(Ts):
+        p, q, s, _ = synthetic.utterance(T, 95 + b, None)
+        ph[b, :T], pu[b, :T], spk[b] = p, q, s
+    dur[0, 0] = 2
+    dur[1, :9] = [0, 3, 0, 0, 5, 1, 0, 2, 0]                          # dropped phonemes (duration 0) inside and at both ends
+    out = ctx.synthesize(ph, pu, np.array(Ts, np.int32), spk, dur, np.array([4, 11], np.int32))
+    for b, T in enumerate(Ts):
+        ref = O.inference_ex(sd, hsd, cfg, h, ph[b, :T], pu[b, :T], spk[b], duration=dur[b, :T], pad_to=[4, 11][b])
+        ml = ref["mel_len"]
+        assert int(out["mel_len"][b]) == ml == int(dur[b, :T].sum())
+        check_mel(out["mel"][b, :ml], ref["mel"].T, prec, f"mel[{b}]")
+        check_wav(out["wav"][b, : ml * 256], ref["wav"], prec, f"wav[{b}]")
+
+
+def test_predicted_length_overflow_reports_buffer_error():
+    ctx = ctx_for("styletts", "tiny", "f32")
+    ph, pu, T, spk, _ = synthetic.batch(1, 12, 0, None)
+    with pytest.raises(_lib.ZvxError) as e:
+        ctx.synthesize(ph, pu, T, spk, None, None, Lmax_cap=3)          # predicted ~6 frames per phoneme
+    assert e.value.code == _lib.ZVX_E_BUFFER
+    out = ctx.synthesize(ph, pu, T, spk, None, np.array([64], np.int32), Lmax_cap=400)
+    assert 12 <= int(out["mel_len"][0]) <= 400
+
+
+def test_speaker_encoder_short_and_odd_lengths():
+    ctx = ctx_for("styletts", "tiny", "f32")
+    cfg, sd = tts_sd("styletts")
+    r = np.random.default_rng(11)
+    lens = np.array([9, 17, 31, 2], np.int32)                            # stride-2 levels shrink these to 2 / 3 / 4 / 1 columns
+    mels = r.standard_normal((4, 31, 80)).astype(np.float32)
+    e = ctx.spkemb(mels, lens)
+    for b in range(4):
+        check_f32(e[b], O.resnet_se34v2(mels[b, :lens[b]], sd, cfg), f"embed[{b}]", 5e-5)
+
+
+def test_stage_times_and_kernel_stats_are_reported():
+    ctx = ctx_for("styletts", "tiny", "bf16")
+    ph, pu, T, spk, dur = synthetic.batch(2, 16, 0, "uniform")
+    ctx.set_int("profile", 2)
+    ctx.reset_stats()
+    ctx.synthesize(ph, pu, T, spk, dur, np.array([32, 32], np.int32))
+    st, ks = ctx.stage_times(), ctx.kernel_stats()
+    ctx.set_int("profile", 0)
+    assert st["encoder"] > 0 and st["decoder"] > 0 and st["vocoder"] > 0
+    assert ks and all(k["launches"] > 0 and k["ms"] > 0 and k["flops"] > 0 for k in ks)
