@@ -864,7 +864,8 @@ static int launch_convslab(GemmArgs a, hipStream_t stream) {
     }
     static const int bms[4] = {128, 256, 256, 256};
     const int bn = bns[best], bm = bms[best];
-    const int ntn = (a.N + bn - 1) / bn, ntm = (a.M + bm - 1) / bm;
+    const int ntn = (a.N + bn - 1) / bn;
+    const int ntm = (a.M + bm - 1) / bm;
     dim3 grid(ntn * ntm, a.nbatch);
     const int tn = (bn >= 128) ? 2 : 1;
     size_t lds = (((size_t)(bm + hl + hr) * SLAB_PITCH + 1023) & ~(size_t)1023) + (size_t)4 * 4 * tn * 1024;

@@ -270,24 +270,58 @@ void launch_se_pool(const void* x, int x_dt, int B, int H, int Wmax, const int* 
     hipLaunchKernelGGL(k_colstats, dim3((C + 63) / 64, B), dim3(256), 0, s, x, x_dt, C, H, Wmax, W, C, 0.f, mean, (float*)nullptr);
 }
 
-__global__ void k_norm_affine_act(const void* x, int xdt, int ldx, void* y, int ydt, int ldy, int Lmax, const int* L, int C,
-                                  const float* mean, const float* rstd, const float* gamma, const float* beta, long g_bs,
-                                  int one_plus, int act, float slope) {
-    const int b = blockIdx.y, l = blockIdx.x;
-    if (l >= L[b]) return;
-    const long xo = ((long)b * Lmax + l) * ldx, yo = ((long)b * Lmax + l) * ldy;
-    for (int c = threadIdx.x; c < C; c += blockDim.x) {
-        float v = (ld(x, xdt, xo + c) - mean[(long)b * C + c]) * rstd[(long)b * C + c];
-        if (gamma) v = v * ((one_plus ? 1.f : 0.f) + gamma[b * g_bs + c]) + beta[b * g_bs + c];
-        st(y, ydt, yo + c, act_apply(v, act, slope));
+// One wave = 64 x 8-channel vectors of a row (1 KiB of bf16); a block covers 64 rows x 512 channels, each lane keeps the
+// per-(utterance, channel) scale/shift of its 8 channels in registers for all of its rows.
+__global__ __launch_bounds__(256) void k_norm_affine_act(const void* x, int xdt, int ldx, void* y, int ydt, int ldy, int Lmax, const int* L, int C,
+                                                         const float* mean, const float* rstd, const float* gamma, const float* beta, long g_bs,
+                                                         int one_plus, int act, float slope) {
+    const int b = blockIdx.z;
+    const int Lb = L[b];
+    const int l0 = blockIdx.y * 64;
+    if (l0 >= Lb) return;
+    const int c = (blockIdx.x * 64 + (threadIdx.x & 63)) * 8;
+    if (c >= C) return;                                       // C % 8 == 0 for every caller
+    float sc[8], sh[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+        const float m = mean[(long)b * C + c + e], r = rstd[(long)b * C + c + e];
+        float g = 1.f, be = 0.f;
+        if (gamma) { g = (one_plus ? 1.f : 0.f) + gamma[b * g_bs + c + e]; be = beta[b * g_bs + c + e]; }
+        sc[e] = r * g; sh[e] = be - m * r * g;                // (x - m) * r * g + be
+    }
+    const int lend = (l0 + 64 < Lb) ? l0 + 64 : Lb;
+    for (int l = l0 + (threadIdx.x >> 6); l < lend; l += 4) {
+        const long xo = ((long)b * Lmax + l) * ldx + c, yo = ((long)b * Lmax + l) * ldy + c;
+        float v[8];
+        if (xdt == DT_BF16) {
+            const uint4 t = *(const uint4*)((const unsigned short*)x + xo);
+            v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u);
+            v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
+            v[4] = __uint_as_float(t.z << 16); v[5] = __uint_as_float(t.z & 0xffff0000u);
+            v[6] = __uint_as_float(t.w << 16); v[7] = __uint_as_float(t.w & 0xffff0000u);
+        } else {
+            const float4 t0 = *(const float4*)((const float*)x + xo), t1 = *(const float4*)((const float*)x + xo + 4);
+            v[0] = t0.x; v[1] = t0.y; v[2] = t0.z; v[3] = t0.w; v[4] = t1.x; v[5] = t1.y; v[6] = t1.z; v[7] = t1.w;
+        }
+#pragma unroll
+        for (int e = 0; e < 8; e++) v[e] = act_apply(v[e] * sc[e] + sh[e], act, slope);
+        if (ydt == DT_BF16) {
+            uint4 t;
+            t.x = (unsigned)tobf(v[0]) | ((unsigned)tobf(v[1]) << 16); t.y = (unsigned)tobf(v[2]) | ((unsigned)tobf(v[3]) << 16);
+            t.z = (unsigned)tobf(v[4]) | ((unsigned)tobf(v[5]) << 16); t.w = (unsigned)tobf(v[6]) | ((unsigned)tobf(v[7]) << 16);
+            *(uint4*)((unsigned short*)y + yo) = t;
+        } else {
+            *(float4*)((float*)y + yo) = make_float4(v[0], v[1], v[2], v[3]);
+            *(float4*)((float*)y + yo + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        }
     }
 }
 void launch_norm_affine_act(const void* x, int x_dt, int ldx, void* y, int y_dt, int ldy, int B, int Lmax,
                             const int* L, int C, const float* mean, const float* rstd, const float* gamma,
                             const float* beta, long g_bs, int one_plus, int act, float slope, hipStream_t s) {
     if (Lmax <= 0) return;
-    hipLaunchKernelGGL(k_norm_affine_act, dim3(Lmax, B), dim3(256), 0, s, x, x_dt, ldx, y, y_dt, ldy, Lmax, L, C, mean, rstd,
-                       gamma, beta, g_bs, one_plus, act, slope);
+    hipLaunchKernelGGL(k_norm_affine_act, dim3((C / 8 + 63) / 64, (Lmax + 63) / 64, B), dim3(256), 0, s, x, x_dt, ldx, y, y_dt, ldy, Lmax,
+                       L, C, mean, rstd, gamma, beta, g_bs, one_plus, act, slope);
 }
 
 // ---------------------------------------------------------------- mel -> zero-padded vocoder input
