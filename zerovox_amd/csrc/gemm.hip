@@ -262,8 +262,17 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs a) {
 }
 
 // ---- row-major epilogue: accumulators -> per-wave LDS transpose -> every lane owns 8 consecutive channels of a row ----
-// Global traffic of the epilogue (output, residual, f32 accumulator) becomes full-line: a wave instruction
-// touches 8 (NW=64) or 16 (NW=32) rows x 128/64 contiguous bytes instead of 32 rows x 16 bytes.
+// Global traffic of the epilogue (output, residual, f32 accumulator) becomes full-line: a wave instruction touches
+// 8 (NW=64) or 16 (NW=32) rows x 128/64 contiguous bytes instead of 32 rows x 16 bytes.  The per-element arithmetic is kept
+// to a handful of VALU ops (all mode switches are wave-uniform branches OUTSIDE the element loops; leaky-relu = max(x, s*x),
+// its inverse = min(y, y/s); bf16 packing via the hardware RNE convert): with two waves per SIMD the epilogue is otherwise
+// VALU-bound (measured 27k cycles per tile for the branchy per-element version vs 7k for the LDS transposes).
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+    bf16x2_t v = {(__bf16)lo, (__bf16)hi};                 // v_cvt_pk_bf16_f32 on gfx950 (round-to-nearest-even)
+    return __builtin_bit_cast(unsigned, v);
+}
+
 template <int TM, int TN, bool RES_LDS = false>
 __device__ __forceinline__ void epilogue_rows(const GemmArgs& a, f32x16 (&acc)[TN][TM], int b, int row_base, int col_base,
                                               int out_len, int lane, unsigned char* stage /* >= 32*(TN*32*4+16) bytes, this wave's */,
@@ -273,16 +282,36 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs& a, f32x16 (&acc)[T
     constexpr int EP = NW * 4 + 16;             // LDS row pitch in bytes
     constexpr int LPR = NW / 8;                 // lanes per row
     constexpr int RPP = 64 / LPR;               // rows per pass
+    constexpr int NP = 32 / RPP;
     const long ooff = (long)b * a.o_bs, roff = (long)b * a.r_bs, aoff = (long)b * a.a_bs;
     const int c8 = lane % LPR;
     const int n = col_base + c8 * 8;
+    const bool nok = n < a.N;
+    // wave-uniform mode words, read once
+    const float alpha = a.alpha, oscale = a.out_scale, slope = a.slope, rinv = a.res_inv_slope;
+    const int act = a.act, res_mode = RES_LDS ? 2 : a.res_mode, accum_mode = a.accum_mode, bias_mode = a.bias_mode;
+    const bool has_out = a.out != nullptr, out_bf16 = a.out_dtype == DT_BF16, has_post = a.post_scale != nullptr;
     float bcol[8];
 #pragma unroll
     for (int e = 0; e < 8; e++) bcol[e] = 0.f;
-    if (a.bias_mode == 1 && n < a.N) {
+    if (bias_mode == 1 && nok) {
         const float4 b0 = *(const float4*)(a.bias + n), b1 = *(const float4*)(a.bias + n + 4);
         bcol[0] = b0.x; bcol[1] = b0.y; bcol[2] = b0.z; bcol[3] = b0.w; bcol[4] = b1.x; bcol[5] = b1.y; bcol[6] = b1.z; bcol[7] = b1.w;
     }
+    u32x4 pk[TM][NP];                            // bf16 results, stored in one burst at the end
+    // bf16 residual rows from global memory are requested one 32-row block ahead (their latency hides behind the
+    // previous block's LDS transpose + arithmetic)
+    const bool res_glb = !RES_LDS && res_mode && a.res_dtype == DT_BF16;
+    uint4 rnext[NP];
+    auto res_prefetch = [&](int j) {
+#pragma unroll
+        for (int p = 0; p < NP; p++) {
+            const int r = row_base + j * 32 + p * RPP + lane / LPR;
+            const bool okp = r < a.M && r < out_len && nok;
+            rnext[p] = *(const uint4*)((const unsigned short*)a.res + (okp ? roff + (long)r * a.ldr + n : 0));
+        }
+    };
+    if (res_glb) res_prefetch(0);
 #pragma unroll
     for (int j = 0; j < TM; j++) {
         // write this wave's 32 x NW block (MFMA layout: lane = time row, 4 consecutive channels per quad)
@@ -293,89 +322,114 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs& a, f32x16 (&acc)[T
                 *(float4*)(stage + (lane & 31) * EP + (i * 32 + 8 * g + 4 * (lane >> 5)) * 4) =
                     make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
         __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0): the wave's own LDS writes have landed
-        constexpr int NP = 32 / RPP;
         // phase A: every load of the 32-row block in flight at once (branch-free: invalid lanes read element 0)
-        float v[NP][8], rr[NP][8], aa[NP][8];
-        bool ok[NP]; int rows[NP];
+        float v[NP][8];
+        uint4 rraw[NP];
+        float4 aa0[NP], aa1[NP];
+        bool ok[NP];
+        if (res_glb) {
+#pragma unroll
+            for (int p = 0; p < NP; p++) rraw[p] = rnext[p];
+            if (j + 1 < TM) res_prefetch(j + 1);
+        }
 #pragma unroll
         for (int p = 0; p < NP; p++) {
             const int rl = p * RPP + lane / LPR;
             const int r = row_base + j * 32 + rl;
-            rows[p] = r;
-            ok[p] = r < a.M && r < out_len && n < a.N;
+            ok[p] = r < a.M && r < out_len && nok;
             const float4 v0 = *(const float4*)(stage + rl * EP + c8 * 32), v1 = *(const float4*)(stage + rl * EP + c8 * 32 + 16);
             v[p][0] = v0.x; v[p][1] = v0.y; v[p][2] = v0.z; v[p][3] = v0.w; v[p][4] = v1.x; v[p][5] = v1.y; v[p][6] = v1.z; v[p][7] = v1.w;
-            if (RES_LDS) {
-                // residual = this tile's own (activated) input rows, still resident in the LDS slab
-                const uint4 t = *(const uint4*)(res_lds + (j * 32 + rl) * res_pitch + (col_base + c8 * 8) * 2);
-                rr[p][0] = __uint_as_float(t.x << 16); rr[p][1] = __uint_as_float(t.x & 0xffff0000u);
-                rr[p][2] = __uint_as_float(t.y << 16); rr[p][3] = __uint_as_float(t.y & 0xffff0000u);
-                rr[p][4] = __uint_as_float(t.z << 16); rr[p][5] = __uint_as_float(t.z & 0xffff0000u);
-                rr[p][6] = __uint_as_float(t.w << 16); rr[p][7] = __uint_as_float(t.w & 0xffff0000u);
-            } else if (a.res_mode && !(a.dbg & 32)) {
-                const long ri = ok[p] ? roff + (long)r * a.ldr + n : 0;
-                if (a.res_dtype == DT_BF16) {
-                    const uint4 t = *(const uint4*)((const unsigned short*)a.res + ri);
-                    rr[p][0] = __uint_as_float(t.x << 16); rr[p][1] = __uint_as_float(t.x & 0xffff0000u);
-                    rr[p][2] = __uint_as_float(t.y << 16); rr[p][3] = __uint_as_float(t.y & 0xffff0000u);
-                    rr[p][4] = __uint_as_float(t.z << 16); rr[p][5] = __uint_as_float(t.z & 0xffff0000u);
-                    rr[p][6] = __uint_as_float(t.w << 16); rr[p][7] = __uint_as_float(t.w & 0xffff0000u);
-                } else {
-                    const float4 t0 = *(const float4*)((const float*)a.res + ri), t1 = *(const float4*)((const float*)a.res + ri + 4);
-                    rr[p][0] = t0.x; rr[p][1] = t0.y; rr[p][2] = t0.z; rr[p][3] = t0.w; rr[p][4] = t1.x; rr[p][5] = t1.y; rr[p][6] = t1.z; rr[p][7] = t1.w;
-                }
-            }
-            if (a.accum_mode & 1) {
-                const long ai = ok[p] ? aoff + (long)r * a.lda + n : 0;
-                const float4 t0 = *(const float4*)(a.accum + ai), t1 = *(const float4*)(a.accum + ai + 4);
-                aa[p][0] = t0.x; aa[p][1] = t0.y; aa[p][2] = t0.z; aa[p][3] = t0.w; aa[p][4] = t1.x; aa[p][5] = t1.y; aa[p][6] = t1.z; aa[p][7] = t1.w;
+            if (RES_LDS) rraw[p] = *(const uint4*)(res_lds + (j * 32 + rl) * res_pitch + (col_base + c8 * 8) * 2);
+            if (accum_mode & 1) {
+                const float* ap = a.accum + (ok[p] ? aoff + (long)r * a.lda + n : 0);
+                aa0[p] = *(const float4*)ap; aa1[p] = *(const float4*)(ap + 4);
             }
         }
-        // phase B: arithmetic + full-line stores
+        // phase B: arithmetic (uniform branches outside the element loops)
 #pragma unroll
         for (int p = 0; p < NP; p++) {
-            const int r = rows[p];
-            const float brow = (a.bias_mode == 2 && ok[p]) ? a.bias[r] : 0.f;
+            const int r = row_base + j * 32 + p * RPP + lane / LPR;
+            float* t = v[p];
+            if (alpha != 1.f) {
 #pragma unroll
-            for (int e = 0; e < 8; e++) {
-                float t = v[p][e] * a.alpha + bcol[e] + brow;
-                if (a.res_mode) { float q = rr[p][e]; if (a.res_mode == 2) q = q >= 0.f ? q : q * a.res_inv_slope; t += q; }
-                if (a.accum_mode & 1) t += aa[p][e];
-                v[p][e] = t;
+                for (int e = 0; e < 8; e++) t[e] *= alpha;
             }
-            if (!ok[p] || (a.dbg & 64)) continue;
-            if (a.accum_mode & 2) {
-                float* ap = a.accum + aoff + (long)r * a.lda + n;
-                *(float4*)ap = make_float4(v[p][0], v[p][1], v[p][2], v[p][3]);
-                *(float4*)(ap + 4) = make_float4(v[p][4], v[p][5], v[p][6], v[p][7]);
+            if (bias_mode == 1) {
+#pragma unroll
+                for (int e = 0; e < 8; e++) t[e] += bcol[e];
+            } else if (bias_mode == 2) {
+                const float brow = ok[p] ? a.bias[r] : 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; e++) t[e] += brow;
             }
-            if (a.out) {
-#pragma unroll
-                for (int e = 0; e < 8; e++) {
-                    float t = v[p][e] * a.out_scale;
-                    if (a.act == ACT_RELU) t = fmaxf(t, 0.f);
-                    else if (a.act == ACT_LRELU) t = t >= 0.f ? t : t * a.slope;
-                    v[p][e] = t;
-                }
-                if (a.post_scale) {
-#pragma unroll
-                    for (int e = 0; e < 8; e++) v[p][e] = v[p][e] * a.post_scale[n + e] + a.post_shift[n + e];
-                }
-                const long o = ooff + (long)r * a.ldo + n;
-                if (a.out_dtype == DT_F32) {
-                    *(float4*)((float*)a.out + o) = make_float4(v[p][0], v[p][1], v[p][2], v[p][3]);
-                    *(float4*)((float*)a.out + o + 4) = make_float4(v[p][4], v[p][5], v[p][6], v[p][7]);
+            if (res_mode) {
+                float q[8];
+                if (RES_LDS || a.res_dtype == DT_BF16) {
+                    q[0] = __uint_as_float(rraw[p].x << 16); q[1] = __uint_as_float(rraw[p].x & 0xffff0000u);
+                    q[2] = __uint_as_float(rraw[p].y << 16); q[3] = __uint_as_float(rraw[p].y & 0xffff0000u);
+                    q[4] = __uint_as_float(rraw[p].z << 16); q[5] = __uint_as_float(rraw[p].z & 0xffff0000u);
+                    q[6] = __uint_as_float(rraw[p].w << 16); q[7] = __uint_as_float(rraw[p].w & 0xffff0000u);
                 } else {
-                    uint4 t;
-                    t.x = (unsigned)f32_to_bf16(v[p][0]) | ((unsigned)f32_to_bf16(v[p][1]) << 16);
-                    t.y = (unsigned)f32_to_bf16(v[p][2]) | ((unsigned)f32_to_bf16(v[p][3]) << 16);
-                    t.z = (unsigned)f32_to_bf16(v[p][4]) | ((unsigned)f32_to_bf16(v[p][5]) << 16);
-                    t.w = (unsigned)f32_to_bf16(v[p][6]) | ((unsigned)f32_to_bf16(v[p][7]) << 16);
-                    *(uint4*)((unsigned short*)a.out + o) = t;
+                    const float* rp = (const float*)a.res + (ok[p] ? roff + (long)r * a.ldr + n : 0);
+                    const float4 t0 = *(const float4*)rp, t1 = *(const float4*)(rp + 4);
+                    q[0] = t0.x; q[1] = t0.y; q[2] = t0.z; q[3] = t0.w; q[4] = t1.x; q[5] = t1.y; q[6] = t1.z; q[7] = t1.w;
+                }
+                if (res_mode == 2) {            // inverse leaky-relu (1/slope > 1): x = min(y, y/slope)
+#pragma unroll
+                    for (int e = 0; e < 8; e++) t[e] += fminf(q[e], q[e] * rinv);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; e++) t[e] += q[e];
+                }
+            }
+            if (accum_mode & 1) {
+                t[0] += aa0[p].x; t[1] += aa0[p].y; t[2] += aa0[p].z; t[3] += aa0[p].w;
+                t[4] += aa1[p].x; t[5] += aa1[p].y; t[6] += aa1[p].z; t[7] += aa1[p].w;
+            }
+            if ((accum_mode & 2) && ok[p]) {
+                float* ap = a.accum + aoff + (long)r * a.lda + n;
+                *(float4*)ap = make_float4(t[0], t[1], t[2], t[3]);
+                *(float4*)(ap + 4) = make_float4(t[4], t[5], t[6], t[7]);
+            }
+            if (has_out) {
+                if (oscale != 1.f) {
+#pragma unroll
+                    for (int e = 0; e < 8; e++) t[e] *= oscale;
+                }
+                if (act == ACT_LRELU) {          // 0 <= slope <= 1: leaky-relu = max(x, slope*x)
+#pragma unroll
+                    for (int e = 0; e < 8; e++) t[e] = fmaxf(t[e], t[e] * slope);
+                } else if (act == ACT_RELU) {
+#pragma unroll
+                    for (int e = 0; e < 8; e++) t[e] = fmaxf(t[e], 0.f);
+                }
+                if (has_post && nok) {
+                    const float4 s0 = *(const float4*)(a.post_scale + n), s1 = *(const float4*)(a.post_scale + n + 4);
+                    const float4 h0 = *(const float4*)(a.post_shift + n), h1 = *(const float4*)(a.post_shift + n + 4);
+                    t[0] = t[0] * s0.x + h0.x; t[1] = t[1] * s0.y + h0.y; t[2] = t[2] * s0.z + h0.z; t[3] = t[3] * s0.w + h0.w;
+                    t[4] = t[4] * s1.x + h1.x; t[5] = t[5] * s1.y + h1.y; t[6] = t[6] * s1.z + h1.z; t[7] = t[7] * s1.w + h1.w;
+                }
+                if (out_bf16) {
+                    pk[j][p] = (u32x4){pack_bf16x2(t[0], t[1]), pack_bf16x2(t[2], t[3]), pack_bf16x2(t[4], t[5]), pack_bf16x2(t[6], t[7])};
+                } else if (ok[p]) {
+                    float* op = (float*)a.out + ooff + (long)r * a.ldo + n;
+                    *(float4*)op = make_float4(t[0], t[1], t[2], t[3]);
+                    *(float4*)(op + 4) = make_float4(t[4], t[5], t[6], t[7]);
                 }
             }
         }
         __builtin_amdgcn_s_waitcnt(0xc07f);      // reads done before the next j overwrites the stage
+    }
+    if (has_out && out_bf16) {
+        unsigned short* obase = (unsigned short*)a.out + ooff + n;
+        const int ldo = a.ldo;
+#pragma unroll
+        for (int j = 0; j < TM; j++)
+#pragma unroll
+            for (int p = 0; p < NP; p++) {
+                const int r = row_base + j * 32 + p * RPP + lane / LPR;
+                if (r < a.M && r < out_len && nok) *(u32x4*)(obase + (long)r * ldo) = pk[j][p];
+            }
     }
 }
 
@@ -472,6 +526,30 @@ __global__ __launch_bounds__(256, MINW) void convslab_kernel(const GemmArgs a) {
 
     for (int kc = 0; kc < nkc; kc++) {
         if (kc) __syncthreads();
+        // ---- weights: per-wave LDS ring filled by LDS-DMA (global_load_lds, 1 KiB fragment per instruction) ----
+        // The packed weight stream of this wave's channel tiles is contiguous over (tap, k16): step st = tap*4+kk
+        // lives at wbase + st KiB and lands in ring slot kk.  DMAs run 3 steps ahead of the MFMAs; the only
+        // synchronisation is this wave's own counted vmcnt (no barrier, no VGPR staging).
+        const uint4* wbase[TN];
+#pragma unroll
+        for (int i = 0; i < TN; i++) {
+            const int t32 = nt32 + i;
+            wbase[i] = Wq + (((long)(t32 < nt32_total ? t32 : 0) * nkc + kc) * ntaps) * 4 * 64 + lane;
+        }
+        const int nsteps = ntaps * 4;
+        const long next_chunk = (kc + 1 < nkc) ? (long)ntaps * 4 * 64 : -1;   // packed stream: chunk kc+1 follows chunk kc
+        auto dma = [&](int st, int slot) {
+            // tail (st >= nsteps): these three requests ARE the next K-chunk's first fragments (slots 0..2) -- its weight
+            // latency hides behind this chunk's last MFMAs and the slab refill; on the last chunk: harmless re-loads
+            long off = (long)st * 64;
+            if (st >= nsteps) off = next_chunk >= 0 ? next_chunk + (long)(st - nsteps) * 64 : (long)(nsteps - 1) * 64;
+#pragma unroll
+            for (int i = 0; i < TN; i++)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wbase[i] + off),
+                                                 (__attribute__((address_space(3))) void*)(ring + (slot * TN + i) * 1024), 16, 0, 0);
+        };
+        // the first three weight fragments are requested BEFORE the slab fill so that their L2 latency overlaps the fill's
+        if (!(a.dbg & 2) && kc == 0) { dma(0, 0); dma(1, 1); dma(2, 2); }    // later chunks: requested by the previous chunk's tail
         // ---- stage the slab: rows [m0-HL, m0+BM+HR) x 64 channels of chunk kc (all loads in flight, then the stores) ----
         {
             uint4 sv[NIT];
@@ -493,24 +571,6 @@ __global__ __launch_bounds__(256, MINW) void convslab_kernel(const GemmArgs a) {
         int nk16 = 4;
         if (!FULLK) { nk16 = n16 - kc * 4; if (nk16 > 4) nk16 = 4; }
 
-        // ---- weights: per-wave LDS ring filled by LDS-DMA (global_load_lds, 1 KiB fragment per instruction) ----
-        // The packed weight stream of this wave's channel tiles is contiguous over (tap, k16): step st = tap*4+kk
-        // lives at wbase + st KiB and lands in ring slot kk.  DMAs run 3 steps ahead of the MFMAs; the only
-        // synchronisation is this wave's own counted vmcnt (no barrier, no VGPR staging).
-        const uint4* wbase[TN];
-#pragma unroll
-        for (int i = 0; i < TN; i++) {
-            const int t32 = nt32 + i;
-            wbase[i] = Wq + (((long)(t32 < nt32_total ? t32 : 0) * nkc + kc) * ntaps) * 4 * 64 + lane;
-        }
-        const int nsteps = ntaps * 4;
-        auto dma = [&](int st, int slot) {
-            const int sc = st < nsteps ? st : nsteps - 1;               // tail: harmless re-load, keeps the vmcnt count uniform
-#pragma unroll
-            for (int i = 0; i < TN; i++)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wbase[i] + (long)sc * 64),
-                                                 (__attribute__((address_space(3))) void*)(ring + (slot * TN + i) * 1024), 16, 0, 0);
-        };
         // LDS reads of the main loop are inline asm: hipcc would otherwise drain every pending LDS-DMA (vmcnt(0))
         // in front of each ds_read.  Fragments of step s+1 are read while the MFMAs of step s run (sets A/B).
         uint4 xA[TM], wA[TN], xB[TM], wB[TN];
@@ -536,7 +596,6 @@ __global__ __launch_bounds__(256, MINW) void convslab_kernel(const GemmArgs a) {
             return (unsigned)((xrow0 + d) * SLAB_PITCH + koff);
         };
         if (a.dbg & 2) continue;
-        dma(0, 0); dma(1, 1); dma(2, 2);
         if (TN == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         unsigned rowoff = rowoff_of(0);
         rd(xA, wA, 0, rowoff, 0);
