@@ -23,4 +23,4 @@ for k in sorted(ks, key=lambda k: -k['ms']):
 if os.environ.get("ZVX_TS"):
     ts = ctx.fetch("dbg_ts", (8, 16))
     print("s_memtime deltas (100 MHz ticks -> us = ticks/100) of sampled workgroups: start, fill0, mma0, fill1, mma1, bar, epi, drained")
-    for r in ts[:3]: print("   ", [round(float(v) / 100.0, 2) for v in r])
+    for r in ts[:8]: print("   ", [round(float(v) / 100.0, 2) for v in r])

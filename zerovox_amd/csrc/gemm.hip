@@ -95,12 +95,13 @@ __device__ __forceinline__ void epilogue(const GemmArgs& a, f32x16 (&acc)[TN][TM
                     for (int e = 0; e < 4; e++) v[e] += rr[e];
                 }
                 if (a.accum_mode) {
-                    float* ap = a.accum + aoff + (long)r * a.lda + n;
+                    const long ai = aoff + (long)r * a.lda + n;
                     if (a.accum_mode & 1) {
-                        const float4 t = *(const float4*)ap;
-                        v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
+                        float t[4];
+                        load4_dyn(a.accum, a.accum_dtype, ai, t);
+                        v[0] += t[0]; v[1] += t[1]; v[2] += t[2]; v[3] += t[3];
                     }
-                    if (a.accum_mode & 2) *(float4*)ap = make_float4(v[0], v[1], v[2], v[3]);
+                    if (a.accum_mode & 2) store4_dyn(a.accum, a.accum_dtype, ai, v);
                 }
                 if (a.out) {
 #pragma unroll
@@ -273,11 +274,11 @@ __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
     return __builtin_bit_cast(unsigned, v);
 }
 
-template <int TM, int TN, bool RES_LDS = false>
+template <int TM, int TN, int RES_LDS = 0>   // residual source: 0 global memory, 1 padded LDS slab, 64 / 32: XOR-swizzled LDS slab of that many channels
 __device__ __forceinline__ void epilogue_rows(const GemmArgs& a, f32x16 (&acc)[TN][TM], int b, int row_base, int col_base,
                                               int out_len, int lane, unsigned char* stage /* >= 32*(TN*32*4+16) bytes, this wave's */,
-                                              const unsigned char* res_lds = nullptr /* RES_LDS: LDS row of output row `row_base` */,
-                                              int res_pitch = 0) {
+                                              const unsigned char* res_lds = nullptr /* RES_LDS 1: LDS row of output row `row_base`; > 1: slab base */,
+                                              int res_pitch = 0, int res_row0 = 0 /* RES_LDS > 1: slab row of output row `row_base` */) {
     constexpr int NW = TN * 32;                 // channels handled by this wave
     constexpr int EP = NW * 4 + 16;             // LDS row pitch in bytes
     constexpr int LPR = NW / 8;                 // lanes per row
@@ -291,6 +292,7 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs& a, f32x16 (&acc)[T
     const float alpha = a.alpha, oscale = a.out_scale, slope = a.slope, rinv = a.res_inv_slope;
     const int act = a.act, res_mode = RES_LDS ? 2 : a.res_mode, accum_mode = a.accum_mode, bias_mode = a.bias_mode;
     const bool has_out = a.out != nullptr, out_bf16 = a.out_dtype == DT_BF16, has_post = a.post_scale != nullptr;
+    const bool acc_bf16 = a.accum_dtype == DT_BF16;
     float bcol[8];
 #pragma unroll
     for (int e = 0; e < 8; e++) bcol[e] = 0.f;
@@ -301,7 +303,7 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs& a, f32x16 (&acc)[T
     u32x4 pk[TM][NP];                            // bf16 results, stored in one burst at the end
     // bf16 residual rows from global memory are requested one 32-row block ahead (their latency hides behind the
     // previous block's LDS transpose + arithmetic)
-    const bool res_glb = !RES_LDS && res_mode && a.res_dtype == DT_BF16;
+    const bool res_glb = !RES_LDS && res_mode && a.res_dtype == DT_BF16 && !(a.dbg & 64);
     uint4 rnext[NP];
     auto res_prefetch = [&](int j) {
 #pragma unroll
@@ -326,6 +328,7 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs& a, f32x16 (&acc)[T
         float v[NP][8];
         uint4 rraw[NP];
         float4 aa0[NP], aa1[NP];
+        uint4 aab[NP];
         bool ok[NP];
         if (res_glb) {
 #pragma unroll
@@ -339,10 +342,15 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs& a, f32x16 (&acc)[T
             ok[p] = r < a.M && r < out_len && nok;
             const float4 v0 = *(const float4*)(stage + rl * EP + c8 * 32), v1 = *(const float4*)(stage + rl * EP + c8 * 32 + 16);
             v[p][0] = v0.x; v[p][1] = v0.y; v[p][2] = v0.z; v[p][3] = v0.w; v[p][4] = v1.x; v[p][5] = v1.y; v[p][6] = v1.z; v[p][7] = v1.w;
-            if (RES_LDS) rraw[p] = *(const uint4*)(res_lds + (j * 32 + rl) * res_pitch + (col_base + c8 * 8) * 2);
+            if (RES_LDS == 1) rraw[p] = *(const uint4*)(res_lds + (j * 32 + rl) * res_pitch + (col_base + c8 * 8) * 2);
+            else if (RES_LDS > 1) {
+                const int sr = res_row0 + j * 32 + rl, f = RES_LDS == 64 ? (sr >> 1) & 7 : (sr >> 2) & 3;
+                rraw[p] = *(const uint4*)(res_lds + sr * (RES_LDS * 2) + ((((col_base >> 3) + c8) ^ f) << 4));
+            }
             if (accum_mode & 1) {
-                const float* ap = a.accum + (ok[p] ? aoff + (long)r * a.lda + n : 0);
-                aa0[p] = *(const float4*)ap; aa1[p] = *(const float4*)(ap + 4);
+                const long ai = ok[p] ? aoff + (long)r * a.lda + n : 0;
+                if (acc_bf16) aab[p] = *(const uint4*)((const unsigned short*)a.accum + ai);
+                else { const float* ap = (const float*)a.accum + ai; aa0[p] = *(const float4*)ap; aa1[p] = *(const float4*)(ap + 4); }
             }
         }
         // phase B: arithmetic (uniform branches outside the element loops)
@@ -383,13 +391,26 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs& a, f32x16 (&acc)[T
                 }
             }
             if (accum_mode & 1) {
-                t[0] += aa0[p].x; t[1] += aa0[p].y; t[2] += aa0[p].z; t[3] += aa0[p].w;
-                t[4] += aa1[p].x; t[5] += aa1[p].y; t[6] += aa1[p].z; t[7] += aa1[p].w;
+                if (acc_bf16) {
+                    t[0] += __uint_as_float(aab[p].x << 16); t[1] += __uint_as_float(aab[p].x & 0xffff0000u);
+                    t[2] += __uint_as_float(aab[p].y << 16); t[3] += __uint_as_float(aab[p].y & 0xffff0000u);
+                    t[4] += __uint_as_float(aab[p].z << 16); t[5] += __uint_as_float(aab[p].z & 0xffff0000u);
+                    t[6] += __uint_as_float(aab[p].w << 16); t[7] += __uint_as_float(aab[p].w & 0xffff0000u);
+                } else {
+                    t[0] += aa0[p].x; t[1] += aa0[p].y; t[2] += aa0[p].z; t[3] += aa0[p].w;
+                    t[4] += aa1[p].x; t[5] += aa1[p].y; t[6] += aa1[p].z; t[7] += aa1[p].w;
+                }
             }
             if ((accum_mode & 2) && ok[p]) {
-                float* ap = a.accum + aoff + (long)r * a.lda + n;
-                *(float4*)ap = make_float4(t[0], t[1], t[2], t[3]);
-                *(float4*)(ap + 4) = make_float4(t[4], t[5], t[6], t[7]);
+                const long ai = aoff + (long)r * a.lda + n;
+                if (acc_bf16) {
+                    *(u32x4*)((unsigned short*)a.accum + ai) =
+                        (u32x4){pack_bf16x2(t[0], t[1]), pack_bf16x2(t[2], t[3]), pack_bf16x2(t[4], t[5]), pack_bf16x2(t[6], t[7])};
+                } else {
+                    float* ap = (float*)a.accum + ai;
+                    *(float4*)ap = make_float4(t[0], t[1], t[2], t[3]);
+                    *(float4*)(ap + 4) = make_float4(t[4], t[5], t[6], t[7]);
+                }
             }
             if (has_out) {
                 if (oscale != 1.f) {
@@ -428,7 +449,10 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs& a, f32x16 (&acc)[T
 #pragma unroll
             for (int p = 0; p < NP; p++) {
                 const int r = row_base + j * 32 + p * RPP + lane / LPR;
-                if (r < a.M && r < out_len && nok) *(u32x4*)(obase + (long)r * ldo) = pk[j][p];
+                if (r < a.M && r < out_len && nok && (!(a.dbg & 32) || pk[j][p][0] == 0x12345678u)) {
+                    if (a.dbg & 16) __builtin_nontemporal_store(pk[j][p], (u32x4*)(obase + (long)r * ldo));
+                    else *(u32x4*)(obase + (long)r * ldo) = pk[j][p];
+                }
             }
     }
 }
@@ -480,7 +504,7 @@ void launch_pack_weights(const void* w_bf16, int ntaps, int N, int K, void* out,
                        (unsigned short*)out, nkc, total);
 }
 
-template <int BM, int BN, int WM, int WN, bool FULLK, int MINW>
+template <int BM, int BN, int WM, int WN, bool FULLK, int MINW, int R>
 __global__ __launch_bounds__(256, MINW) void convslab_kernel(const GemmArgs a) {
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int NIT = ((BM + 64) * 8 + 255) / 256;      // staging iterations (halo <= 64 rows)
@@ -514,42 +538,42 @@ __global__ __launch_bounds__(256, MINW) void convslab_kernel(const GemmArgs a) {
 #pragma unroll
             for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
 
-    // this wave's first 32-channel tile and its packed-weight stream
-    const int nt32 = (n0 + wc * (BN / WN)) >> 5;
+    // ---- weights: ONE ring per workgroup, filled by LDS-DMA (global_load_lds, 1 KiB fragment per instruction) ----
+    // The packed stream of a 32-channel tile is contiguous over (K-chunk, tap, k16): global step gs lives at
+    // tile base + gs KiB.  Ring slot gs % R holds the F fragments (all channel tiles of the workgroup) of step gs;
+    // wave w requests fragments [w*CNT, w*CNT+CNT) of every step, D = R-1 steps ahead of the MFMAs, so each
+    // fragment is fetched once per workgroup.  Per step: this wave's counted vmcnt (its pieces of step s+1 have
+    // landed) + s_barrier (so have everyone else's; and every wave is done reading slot s-1, which the next
+    // request overwrites).  No VGPR staging, no fence: DMAs stay in flight across the barrier.
+    constexpr int F = BN / 32, CNT = F >= 4 ? F / 4 : 1, D = R - 1, WAITN = (D - 2) * CNT;
     const int nt32_total = (a.N + 31) >> 5;
-    const uint4* Wq = (const uint4*)a.Wp;
+    const int nsteps = a.ntaps * 4, gtotal = nkc * nsteps;
+    const uint4* wsrc[CNT];
+#pragma unroll
+    for (int j = 0; j < CNT; j++) {
+        const int f = wave * CNT + j, t32 = (n0 >> 5) + f;
+        wsrc[j] = (const uint4*)a.Wp + (long)(t32 < nt32_total ? t32 : 0) * gtotal * 64 + lane;
+    }
     const int xrow0 = HL + wr * (BM / WM) + (lane & 31);
     const int koff = (lane >> 5) * 16;
-    unsigned char* ring = slab + ((SR * SLAB_PITCH + 1023) & ~1023) + wave * (4 * TN * 1024);
+    unsigned char* ring = slab + ((SR * SLAB_PITCH + 1023) & ~1023);
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)slab;   // LDS byte address of the window
     const int dvreg = a.dv[lane & (ZVX_MAX_TAPS - 1)];              // lane t holds tap t's row offset (read back with v_readlane)
+    const bool loader = wave * CNT < F;
+    auto dma = [&](int gs) {
+        if ((a.dbg & 8) || !loader) return;
+        const int slot = gs & (R - 1);
+        const long off = (long)(gs < gtotal ? gs : gtotal - 1) * 64;      // past the end: harmless re-loads keep vmcnt counting uniform
+#pragma unroll
+        for (int j = 0; j < CNT; j++)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[j] + off),
+                                             (__attribute__((address_space(3))) void*)(ring + (slot * F + wave * CNT + j) * 1024), 16, 0, 0);
+    };
+    // the first D steps are requested BEFORE the slab fill so that their L2 latency overlaps the fill's
+#pragma unroll
+    for (int s0 = 0; s0 < D; s0++) dma(s0);
 
     for (int kc = 0; kc < nkc; kc++) {
-        if (kc) __syncthreads();
-        // ---- weights: per-wave LDS ring filled by LDS-DMA (global_load_lds, 1 KiB fragment per instruction) ----
-        // The packed weight stream of this wave's channel tiles is contiguous over (tap, k16): step st = tap*4+kk
-        // lives at wbase + st KiB and lands in ring slot kk.  DMAs run 3 steps ahead of the MFMAs; the only
-        // synchronisation is this wave's own counted vmcnt (no barrier, no VGPR staging).
-        const uint4* wbase[TN];
-#pragma unroll
-        for (int i = 0; i < TN; i++) {
-            const int t32 = nt32 + i;
-            wbase[i] = Wq + (((long)(t32 < nt32_total ? t32 : 0) * nkc + kc) * ntaps) * 4 * 64 + lane;
-        }
-        const int nsteps = ntaps * 4;
-        const long next_chunk = (kc + 1 < nkc) ? (long)ntaps * 4 * 64 : -1;   // packed stream: chunk kc+1 follows chunk kc
-        auto dma = [&](int st, int slot) {
-            // tail (st >= nsteps): these three requests ARE the next K-chunk's first fragments (slots 0..2) -- its weight
-            // latency hides behind this chunk's last MFMAs and the slab refill; on the last chunk: harmless re-loads
-            long off = (long)st * 64;
-            if (st >= nsteps) off = next_chunk >= 0 ? next_chunk + (long)(st - nsteps) * 64 : (long)(nsteps - 1) * 64;
-#pragma unroll
-            for (int i = 0; i < TN; i++)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wbase[i] + off),
-                                                 (__attribute__((address_space(3))) void*)(ring + (slot * TN + i) * 1024), 16, 0, 0);
-        };
-        // the first three weight fragments are requested BEFORE the slab fill so that their L2 latency overlaps the fill's
-        if (!(a.dbg & 2) && kc == 0) { dma(0, 0); dma(1, 1); dma(2, 2); }    // later chunks: requested by the previous chunk's tail
         // ---- stage the slab: rows [m0-HL, m0+BM+HR) x 64 channels of chunk kc (all loads in flight, then the stores) ----
         {
             uint4 sv[NIT];
@@ -561,24 +585,27 @@ __global__ __launch_bounds__(256, MINW) void convslab_kernel(const GemmArgs a) {
                 sv[it] = make_uint4(0, 0, 0, 0);
                 if (!(a.dbg & 4) && c < SR * 8 && g >= 0 && g < in_len && k < a.K) sv[it] = *(const uint4*)(Xp + (long)g * a.ldx + k);
             }
+            if (kc) __syncthreads();              // (after the refill loads are in flight) every wave is done with chunk kc-1's slab
 #pragma unroll
             for (int it = 0; it < NIT; it++) {
                 const int c = tid + it * 256;
                 if (c < SR * 8) *(uint4*)(slab + (c >> 3) * SLAB_PITCH + (c & 7) * 16) = sv[it];
             }
         }
-        __syncthreads();
+        __syncthreads();                          // (drains this wave's DMAs too: the chunk's first D steps are in the ring)
         int nk16 = 4;
         if (!FULLK) { nk16 = n16 - kc * 4; if (nk16 > 4) nk16 = 4; }
 
         // LDS reads of the main loop are inline asm: hipcc would otherwise drain every pending LDS-DMA (vmcnt(0))
         // in front of each ds_read.  Fragments of step s+1 are read while the MFMAs of step s run (sets A/B).
         uint4 xA[TM], wA[TN], xB[TM], wB[TN];
-        const unsigned ring_rd = (unsigned)(size_t)(ring - slab) + lane * 16;     // byte offset inside the dynamic LDS window
-        auto rd = [&](uint4 (&xf)[TM], uint4 (&wf)[TN], int slot, unsigned rowoff, int kk) {
+        const unsigned ring_rd = lds_base + (unsigned)(size_t)(ring - slab) + lane * 16 + wc * TN * 1024;
+        const int gs0 = kc * nsteps;
+        auto rd = [&](uint4 (&xf)[TM], uint4 (&wf)[TN], int gs, unsigned rowoff, int kk) {
+            const unsigned wa = ring_rd + (gs & (R - 1)) * (F * 1024);
 #pragma unroll
             for (int i = 0; i < TN; i++)
-                asm volatile("ds_read_b128 %0, %1" : "=v"(wf[i]) : "v"(lds_base + ring_rd + (slot * TN + i) * 1024));
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(wf[i]) : "v"(wa), "n"(i * 1024));
 #pragma unroll
             for (int j = 0; j < TM; j++)
                 asm volatile("ds_read_b128 %0, %1" : "=v"(xf[j]) : "v"(lds_base + rowoff + j * 32 * SLAB_PITCH + kk * 32));
@@ -596,31 +623,29 @@ __global__ __launch_bounds__(256, MINW) void convslab_kernel(const GemmArgs a) {
             return (unsigned)((xrow0 + d) * SLAB_PITCH + koff);
         };
         if (a.dbg & 2) continue;
-        if (TN == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         unsigned rowoff = rowoff_of(0);
-        rd(xA, wA, 0, rowoff, 0);
+        rd(xA, wA, gs0, rowoff, 0);
         for (int tap = 0; tap < ntaps; tap++) {
             const unsigned rowoff_next = rowoff_of(tap + 1);
 #pragma unroll
             for (int kk = 0; kk < 4; kk++) {
-                dma(tap * 4 + kk + 3, (kk + 3) & 3);
-                // fragment of step s+1 must have landed: only the DMAs of steps s+2, s+3 may stay in flight
-                if (TN == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-                if (kk & 1) rd(xA, wA, (kk + 1) & 3, kk == 3 ? rowoff_next : rowoff, (kk + 1) & 3);
-                else        rd(xB, wB, (kk + 1) & 3, rowoff, kk + 1);
+                const int gs = gs0 + tap * 4 + kk;
+                // this wave's pieces of step gs+1 have landed: only its requests for steps gs+2 .. gs+D-1 may stay in flight
+                asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(WAITN) : "memory");
+                dma(gs + D);
+                if (kk & 1) rd(xA, wA, gs + 1, kk == 3 ? rowoff_next : rowoff, (kk + 1) & 3);
+                else        rd(xB, wB, gs + 1, rowoff, kk + 1);
                 // wait for THIS step's set only: the TM+TN reads just issued may remain outstanding
-                if (TM + TN == 6) asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
-                else if (TM + TN == 5) asm volatile("s_waitcnt lgkmcnt(5)" ::: "memory");
-                else if (TM + TN == 3) asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");
-                else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(TM + TN) : "memory");
                 __builtin_amdgcn_sched_barrier(0);
                 if (FULLK || kk < nk16) { if (kk & 1) mma(xB, wB); else mma(xA, wA); }
                 __builtin_amdgcn_sched_barrier(0);
             }
             rowoff = rowoff_next;
         }
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // drain tail DMAs / reads before ring and slab are reused
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the speculative reads of the chunk's last step
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // tail DMAs
     if (a.dbg & 1) { if (acc[0][0][0] == 123.456f) ((float*)a.out)[0] = 1.f; return; }
     __syncthreads();                             // every wave is done with the slab: its LDS becomes the transpose stage
     epilogue_rows<TM, TN>(a, acc, b, m0 + wr * (BM / WM), n0 + wc * (BN / WN), out_len, lane, slab + wave * (32 * (TN * 32 * 4 + 16)));
@@ -851,8 +876,319 @@ __global__ __launch_bounds__(256, MINW) void resfuse_kernel(const GemmArgs a) {
     __syncthreads();                                       // T1 is dead: its area becomes the transpose stage
     const int lim = (m0 + BMO < out_len) ? m0 + BMO : out_len;
     // residual x = inverse-lrelu of the slab rows of this tile (output row j <-> slab row j + H2 + H1): no global re-read
-    epilogue_rows<TM, 1, true>(a, acc, b, m0 + wrow, wc * 32, lim, lane, t1 + wave * (32 * (32 * 4 + 16)),
+    epilogue_rows<TM, 1, 1>(a, acc, b, m0 + wrow, wc * 32, lim, lane, t1 + wave * (32 * (32 * 4 + 16)),
                                slab + (wrow + H2 + H1) * PITCH_, PITCH_);
+}
+
+
+// ================================================================================================
+// resfuse, persistent form: the same fused ResBlock1 pair, but the weights are loaded ONCE per CU.
+// The per-tile version above re-fetches both convs' fragments (up to 88 KiB per wave) for every tile of
+// ~118 rows.  Here one 8-wave workgroup per CU loops over its tiles q_0, q_1, ... with wave-specialised roles;
+// in iteration i
+//     waves 0-3 (conv1, dilated):  request slab(q_i+2) by LDS-DMA;  T1(q_i) = lrelu(acc + b1) -> LDS;  acc = conv1(slab(q_i+1))
+//     waves 4-7 (conv2):           acc = conv2(T1(q_i-1));  out(q_i-1) = acc + b2 + x   (residual from slab(q_i-1), row-major epilogue)
+// so that on every SIMD (waves w and w+4 share one) the MFMA phase of one role runs beside the VALU/LDS/store
+// phase of the other.  Each wave keeps the weight fragments of ITS conv and ITS 32 output channels in registers
+// for the whole launch.  Slabs (4 rotating buffers, padded rows) are filled by `buffer_load_dwordx4 ... lds`
+// (bounds-checked: rows outside the utterance arrive as zeros; the pad slot of each row fetches nothing); the
+// DMA is inline asm, so hipcc schedules no waits for it -- the only vmcnt wait is the one in front of the
+// barrier that ends the iteration, a full iteration after the request.  T1 is double-buffered.
+// ================================================================================================
+// AM = accum_mode (bit0: += xs, bit1: xs = result), HAS_OUT: a bf16 output is written (act = leaky-relu with a.slope, or none).
+// Compile-time, because a run-time mode switch inside the epilogue makes hipcc merge the paths' `s_waitcnt vmcnt`s
+// (accumulator loads) into every launch, where they then wait for the previous tile's stores.
+typedef float f32x2 __attribute__((ext_vector_type(2)));      // float pairs: v_pk_add_f32 / v_pk_mul_f32 (two elements per VALU slot)
+__device__ __forceinline__ f32x2 unpack_bf16x2(unsigned u) { return (f32x2){__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u)}; }
+__device__ __forceinline__ f32x2 lrelu2(f32x2 v, float slope) { const f32x2 m = v * slope; return (f32x2){fmaxf(v.x, m.x), fmaxf(v.y, m.y)}; }     // 0 <= slope <= 1
+__device__ __forceinline__ f32x2 inv_lrelu2(f32x2 y, float inv_slope) { const f32x2 m = y * inv_slope; return (f32x2){fminf(y.x, m.x), fminf(y.y, m.y)}; }  // inv_slope >= 1
+
+template <int C, int NT, int AM, bool HAS_OUT>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void resfuse_persist_kernel(const GemmArgs a, int ntm, int ntiles) {
+    constexpr int KS = C / 16, CPR = C / 8, NTL = C / 32, RG = 4 / NTL, TM = 2;
+    constexpr int BM1 = 64 * RG;                          // T1 rows per tile (conv2's input incl. its halo)
+    constexpr int H2 = (NT - 1) / 2, BMO = BM1 - 2 * H2;  // output rows per tile
+    constexpr int P = C * 2 + 16, CPP = CPR + 1;          // padded row pitch (conflict-free b128 reads), 16-byte slots per row
+    constexpr int NW = NT * KS, NRES = NW > 36 ? 28 : NW; // fragments per wave / of those resident in registers (the rest: re-read from L2 per tile)
+    typedef __attribute__((ext_vector_type(4))) int i32x4;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform -> SGPRs, scalar branches
+    const int role = wave >> 2, w4 = wave & 3;
+    const int wc = w4 % NTL, wr = w4 / NTL, wrow = wr * 64;
+    const int H1 = a.halo_l, SR = BM1 + 2 * H1;
+    const int dil = a.dv1[1] - a.dv1[0];
+    const float slope1 = a.slope1;
+    const int SB = (SR * P + 1023) & ~1023;               // bytes per slab buffer (whole 1-KiB DMA pieces)
+    const int TB = ((BM1 + 2 * H2) * P + 15) & ~15;
+    unsigned char* const t1base = lds + 4 * SB;
+    unsigned char* const stage = t1base + 2 * TB + w4 * (32 * 80);          // conv2 waves: 32 rows x 32 ch bf16, pitch 80
+    float* const bias1_l = (float*)(t1base + 2 * TB + 4 * (32 * 80));
+    float* const bias2_l = bias1_l + C;
+    const unsigned lds_addr0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
+    const int G = gridDim.x;
+    if (tid < C) { bias1_l[tid] = a.bias1[tid]; bias2_l[tid] = a.bias[tid]; }
+
+    // this wave's weights: conv1 <- Wp2, conv2 <- Wp (packed stream [nt32][tap][4 k16 slots], 1 KiB fragments)
+    const uint4* const Wq = (const uint4*)(role ? a.Wp : a.Wp2) + ((long)wc * NT * 4) * 64 + lane;
+    uint4 w[NRES];
+#pragma unroll
+    for (int i = 0; i < NRES; i++) w[i] = Wq[((i / KS) * 4 + (i % KS)) * 64];
+
+    // this wave's bias (conv1: b1, conv2: b2) for its 16 channels per lane: registers when they are to spare, else LDS
+    constexpr bool BIAS_REG = NW <= 22;
+    const int h4 = 4 * (lane >> 5);
+    float4 bq[4];
+    if (BIAS_REG) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) bq[q] = *(const float4*)((role ? a.bias : a.bias1) + wc * 32 + 8 * q + h4);
+    }
+    // Settle every load issued so far HERE: a compiler-placed `s_waitcnt vmcnt(n)` at a first use inside the tile loop
+    // would also wait for the (hidden, in-order) slab DMAs of the conv1 waves and expose their full latency.
+#pragma unroll
+    for (int i = 0; i < NRES; i++) asm volatile("" :: "v"(w[i].x));
+    if (BIAS_REG) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) asm volatile("" :: "v"(bq[q].x));
+    }
+    __syncthreads();                                        // bias1_l / bias2_l visible
+    struct Tile { int t, b, m0, in_len, out_len; };
+    // per-utterance lengths through the scalar cache: a vector load here would make hipcc wait vmcnt(0) inside the tile
+    // loop, i.e. for every store (conv2 waves) or slab DMA (conv1 waves) still in flight
+    auto sload = [&](const int* p) { int v; asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory"); return v; };
+    auto load_tile = [&](int t) {
+        Tile q; q.t = -1; q.b = q.m0 = q.in_len = q.out_len = 0;
+        for (; t < ntiles; t += G) {
+            const int b = t / ntm, m0 = (t % ntm) * BMO, ol = a.out_len ? sload(a.out_len + b) : a.M;
+            if (m0 < ol) { q.t = t; q.b = b; q.m0 = m0; q.out_len = ol; q.in_len = a.in_len ? sload(a.in_len + b) : a.in_len_static; break; }
+        }
+        q.t = __builtin_amdgcn_readfirstlane(q.t); q.b = __builtin_amdgcn_readfirstlane(q.b); q.m0 = __builtin_amdgcn_readfirstlane(q.m0);
+        q.in_len = __builtin_amdgcn_readfirstlane(q.in_len); q.out_len = __builtin_amdgcn_readfirstlane(q.out_len);
+        return q;
+    };
+    // LDS-DMA of a tile's slab (global rows g0 = m0-H2-H1 ..) into buffer `buf`: piece p = 64 lanes x 16 B, lane-linear in
+    // LDS (padded rows: the 9th / 5th 16-byte slot of a row is the pad and fetches nothing).  The buffer descriptor is
+    // based at row g0, so the lane offsets are tile-independent (computed once); num_records ends at the utterance's last
+    // row (rows past it -> zeros), rows before its first row are sent out of range by hand.
+    constexpr int MAXP = 8;
+    constexpr bool VREL_REG = NW <= 22;
+    const int npieces = SB >> 10;
+    auto vrel_of = [&](int n) {
+        const int cp = (w4 + 4 * n) * 64 + lane, row = cp / CPP, qs = cp % CPP;
+        return qs == CPR ? -(1 << 30) : (row * a.ldx + (qs << 3)) * 2;
+    };
+    int vrel[VREL_REG ? MAXP : 1];
+    if (VREL_REG) {
+#pragma unroll
+        for (int n = 0; n < MAXP; n++) vrel[n] = vrel_of(n);
+    }
+    auto dma_slab = [&](const Tile& q, int buf) {
+        const int g0 = q.m0 - H2 - H1;
+        const unsigned long long pa = (unsigned long long)((const unsigned short*)a.X + (long)q.b * a.x_bs + (long)g0 * a.ldx);
+        const i32x4 rs = {__builtin_amdgcn_readfirstlane((int)(unsigned)pa), __builtin_amdgcn_readfirstlane((int)((pa >> 32) & 0xffff)),
+                          __builtin_amdgcn_readfirstlane((q.in_len - g0) * a.ldx * 2), 0x00020000};
+        const int thr = -g0 * a.ldx * 2;                    // offsets below this belong to rows before the utterance
+        const unsigned la0 = lds_addr0 + buf * SB + w4 * 1024;
+#pragma unroll
+        for (int n = 0; n < MAXP; n++) {
+            if (w4 + 4 * n < npieces) {
+                const int vr = VREL_REG ? vrel[VREL_REG ? n : 0] : vrel_of(n);
+                const int voff = vr < thr ? -16 : vr;
+                const unsigned la = __builtin_amdgcn_readfirstlane(la0 + n * 4096);
+                asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" :: "s"(la), "v"(voff), "s"(rs) : "memory", "m0");
+            }
+        }
+    };
+
+    Tile qA, qB, qC, qD;                                    // q_i-1 (conv2), q_i (T1 epilogue), q_i+1 (conv1 MFMA), q_i+2 (DMA)
+    qA = load_tile(ntiles); qB = qA;
+    qC = load_tile(blockIdx.x);
+    qD = qC.t >= 0 ? load_tile(qC.t + G) : qA;
+    if (role == 0 && qC.t >= 0) dma_slab(qC, 0);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    const int koff = (lane >> 5) * 16;
+    f32x16 acc[1][TM];
+    for (int ph = 0; qA.t >= 0 || qB.t >= 0 || qC.t >= 0; ph++) {
+        // slab buffer of q_n is n & 3 (q_i+1 <-> ph); T1 buffer of q_i is (ph-1) & 1
+        const Tile qE = qD.t >= 0 ? load_tile(qD.t + G) : qD;      // looked up early: its scalar loads hide behind the iteration
+        if (role == 0) {
+            if (qD.t >= 0) dma_slab(qD, (ph + 1) & 3);
+            if (qB.t >= 0) {
+                // ---- T1 = lrelu(acc + b1) as bf16, zero outside the sequence (conv2 zero-pads ITS input, hifigan.py:39-44) ----
+                unsigned char* t1 = t1base + ((ph - 1) & 1) * TB;
+#pragma unroll
+                for (int j = 0; j < TM; j++) {
+                    const int i = wrow + j * 32 + (lane & 31);
+                    const int g = qB.m0 - H2 + i;
+                    const bool inside = g >= 0 && g < qB.in_len;
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const int co = wc * 32 + 8 * q + h4;
+                        const float4 bb = BIAS_REG ? bq[q] : *(const float4*)(bias1_l + co);
+                        const f32x2 v01 = lrelu2((f32x2){acc[0][j][4 * q], acc[0][j][4 * q + 1]} + (f32x2){bb.x, bb.y}, slope1);
+                        const f32x2 v23 = lrelu2((f32x2){acc[0][j][4 * q + 2], acc[0][j][4 * q + 3]} + (f32x2){bb.z, bb.w}, slope1);
+                        uint2 pk;
+                        pk.x = inside ? pack_bf16x2(v01.x, v01.y) : 0u;
+                        pk.y = inside ? pack_bf16x2(v23.x, v23.y) : 0u;
+                        *(uint2*)(t1 + i * P + co * 2) = pk;
+                    }
+                }
+            }
+            if (qC.t >= 0) {
+                // ---- conv1 (dilated): T1 row i <-> global row m0 - H2 + i, reads slab rows i + H1 + (t - H2) * dil ----
+#pragma unroll
+                for (int j = 0; j < TM; j++)
+#pragma unroll
+                    for (int e = 0; e < 16; e++) acc[0][j][e] = 0.f;
+                const unsigned char* rowp0 = lds + (ph & 3) * SB + (wrow + (lane & 31) + H1 - H2 * dil) * P + koff;
+#pragma unroll
+                for (int t = 0; t < NT; t++) {
+                    const unsigned char* rowp = rowp0 + t * dil * P;
+#pragma unroll
+                    for (int kk = 0; kk < KS; kk++) {
+                        const uint4 wf = (t * KS + kk < NRES) ? w[t * KS + kk < NRES ? t * KS + kk : 0] : Wq[(t * 4 + kk) * 64];
+#pragma unroll
+                        for (int j = 0; j < TM; j++) {
+                            const uint4 xf = *(const uint4*)(rowp + j * 32 * P + kk * 32);
+                            acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf), __builtin_bit_cast(bf16x8, xf),
+                                                                               acc[0][j], 0, 0, 0);
+                        }
+                    }
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this iteration's slab request has landed
+        } else if (qA.t >= 0) {
+            // ---- conv2 (dilation 1): output row j <-> global m0 + j, reads T1 rows j + t ----
+#pragma unroll
+            for (int j = 0; j < TM; j++)
+#pragma unroll
+                for (int e = 0; e < 16; e++) acc[0][j][e] = 0.f;
+            const unsigned char* rowp = t1base + (ph & 1) * TB + (wrow + (lane & 31)) * P + koff;
+#pragma unroll
+            for (int t = 0; t < NT; t++)
+#pragma unroll
+                for (int kk = 0; kk < KS; kk++) {
+                    const uint4 wf = (t * KS + kk < NRES) ? w[t * KS + kk < NRES ? t * KS + kk : 0] : Wq[(t * 4 + kk) * 64];
+#pragma unroll
+                    for (int j = 0; j < TM; j++) {
+                        const uint4 xf = *(const uint4*)(rowp + (t + j * 32) * P + kk * 32);
+                        acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf), __builtin_bit_cast(bf16x8, xf),
+                                                                           acc[0][j], 0, 0, 0);
+                    }
+                }
+            const int lim = (qA.m0 + BMO < qA.out_len) ? qA.m0 + BMO : qA.out_len;
+            // ---- epilogue in the MFMA layout (lane = time row, 4 consecutive channels per quad): + b2, + x (inverse lrelu of
+            //      the slab rows of this tile: output row j <-> slab row j + H2 + H1), xs accumulation, activation; the bf16
+            //      results pass through a per-wave LDS stage only to be stored as whole 64-byte row segments ----
+            {
+                const float rinv = a.res_inv_slope, oscale = a.out_scale, slope = a.act == ACT_LRELU ? a.slope : 1.f;
+                const unsigned char* resp = lds + ((ph + 2) & 3) * SB + (wrow + H2 + H1 + (lane & 31)) * P + (wc * 32 + h4) * 2;
+                const long rm_off = wc * 32 + (lane & 3) * 8;       // row-major phase: this lane's 8 channels
+                unsigned short* accp = (unsigned short*)a.accum + (long)qA.b * a.a_bs + rm_off;
+                unsigned short* outp = (unsigned short*)a.out + (long)qA.b * a.o_bs + rm_off;
+                float4 bb[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) bb[q] = BIAS_REG ? bq[q] : *(const float4*)(bias2_l + wc * 32 + 8 * q + h4);
+                // running sum xs of the resblocks (bf16, row-major): requested up front, consumed in the copy-out phase
+                constexpr bool XS_EARLY = NW < 28;            // registers permitting, for the whole tile at once
+                uint4 xs[TM][2];
+                if ((AM & 1) && XS_EARLY) {
+#pragma unroll
+                    for (int j = 0; j < TM; j++)
+#pragma unroll
+                        for (int h = 0; h < 2; h++) {
+                            const int gr = qA.m0 + wrow + j * 32 + h * 16 + (lane >> 2);
+                            xs[j][h] = *(const uint4*)(accp + (gr < lim ? (long)gr * a.lda : 0));
+                        }
+                }
+#pragma unroll
+                for (int j = 0; j < TM; j++) {
+                    if ((AM & 1) && !XS_EARLY) {
+#pragma unroll
+                        for (int h = 0; h < 2; h++) {
+                            const int gr = qA.m0 + wrow + j * 32 + h * 16 + (lane >> 2);
+                            xs[j][h] = *(const uint4*)(accp + (gr < lim ? (long)gr * a.lda : 0));
+                        }
+                    }
+                    // MFMA layout: y = acc + b2 + x;  without xs the activation is applied here, with xs in the row-major phase
+                    uint2 rrj[4];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) rrj[q] = *(const uint2*)(resp + j * 32 * P + q * 16);
+                    uint2 pk[4];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        f32x2 v01 = (f32x2){acc[0][j][4 * q], acc[0][j][4 * q + 1]} + (f32x2){bb[q].x, bb[q].y} + inv_lrelu2(unpack_bf16x2(rrj[q].x), rinv);
+                        f32x2 v23 = (f32x2){acc[0][j][4 * q + 2], acc[0][j][4 * q + 3]} + (f32x2){bb[q].z, bb[q].w} + inv_lrelu2(unpack_bf16x2(rrj[q].y), rinv);
+                        if (!AM) { v01 = lrelu2(v01, slope); v23 = lrelu2(v23, slope); }      // slope 1 = no activation
+                        pk[q].x = pack_bf16x2(v01.x, v01.y);
+                        pk[q].y = pack_bf16x2(v23.x, v23.y);
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; q++) *(uint2*)(stage + (lane & 31) * 80 + (8 * q + h4) * 2) = pk[q];
+                    // row-major: 16 rows x 64 bytes per instruction
+                    uint4 o[2];
+#pragma unroll
+                    for (int h = 0; h < 2; h++) o[h] = *(const uint4*)(stage + (h * 16 + (lane >> 2)) * 80 + (lane & 3) * 16);
+#pragma unroll
+                    for (int h = 0; h < 2; h++) {
+                        const int gr = qA.m0 + wrow + j * 32 + h * 16 + (lane >> 2);
+                        if (AM) {
+                            f32x2 t[4] = {unpack_bf16x2(o[h].x), unpack_bf16x2(o[h].y), unpack_bf16x2(o[h].z), unpack_bf16x2(o[h].w)};
+                            if (AM & 1) {
+                                t[0] += unpack_bf16x2(xs[j][h].x); t[1] += unpack_bf16x2(xs[j][h].y);
+                                t[2] += unpack_bf16x2(xs[j][h].z); t[3] += unpack_bf16x2(xs[j][h].w);
+                            }
+                            if ((AM & 2) && gr < lim)
+                                *(u32x4*)(accp + (long)gr * a.lda) = (u32x4){pack_bf16x2(t[0].x, t[0].y), pack_bf16x2(t[1].x, t[1].y),
+                                                                            pack_bf16x2(t[2].x, t[2].y), pack_bf16x2(t[3].x, t[3].y)};
+                            if (HAS_OUT) {
+#pragma unroll
+                                for (int e = 0; e < 4; e++) t[e] = lrelu2(t[e] * oscale, slope);
+                                o[h] = make_uint4(pack_bf16x2(t[0].x, t[0].y), pack_bf16x2(t[1].x, t[1].y), pack_bf16x2(t[2].x, t[2].y), pack_bf16x2(t[3].x, t[3].y));
+                            }
+                        }
+                        if (HAS_OUT && gr < lim) *(uint4*)(outp + (long)gr * a.ldo) = o[h];
+                    }
+                }
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        qA = qB; qB = qC; qC = qD; qD = qE;
+    }
+}
+
+template <int C>
+static bool launch_resfuse_persist_c(const GemmArgs& a, hipStream_t stream) {
+    constexpr int BM1 = 64 * (4 / (C / 32));
+    const int h2 = (a.ntaps - 1) / 2, bmo = BM1 - 2 * h2;
+    const int ntm = (a.M + bmo - 1) / bmo, ntiles = ntm * a.nbatch;
+    static int ncu = 0;
+    if (!ncu) { int dev = 0; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) ncu = 256; }
+    dim3 grid(ntiles < ncu ? ntiles : ncu);
+    for (int t = 0; t < a.ntaps; t++)                      // the kernel derives the taps from (kernel size, dilation)
+        if (a.dv[t] != t - h2 || a.dv1[t] != (t - h2) * (a.dv1[1] - a.dv1[0])) return false;
+    const size_t sb = ((size_t)(BM1 + 2 * a.halo_l) * (C * 2 + 16) + 1023) & ~(size_t)1023;
+    const size_t tb = ((size_t)(BM1 + 2 * h2) * (C * 2 + 16) + 15) & ~(size_t)15;
+    const size_t lds = 4 * sb + 2 * tb + 4 * 32 * 80 + 2 * C * 4;
+    if (lds > 160 * 1024) return false;
+    // the in-kernel epilogue covers exactly what the vocoder asks for
+    if (a.alpha != 1.f || a.bias_mode != 1 || a.post_scale || (a.out && a.out_dtype != DT_BF16) || a.res_mode != 2 || a.ldo % 8 || (a.accum && (a.lda % 8 || a.accum_dtype != DT_BF16))) return false;
+    if (a.act != ACT_NONE && a.act != ACT_LRELU) return false;
+    if (!a.accum_mode && a.out_scale != 1.f) return false;
+    const int am = a.accum ? a.accum_mode : 0;
+    if (!a.out && !(am & 2)) return false;
+#define ZVX_RFP(NT_, AM_, HO_) hipLaunchKernelGGL((resfuse_persist_kernel<C, NT_, AM_, HO_>), grid, dim3(512), lds, stream, a, ntm, ntiles); return true
+#define ZVX_RFP_MODE(NT_) \
+    if (a.out) { if (am == 0) { ZVX_RFP(NT_, 0, true); } if (am == 1) { ZVX_RFP(NT_, 1, true); } if (am == 2) { ZVX_RFP(NT_, 2, true); } ZVX_RFP(NT_, 3, true); } \
+    else { if (am == 2) { ZVX_RFP(NT_, 2, false); } ZVX_RFP(NT_, 3, false); }
+    switch (a.ntaps) {
+        case 3: ZVX_RFP_MODE(3)
+        case 7: ZVX_RFP_MODE(7)
+        case 11: ZVX_RFP_MODE(11)
+    }
+#undef ZVX_RFP_MODE
+#undef ZVX_RFP
+    return false;
 }
 
 template <int C, int BM, int WM, int WN, int MINW>
@@ -878,6 +1214,12 @@ int launch_resfuse(GemmArgs a, hipStream_t stream) {
     if (h1 > 32) return -1;
     a.halo_l = a.halo_r = h1;
     a.fused = 1;
+    static const char* v1 = getenv("ZVX_RESFUSE_V1");
+    if (!v1) {
+        if (a.N == 32 && launch_resfuse_persist_c<32>(a, stream)) return 16;
+        // C = 64, k = 11: 44 fragments per wave do not fit beside the epilogue's registers (spills) -> per-tile kernel
+        if (a.N == 64 && a.ntaps != 11 && launch_resfuse_persist_c<64>(a, stream)) return 17;
+    }
     if (a.N == 32 && launch_resfuse_c<32, 256, 4, 1, 2>(a, stream)) return 16;
     if (a.N == 64 && launch_resfuse_c<64, 128, 2, 2, 2>(a, stream)) return 17;
     return -1;
@@ -898,10 +1240,10 @@ static const Variant kVariants[] = {
 const char* gemm_variant_name(int id) { return kVariants[id].name; }
 int gemm_num_variants() { return (int)(sizeof(kVariants) / sizeof(kVariants[0])); }
 
-template <int BM, int BN, int WM, int WN, int MINW>
+template <int BM, int BN, int WM, int WN, int MINW, int R>
 static void launch_slab_variant(const GemmArgs& a, dim3 grid, size_t lds, hipStream_t stream) {
-    if (a.K % SLAB_KC == 0) hipLaunchKernelGGL((convslab_kernel<BM, BN, WM, WN, true, MINW>), grid, dim3(256), lds, stream, a);
-    else hipLaunchKernelGGL((convslab_kernel<BM, BN, WM, WN, false, MINW>), grid, dim3(256), lds, stream, a);
+    if (a.K % SLAB_KC == 0) hipLaunchKernelGGL((convslab_kernel<BM, BN, WM, WN, true, MINW, R>), grid, dim3(256), lds, stream, a);
+    else hipLaunchKernelGGL((convslab_kernel<BM, BN, WM, WN, false, MINW, R>), grid, dim3(256), lds, stream, a);
 }
 
 static int launch_convslab(GemmArgs a, hipStream_t stream) {
@@ -922,19 +1264,26 @@ static int launch_convslab(GemmArgs a, hipStream_t stream) {
         if (best_cost < 0 || cost < best_cost - 1e-9) { best_cost = cost; best = i; }
     }
     static const int bms[4] = {128, 256, 256, 256};
-    const int bn = bns[best], bm = bms[best];
+    static const char* t128 = getenv("ZVX_T128");
+    static const int t128r = t128 ? atoi(t128) : 0;
+    int ring_slots = best == 0 ? 4 : 8;
+    int bn = bns[best], bm = bms[best];
+    if (t128r && best == 1) { bm = 128; ring_slots = t128r; }
     const int ntn = (a.N + bn - 1) / bn;
     const int ntm = (a.M + bm - 1) / bm;
     dim3 grid(ntn * ntm, a.nbatch);
     const int tn = (bn >= 128) ? 2 : 1;
-    size_t lds = (((size_t)(bm + hl + hr) * SLAB_PITCH + 1023) & ~(size_t)1023) + (size_t)4 * 4 * tn * 1024;
+    size_t lds = (((size_t)(bm + hl + hr) * SLAB_PITCH + 1023) & ~(size_t)1023) + (size_t)ring_slots * (bn / 32) * 1024;      // slab + weight ring (R slots x bn/32 KiB)
     const size_t stage = (size_t)4 * 32 * (tn * 128 + 16);
     if (lds < stage) lds = stage;
     switch (best) {
-        case 0: launch_slab_variant<128, 256, 1, 4, 2>(a, grid, lds, stream); break;
-        case 1: launch_slab_variant<256, 128, 2, 2, 2>(a, grid, lds, stream); break;
-        case 2: launch_slab_variant<256, 64, 2, 2, 2>(a, grid, lds, stream); break;
-        case 3: launch_slab_variant<256, 32, 4, 1, 2>(a, grid, lds, stream); break;
+        case 0: launch_slab_variant<128, 256, 1, 4, 2, 4>(a, grid, lds, stream); break;
+        case 1: if (t128r == 4) launch_slab_variant<128, 128, 2, 2, 4, 4>(a, grid, lds, stream);
+                else if (t128r == 8) launch_slab_variant<128, 128, 2, 2, 3, 8>(a, grid, lds, stream);
+                else launch_slab_variant<256, 128, 2, 2, 2, 8>(a, grid, lds, stream);
+                break;
+        case 2: launch_slab_variant<256, 64, 2, 2, 2, 8>(a, grid, lds, stream); break;
+        case 3: launch_slab_variant<256, 32, 4, 1, 2, 8>(a, grid, lds, stream); break;
     }
     return 6 + best;
 }

@@ -47,7 +47,7 @@ struct Tensor {
 
 struct DevBuf { void* p = nullptr; void* base = nullptr; size_t cap = 0; };
 
-struct GemmEvent { hipEvent_t a, b; int variant; double flops, bytes; };
+struct GemmEvent { hipEvent_t a, b; int variant; double flops, bytes; long rows; int N, K, taps, res, fused; };
 
 }  // namespace
 
@@ -136,7 +136,7 @@ struct zvx_ctx {
     void gemm(GemmArgs& a) {
         if (a.flops <= 0) a.flops = 2.0 * (double)a.M * a.nbatch * a.nheads * (double)a.N * (double)a.K * a.ntaps;
         { static const char* e = getenv("ZVX_DBG"); a.dbg = e ? atoi(e) : 0; }
-        { static const char* e = getenv("ZVX_TS"); if (e && a.M * (long)a.nbatch > 1000000 && a.N == 128 && a.K == 128 && a.ntaps == atoi(e) && !a.res_mode == (getenv("ZVX_TS_C1") != nullptr)) a.ts = (unsigned long long*)buf("dbg.ts", 8 * 16 * 8); }
+        { static const char* e = getenv("ZVX_TS"); if (e && a.M * (long)a.nbatch > 1000000 && a.N == (getenv("ZVX_TS_N") ? atoi(getenv("ZVX_TS_N")) : 128) && a.K == a.N && a.ntaps == atoi(e) && !a.res_mode == (getenv("ZVX_TS_C1") != nullptr)) a.ts = (unsigned long long*)buf("dbg.ts", 8 * 16 * 8); }
         if (!a.Wp && a.dtype == DT_BF16) { auto it = packed.find(a.W); if (it != packed.end()) a.Wp = it->second; }
         GemmEvent ev{};
         const bool prof = profile >= 2;
@@ -145,7 +145,7 @@ struct zvx_ctx {
         if (id < 0) fail(ZVX_E_INVALID, "launch_gemm rejected shape M=%d N=%d K=%d taps=%d", a.M, a.N, a.K, a.ntaps);
         if (prof) {
             HIPCHK(hipEventRecord(ev.b, stream));
-            ev.variant = id; ev.flops = a.flops;
+            ev.variant = id; ev.flops = a.flops; ev.rows = (long)a.M * a.nbatch * a.nheads; ev.N = a.N; ev.K = a.K; ev.taps = a.ntaps; ev.res = a.res_mode; ev.fused = a.fused;
             const double esz = dtype_size(a.dtype);
             ev.bytes = ((double)a.M * a.nbatch * a.nheads) * ((double)a.K * esz + (double)a.N * dtype_size(a.out_dtype)) +
                        (double)a.N * a.K * a.ntaps * esz;
@@ -160,6 +160,9 @@ struct zvx_ctx {
         for (auto& e : pending) {
             float ms = 0.f;
             HIPCHK(hipEventElapsedTime(&ms, e.a, e.b));
+            static const char* shape_log = getenv("ZVX_SHAPE_LOG");      // dev aid: one stderr line per launch
+            if (shape_log) fprintf(stderr, "launch %-24s rows=%-8ld N=%-4d K=%-4d taps=%-2d res=%d fused=%d  %8.3f ms %8.1f TF/s %8.1f GB/s(alg)\n",
+                                   gemm_variant_name(e.variant), e.rows, e.N, e.K, e.taps, e.res, e.fused, ms, e.flops / ms / 1e9, e.bytes / ms / 1e6);
             auto& s = stats[e.variant];
             s.launches++; s.ms += ms; s.flops += e.flops; s.bytes += e.bytes;
             event_pool.push_back(e.a); event_pool.push_back(e.b);
@@ -667,7 +670,7 @@ void run_vocoder(zvx_ctx* c, const float* mel, int ldm, int Lmel_max, const int*
     void* X0 = c->buf("voc.X0", maxel * es);      // upsampled stage tensor (activated)
     void* T1 = c->buf("voc.T1", maxel * es);
     void* PP[2] = {c->buf("voc.PP0", maxel * es), c->buf("voc.PP1", maxel * es)};
-    float* XS = c->fbuf("voc.XS", maxel);
+    void* XS = c->buf("voc.XS", maxel * es);     // running sum over the resblocks of a stage, in the activation dtype
     { static const char* sw = getenv("ZVX_SWAP_BUFS"); if (sw) { int m = atoi(sw); if (m & 1) std::swap(T1, PP[0]); if (m & 2) std::swap(T1, A); if (m & 4) std::swap(X0, PP[1]); } }
 
     launch_mel_pad(mel, DT_F32, ldm, Lmel_max, mel_len_d, vin, dt, nm, Pmax, P_d, B, nm, c->stream);     // model.py:331-335
@@ -754,7 +757,7 @@ void run_vocoder(zvx_ctx* c, const float* mel, int ldm, int Lmel_max, const int*
                     cur = PP[pp]; pp ^= 1;
                 } else {
                     // xs (+)= resblock output; last kernel size: x = xs / num_kernels, stored activated for the next stage
-                    a.accum = XS; a.a_bs = (long)rows * Cout; a.lda = Cout;
+                    a.accum = XS; a.accum_dtype = dt; a.a_bs = (long)rows * Cout; a.lda = Cout;
                     if (nk == 1) { a.accum_mode = 0; a.accum = nullptr; }
                     else if (j == 0) a.accum_mode = 2;
                     else if (j < nk - 1) a.accum_mode = 3;

@@ -54,7 +54,8 @@ struct GemmArgs {
     const float* bias; int bias_mode;            // 0 none, 1 per n, 2 per row r
     const void* res; long r_bs, r_hs; int ldr; int res_dtype; int res_mode;  // 0 none, 1 raw, 2 inverse leaky-relu
     float res_inv_slope;                         // res_mode 2: x = y >= 0 ? y : y * res_inv_slope
-    float* accum; long a_bs; int lda; int accum_mode;  // bit0: v += accum, bit1: accum = v (after add)
+    void* accum; long a_bs; int lda; int accum_mode;   // bit0: v += accum, bit1: accum = v (after add)
+    int accum_dtype;                             // DT_F32 / DT_BF16 storage of the running sum
     float out_scale;
     int act; float slope;
     const float* post_scale; const float* post_shift;
