@@ -274,36 +274,53 @@ __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
     return __builtin_bit_cast(unsigned, v);
 }
 
-template <int TM, int TN, int RES_LDS = 0>   // residual source: 0 global memory, 1 padded LDS slab, 64 / 32: XOR-swizzled LDS slab of that many channels
+typedef float f32x2 __attribute__((ext_vector_type(2)));      // float pairs: v_pk_add_f32 / v_pk_mul_f32 (two elements per VALU slot)
+__device__ __forceinline__ f32x2 unpack_bf16x2(unsigned u) { return (f32x2){__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u)}; }
+__device__ __forceinline__ f32x2 lrelu2(f32x2 v, float slope) { const f32x2 m = v * slope; return (f32x2){fmaxf(v.x, m.x), fmaxf(v.y, m.y)}; }     // 0 <= slope <= 1
+__device__ __forceinline__ f32x2 inv_lrelu2(f32x2 y, float inv_slope) { const f32x2 m = y * inv_slope; return (f32x2){fminf(y.x, m.x), fminf(y.y, m.y)}; }  // inv_slope >= 1
+
+// Epilogue modes known at compile time (EPI >= 0) cover the HiFi-GAN convolutions: alpha = 1, per-channel bias, bf16
+// output (or none), activation none / leaky-relu, bf16 residual in the activated domain, bf16 running sum.
+//   bit 0: residual (res_mode 2)   bits 1-2: accum_mode   bit 3: an output is written
+// EPI < 0: everything is read from GemmArgs at run time (decoder GEMMs, f32 outputs, per-row bias, ...).  A run-time
+// switch costs more than its branches: hipcc merges the `s_waitcnt vmcnt` of the untaken paths' loads into every launch.
+#define ZVX_EPI(res, am, out) ((res) | ((am) << 1) | ((out) << 3))
+
+template <int TM, int TN, int RES_LDS = 0, int EPI = -1>   // RES_LDS: residual source: 0 global memory, 1 padded LDS slab
 __device__ __forceinline__ void epilogue_rows(const GemmArgs& a, f32x16 (&acc)[TN][TM], int b, int row_base, int col_base,
                                               int out_len, int lane, unsigned char* stage /* >= 32*(TN*32*4+16) bytes, this wave's */,
-                                              const unsigned char* res_lds = nullptr /* RES_LDS 1: LDS row of output row `row_base`; > 1: slab base */,
-                                              int res_pitch = 0, int res_row0 = 0 /* RES_LDS > 1: slab row of output row `row_base` */) {
+                                              const unsigned char* res_lds = nullptr /* RES_LDS 1: LDS row of output row `row_base` */,
+                                              int res_pitch = 0) {
     constexpr int NW = TN * 32;                 // channels handled by this wave
     constexpr int EP = NW * 4 + 16;             // LDS row pitch in bytes
     constexpr int LPR = NW / 8;                 // lanes per row
     constexpr int RPP = 64 / LPR;               // rows per pass
     constexpr int NP = 32 / RPP;
+    constexpr bool CT = EPI >= 0;
+    constexpr bool BURST = !(CT && ((EPI >> 1) & 1));       // xs-reading modes hold more registers: store each row block at once
     const long ooff = (long)b * a.o_bs, roff = (long)b * a.r_bs, aoff = (long)b * a.a_bs;
     const int c8 = lane % LPR;
     const int n = col_base + c8 * 8;
     const bool nok = n < a.N;
-    // wave-uniform mode words, read once
-    const float alpha = a.alpha, oscale = a.out_scale, slope = a.slope, rinv = a.res_inv_slope;
-    const int act = a.act, res_mode = RES_LDS ? 2 : a.res_mode, accum_mode = a.accum_mode, bias_mode = a.bias_mode;
-    const bool has_out = a.out != nullptr, out_bf16 = a.out_dtype == DT_BF16, has_post = a.post_scale != nullptr;
-    const bool acc_bf16 = a.accum_dtype == DT_BF16;
-    float bcol[8];
+    // mode words: compile-time constants or wave-uniform run-time values, read once
+    const float alpha = CT ? 1.f : a.alpha, oscale = a.out_scale, rinv = a.res_inv_slope;
+    const int act = CT ? ACT_LRELU : a.act;
+    const float slope = CT ? (a.act == ACT_LRELU ? a.slope : 1.f) : a.slope;        // CT: slope 1 = no activation
+    const int res_mode = RES_LDS ? 2 : (CT ? ((EPI & 1) ? 2 : 0) : a.res_mode);
+    const int accum_mode = CT ? (EPI >> 1) & 3 : a.accum_mode, bias_mode = CT ? 1 : a.bias_mode;
+    const bool has_out = CT ? (EPI >> 3) & 1 : a.out != nullptr, out_bf16 = CT || a.out_dtype == DT_BF16, has_post = !CT && a.post_scale != nullptr;
+    const bool acc_bf16 = CT || a.accum_dtype == DT_BF16, res_bf16 = CT || RES_LDS || a.res_dtype == DT_BF16;
+    f32x2 bcol[4];
 #pragma unroll
-    for (int e = 0; e < 8; e++) bcol[e] = 0.f;
+    for (int e = 0; e < 4; e++) bcol[e] = (f32x2){0.f, 0.f};
     if (bias_mode == 1 && nok) {
         const float4 b0 = *(const float4*)(a.bias + n), b1 = *(const float4*)(a.bias + n + 4);
-        bcol[0] = b0.x; bcol[1] = b0.y; bcol[2] = b0.z; bcol[3] = b0.w; bcol[4] = b1.x; bcol[5] = b1.y; bcol[6] = b1.z; bcol[7] = b1.w;
+        bcol[0] = (f32x2){b0.x, b0.y}; bcol[1] = (f32x2){b0.z, b0.w}; bcol[2] = (f32x2){b1.x, b1.y}; bcol[3] = (f32x2){b1.z, b1.w};
     }
     u32x4 pk[TM][NP];                            // bf16 results, stored in one burst at the end
     // bf16 residual rows from global memory are requested one 32-row block ahead (their latency hides behind the
     // previous block's LDS transpose + arithmetic)
-    const bool res_glb = !RES_LDS && res_mode && a.res_dtype == DT_BF16 && !(a.dbg & 64);
+    const bool res_glb = !RES_LDS && res_mode && res_bf16;
     uint4 rnext[NP];
     auto res_prefetch = [&](int j) {
 #pragma unroll
@@ -323,9 +340,8 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs& a, f32x16 (&acc)[T
             for (int g = 0; g < 4; g++)
                 *(float4*)(stage + (lane & 31) * EP + (i * 32 + 8 * g + 4 * (lane >> 5)) * 4) =
                     make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
-        __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0): the wave's own LDS writes have landed
         // phase A: every load of the 32-row block in flight at once (branch-free: invalid lanes read element 0)
-        float v[NP][8];
+        f32x2 v[NP][4];
         uint4 rraw[NP];
         float4 aa0[NP], aa1[NP];
         uint4 aab[NP];
@@ -341,107 +357,98 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs& a, f32x16 (&acc)[T
             const int r = row_base + j * 32 + rl;
             ok[p] = r < a.M && r < out_len && nok;
             const float4 v0 = *(const float4*)(stage + rl * EP + c8 * 32), v1 = *(const float4*)(stage + rl * EP + c8 * 32 + 16);
-            v[p][0] = v0.x; v[p][1] = v0.y; v[p][2] = v0.z; v[p][3] = v0.w; v[p][4] = v1.x; v[p][5] = v1.y; v[p][6] = v1.z; v[p][7] = v1.w;
+            v[p][0] = (f32x2){v0.x, v0.y}; v[p][1] = (f32x2){v0.z, v0.w}; v[p][2] = (f32x2){v1.x, v1.y}; v[p][3] = (f32x2){v1.z, v1.w};
             if (RES_LDS == 1) rraw[p] = *(const uint4*)(res_lds + (j * 32 + rl) * res_pitch + (col_base + c8 * 8) * 2);
-            else if (RES_LDS > 1) {
-                const int sr = res_row0 + j * 32 + rl, f = RES_LDS == 64 ? (sr >> 1) & 7 : (sr >> 2) & 3;
-                rraw[p] = *(const uint4*)(res_lds + sr * (RES_LDS * 2) + ((((col_base >> 3) + c8) ^ f) << 4));
-            }
             if (accum_mode & 1) {
                 const long ai = ok[p] ? aoff + (long)r * a.lda + n : 0;
                 if (acc_bf16) aab[p] = *(const uint4*)((const unsigned short*)a.accum + ai);
                 else { const float* ap = (const float*)a.accum + ai; aa0[p] = *(const float4*)ap; aa1[p] = *(const float4*)(ap + 4); }
             }
         }
-        // phase B: arithmetic (uniform branches outside the element loops)
+        // phase B: arithmetic on float pairs (uniform branches outside the element loops)
 #pragma unroll
         for (int p = 0; p < NP; p++) {
             const int r = row_base + j * 32 + p * RPP + lane / LPR;
-            float* t = v[p];
+            f32x2* t = v[p];
             if (alpha != 1.f) {
 #pragma unroll
-                for (int e = 0; e < 8; e++) t[e] *= alpha;
+                for (int e = 0; e < 4; e++) t[e] *= alpha;
             }
             if (bias_mode == 1) {
 #pragma unroll
-                for (int e = 0; e < 8; e++) t[e] += bcol[e];
+                for (int e = 0; e < 4; e++) t[e] += bcol[e];
             } else if (bias_mode == 2) {
                 const float brow = ok[p] ? a.bias[r] : 0.f;
 #pragma unroll
-                for (int e = 0; e < 8; e++) t[e] += brow;
+                for (int e = 0; e < 4; e++) t[e] += brow;
             }
             if (res_mode) {
-                float q[8];
-                if (RES_LDS || a.res_dtype == DT_BF16) {
-                    q[0] = __uint_as_float(rraw[p].x << 16); q[1] = __uint_as_float(rraw[p].x & 0xffff0000u);
-                    q[2] = __uint_as_float(rraw[p].y << 16); q[3] = __uint_as_float(rraw[p].y & 0xffff0000u);
-                    q[4] = __uint_as_float(rraw[p].z << 16); q[5] = __uint_as_float(rraw[p].z & 0xffff0000u);
-                    q[6] = __uint_as_float(rraw[p].w << 16); q[7] = __uint_as_float(rraw[p].w & 0xffff0000u);
+                f32x2 q[4];
+                if (res_bf16) {
+                    q[0] = unpack_bf16x2(rraw[p].x); q[1] = unpack_bf16x2(rraw[p].y); q[2] = unpack_bf16x2(rraw[p].z); q[3] = unpack_bf16x2(rraw[p].w);
                 } else {
                     const float* rp = (const float*)a.res + (ok[p] ? roff + (long)r * a.ldr + n : 0);
                     const float4 t0 = *(const float4*)rp, t1 = *(const float4*)(rp + 4);
-                    q[0] = t0.x; q[1] = t0.y; q[2] = t0.z; q[3] = t0.w; q[4] = t1.x; q[5] = t1.y; q[6] = t1.z; q[7] = t1.w;
+                    q[0] = (f32x2){t0.x, t0.y}; q[1] = (f32x2){t0.z, t0.w}; q[2] = (f32x2){t1.x, t1.y}; q[3] = (f32x2){t1.z, t1.w};
                 }
                 if (res_mode == 2) {            // inverse leaky-relu (1/slope > 1): x = min(y, y/slope)
 #pragma unroll
-                    for (int e = 0; e < 8; e++) t[e] += fminf(q[e], q[e] * rinv);
+                    for (int e = 0; e < 4; e++) t[e] += inv_lrelu2(q[e], rinv);
                 } else {
 #pragma unroll
-                    for (int e = 0; e < 8; e++) t[e] += q[e];
+                    for (int e = 0; e < 4; e++) t[e] += q[e];
                 }
             }
             if (accum_mode & 1) {
                 if (acc_bf16) {
-                    t[0] += __uint_as_float(aab[p].x << 16); t[1] += __uint_as_float(aab[p].x & 0xffff0000u);
-                    t[2] += __uint_as_float(aab[p].y << 16); t[3] += __uint_as_float(aab[p].y & 0xffff0000u);
-                    t[4] += __uint_as_float(aab[p].z << 16); t[5] += __uint_as_float(aab[p].z & 0xffff0000u);
-                    t[6] += __uint_as_float(aab[p].w << 16); t[7] += __uint_as_float(aab[p].w & 0xffff0000u);
+                    t[0] += unpack_bf16x2(aab[p].x); t[1] += unpack_bf16x2(aab[p].y); t[2] += unpack_bf16x2(aab[p].z); t[3] += unpack_bf16x2(aab[p].w);
                 } else {
-                    t[0] += aa0[p].x; t[1] += aa0[p].y; t[2] += aa0[p].z; t[3] += aa0[p].w;
-                    t[4] += aa1[p].x; t[5] += aa1[p].y; t[6] += aa1[p].z; t[7] += aa1[p].w;
+                    t[0] += (f32x2){aa0[p].x, aa0[p].y}; t[1] += (f32x2){aa0[p].z, aa0[p].w};
+                    t[2] += (f32x2){aa1[p].x, aa1[p].y}; t[3] += (f32x2){aa1[p].z, aa1[p].w};
                 }
             }
             if ((accum_mode & 2) && ok[p]) {
                 const long ai = aoff + (long)r * a.lda + n;
                 if (acc_bf16) {
                     *(u32x4*)((unsigned short*)a.accum + ai) =
-                        (u32x4){pack_bf16x2(t[0], t[1]), pack_bf16x2(t[2], t[3]), pack_bf16x2(t[4], t[5]), pack_bf16x2(t[6], t[7])};
+                        (u32x4){pack_bf16x2(t[0].x, t[0].y), pack_bf16x2(t[1].x, t[1].y), pack_bf16x2(t[2].x, t[2].y), pack_bf16x2(t[3].x, t[3].y)};
                 } else {
                     float* ap = (float*)a.accum + ai;
-                    *(float4*)ap = make_float4(t[0], t[1], t[2], t[3]);
-                    *(float4*)(ap + 4) = make_float4(t[4], t[5], t[6], t[7]);
+                    *(float4*)ap = make_float4(t[0].x, t[0].y, t[1].x, t[1].y);
+                    *(float4*)(ap + 4) = make_float4(t[2].x, t[2].y, t[3].x, t[3].y);
                 }
             }
             if (has_out) {
-                if (oscale != 1.f) {
+                if (CT ? accum_mode != 0 : oscale != 1.f) {      // compile-time modes: only the xs-closing launch scales
 #pragma unroll
-                    for (int e = 0; e < 8; e++) t[e] *= oscale;
+                    for (int e = 0; e < 4; e++) t[e] *= oscale;
                 }
                 if (act == ACT_LRELU) {          // 0 <= slope <= 1: leaky-relu = max(x, slope*x)
 #pragma unroll
-                    for (int e = 0; e < 8; e++) t[e] = fmaxf(t[e], t[e] * slope);
+                    for (int e = 0; e < 4; e++) t[e] = lrelu2(t[e], slope);
                 } else if (act == ACT_RELU) {
 #pragma unroll
-                    for (int e = 0; e < 8; e++) t[e] = fmaxf(t[e], 0.f);
+                    for (int e = 0; e < 4; e++) t[e] = (f32x2){fmaxf(t[e].x, 0.f), fmaxf(t[e].y, 0.f)};
                 }
                 if (has_post && nok) {
                     const float4 s0 = *(const float4*)(a.post_scale + n), s1 = *(const float4*)(a.post_scale + n + 4);
                     const float4 h0 = *(const float4*)(a.post_shift + n), h1 = *(const float4*)(a.post_shift + n + 4);
-                    t[0] = t[0] * s0.x + h0.x; t[1] = t[1] * s0.y + h0.y; t[2] = t[2] * s0.z + h0.z; t[3] = t[3] * s0.w + h0.w;
-                    t[4] = t[4] * s1.x + h1.x; t[5] = t[5] * s1.y + h1.y; t[6] = t[6] * s1.z + h1.z; t[7] = t[7] * s1.w + h1.w;
+                    t[0] = t[0] * (f32x2){s0.x, s0.y} + (f32x2){h0.x, h0.y}; t[1] = t[1] * (f32x2){s0.z, s0.w} + (f32x2){h0.z, h0.w};
+                    t[2] = t[2] * (f32x2){s1.x, s1.y} + (f32x2){h1.x, h1.y}; t[3] = t[3] * (f32x2){s1.z, s1.w} + (f32x2){h1.z, h1.w};
                 }
                 if (out_bf16) {
-                    pk[j][p] = (u32x4){pack_bf16x2(t[0], t[1]), pack_bf16x2(t[2], t[3]), pack_bf16x2(t[4], t[5]), pack_bf16x2(t[6], t[7])};
+                    const u32x4 o = (u32x4){pack_bf16x2(t[0].x, t[0].y), pack_bf16x2(t[1].x, t[1].y), pack_bf16x2(t[2].x, t[2].y), pack_bf16x2(t[3].x, t[3].y)};
+                    if (BURST) pk[j][p] = o;
+                    else if (ok[p]) *(u32x4*)((unsigned short*)a.out + ooff + (long)r * a.ldo + n) = o;
                 } else if (ok[p]) {
                     float* op = (float*)a.out + ooff + (long)r * a.ldo + n;
-                    *(float4*)op = make_float4(t[0], t[1], t[2], t[3]);
-                    *(float4*)(op + 4) = make_float4(t[4], t[5], t[6], t[7]);
+                    *(float4*)op = make_float4(t[0].x, t[0].y, t[1].x, t[1].y);
+                    *(float4*)(op + 4) = make_float4(t[2].x, t[2].y, t[3].x, t[3].y);
                 }
             }
         }
-        __builtin_amdgcn_s_waitcnt(0xc07f);      // reads done before the next j overwrites the stage
     }
-    if (has_out && out_bf16) {
+    if (has_out && out_bf16 && BURST) {
         unsigned short* obase = (unsigned short*)a.out + ooff + n;
         const int ldo = a.ldo;
 #pragma unroll
@@ -449,12 +456,54 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs& a, f32x16 (&acc)[T
 #pragma unroll
             for (int p = 0; p < NP; p++) {
                 const int r = row_base + j * 32 + p * RPP + lane / LPR;
-                if (r < a.M && r < out_len && nok && (!(a.dbg & 32) || pk[j][p][0] == 0x12345678u)) {
-                    if (a.dbg & 16) __builtin_nontemporal_store(pk[j][p], (u32x4*)(obase + (long)r * ldo));
-                    else *(u32x4*)(obase + (long)r * ldo) = pk[j][p];
-                }
+                if (r < a.M && r < out_len && nok) *(u32x4*)(obase + (long)r * ldo) = pk[j][p];
             }
     }
+}
+
+// Epilogue for "bias + activation -> bf16" with nothing to read (EPI = ZVX_EPI(0, 0, 1): conv1 of a ResBlock pair,
+// polyphase ConvTranspose): the arithmetic runs in the MFMA layout, only the bf16 results cross the LDS stage (half
+// the bytes of the f32 transpose) and come back as whole channel rows for 16-byte stores.
+template <int TM, int TN>
+__device__ __forceinline__ void epilogue_direct(const GemmArgs& a, f32x16 (&acc)[TN][TM], int b, int row_base, int col_base,
+                                                int out_len, int lane, unsigned char* stage /* >= 32*(TN*64+16) bytes, this wave's */) {
+    constexpr int NW = TN * 32, EP = NW * 2 + 16, LPR = NW / 8, RPP = 64 / LPR, NP = 32 / RPP;
+    const float slope = a.act == ACT_LRELU ? a.slope : 1.f;
+    const int h4 = 4 * (lane >> 5), c8 = lane % LPR, n = col_base + c8 * 8;
+    const bool nok = n < a.N;
+    float4 bb[TN][4];
+#pragma unroll
+    for (int i = 0; i < TN; i++)
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            const int co = col_base + i * 32 + 8 * g + h4;
+            bb[i][g] = co < a.N ? *(const float4*)(a.bias + co) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    unsigned short* obase = (unsigned short*)a.out + (long)b * a.o_bs + n;
+    u32x4 o[TM][NP];
+#pragma unroll
+    for (int j = 0; j < TM; j++) {
+#pragma unroll
+        for (int i = 0; i < TN; i++)
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const f32x2 v01 = lrelu2((f32x2){acc[i][j][4 * g], acc[i][j][4 * g + 1]} + (f32x2){bb[i][g].x, bb[i][g].y}, slope);
+                const f32x2 v23 = lrelu2((f32x2){acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]} + (f32x2){bb[i][g].z, bb[i][g].w}, slope);
+                uint2 pk;
+                pk.x = pack_bf16x2(v01.x, v01.y);
+                pk.y = pack_bf16x2(v23.x, v23.y);
+                *(uint2*)(stage + (lane & 31) * EP + (i * 32 + 8 * g + h4) * 2) = pk;
+            }
+#pragma unroll
+        for (int p = 0; p < NP; p++) o[j][p] = *(const u32x4*)(stage + (p * RPP + lane / LPR) * EP + c8 * 16);
+    }
+#pragma unroll
+    for (int j = 0; j < TM; j++)
+#pragma unroll
+        for (int p = 0; p < NP; p++) {
+            const int r = row_base + j * 32 + p * RPP + lane / LPR;
+            if (r < a.M && r < out_len && nok) *(u32x4*)(obase + (long)r * a.ldo) = o[j][p];
+        }
 }
 
 // ================================================================================================
@@ -504,14 +553,14 @@ void launch_pack_weights(const void* w_bf16, int ntaps, int N, int K, void* out,
                        (unsigned short*)out, nkc, total);
 }
 
-template <int BM, int BN, int WM, int WN, bool FULLK, int MINW, int R>
+template <int BM, int BN, int WM, int WN, bool FULLK, int MINW, int R, int EPI = -1>
 __global__ __launch_bounds__(256, MINW) void convslab_kernel(const GemmArgs a) {
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int NIT = ((BM + 64) * 8 + 255) / 256;      // staging iterations (halo <= 64 rows)
     static_assert(WM * WN == 4, "4 waves");
     extern __shared__ __attribute__((aligned(16))) unsigned char slab[];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: SGPR arithmetic, scalar branches
     const int wr = wave % WM, wc = wave / WM;
     const int ntn = (a.N + BN - 1) / BN;
     int wg;
@@ -648,7 +697,10 @@ __global__ __launch_bounds__(256, MINW) void convslab_kernel(const GemmArgs a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // tail DMAs
     if (a.dbg & 1) { if (acc[0][0][0] == 123.456f) ((float*)a.out)[0] = 1.f; return; }
     __syncthreads();                             // every wave is done with the slab: its LDS becomes the transpose stage
-    epilogue_rows<TM, TN>(a, acc, b, m0 + wr * (BM / WM), n0 + wc * (BN / WN), out_len, lane, slab + wave * (32 * (TN * 32 * 4 + 16)));
+    if (EPI == ZVX_EPI(0, 0, 1))
+        epilogue_direct<TM, TN>(a, acc, b, m0 + wr * (BM / WM), n0 + wc * (BN / WN), out_len, lane, slab + wave * (32 * (TN * 64 + 16)));
+    else
+        epilogue_rows<TM, TN, 0, EPI>(a, acc, b, m0 + wr * (BM / WM), n0 + wc * (BN / WN), out_len, lane, slab + wave * (32 * (TN * 32 * 4 + 16)));
 }
 
 // ================================================================================================
@@ -898,11 +950,6 @@ __global__ __launch_bounds__(256, MINW) void resfuse_kernel(const GemmArgs a) {
 // AM = accum_mode (bit0: += xs, bit1: xs = result), HAS_OUT: a bf16 output is written (act = leaky-relu with a.slope, or none).
 // Compile-time, because a run-time mode switch inside the epilogue makes hipcc merge the paths' `s_waitcnt vmcnt`s
 // (accumulator loads) into every launch, where they then wait for the previous tile's stores.
-typedef float f32x2 __attribute__((ext_vector_type(2)));      // float pairs: v_pk_add_f32 / v_pk_mul_f32 (two elements per VALU slot)
-__device__ __forceinline__ f32x2 unpack_bf16x2(unsigned u) { return (f32x2){__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u)}; }
-__device__ __forceinline__ f32x2 lrelu2(f32x2 v, float slope) { const f32x2 m = v * slope; return (f32x2){fmaxf(v.x, m.x), fmaxf(v.y, m.y)}; }     // 0 <= slope <= 1
-__device__ __forceinline__ f32x2 inv_lrelu2(f32x2 y, float inv_slope) { const f32x2 m = y * inv_slope; return (f32x2){fminf(y.x, m.x), fminf(y.y, m.y)}; }  // inv_slope >= 1
-
 template <int C, int NT, int AM, bool HAS_OUT>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void resfuse_persist_kernel(const GemmArgs a, int ntm, int ntiles) {
     constexpr int KS = C / 16, CPR = C / 8, NTL = C / 32, RG = 4 / NTL, TM = 2;
@@ -930,10 +977,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     if (tid < C) { bias1_l[tid] = a.bias1[tid]; bias2_l[tid] = a.bias[tid]; }
 
     // this wave's weights: conv1 <- Wp2, conv2 <- Wp (packed stream [nt32][tap][4 k16 slots], 1 KiB fragments)
-    const uint4* const Wq = (const uint4*)(role ? a.Wp : a.Wp2) + ((long)wc * NT * 4) * 64 + lane;
+    constexpr int NKC = (C + 63) / 64;                      // 64-channel K-chunks of the packed stream [nt32][chunk][tap][4 k16 slots]
+    const uint4* const Wq = (const uint4*)(role ? a.Wp : a.Wp2) + ((long)wc * NKC * NT * 4) * 64 + lane;
+    auto wfrag = [](int t, int kk) { return (((kk >> 2) * NT + t) * 4 + (kk & 3)) * 64; };
     uint4 w[NRES];
 #pragma unroll
-    for (int i = 0; i < NRES; i++) w[i] = Wq[((i / KS) * 4 + (i % KS)) * 64];
+    for (int i = 0; i < NRES; i++) w[i] = Wq[wfrag(i / KS, i % KS)];
 
     // this wave's bias (conv1: b1, conv2: b2) for its 16 channels per lane: registers when they are to spare, else LDS
     constexpr bool BIAS_REG = NW <= 22;
@@ -970,7 +1019,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     // LDS (padded rows: the 9th / 5th 16-byte slot of a row is the pad and fetches nothing).  The buffer descriptor is
     // based at row g0, so the lane offsets are tile-independent (computed once); num_records ends at the utterance's last
     // row (rows past it -> zeros), rows before its first row are sent out of range by hand.
-    constexpr int MAXP = 8;
+    constexpr int MAXP = C == 128 ? 10 : 8;
     constexpr bool VREL_REG = NW <= 22;
     const int npieces = SB >> 10;
     auto vrel_of = [&](int n) {
@@ -1046,7 +1095,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     const unsigned char* rowp = rowp0 + t * dil * P;
 #pragma unroll
                     for (int kk = 0; kk < KS; kk++) {
-                        const uint4 wf = (t * KS + kk < NRES) ? w[t * KS + kk < NRES ? t * KS + kk : 0] : Wq[(t * 4 + kk) * 64];
+                        const uint4 wf = (t * KS + kk < NRES) ? w[t * KS + kk < NRES ? t * KS + kk : 0] : Wq[wfrag(t, kk)];
 #pragma unroll
                         for (int j = 0; j < TM; j++) {
                             const uint4 xf = *(const uint4*)(rowp + j * 32 * P + kk * 32);
@@ -1068,7 +1117,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             for (int t = 0; t < NT; t++)
 #pragma unroll
                 for (int kk = 0; kk < KS; kk++) {
-                    const uint4 wf = (t * KS + kk < NRES) ? w[t * KS + kk < NRES ? t * KS + kk : 0] : Wq[(t * 4 + kk) * 64];
+                    const uint4 wf = (t * KS + kk < NRES) ? w[t * KS + kk < NRES ? t * KS + kk : 0] : Wq[wfrag(t, kk)];
 #pragma unroll
                     for (int j = 0; j < TM; j++) {
                         const uint4 xf = *(const uint4*)(rowp + (t + j * 32) * P + kk * 32);
@@ -1181,10 +1230,10 @@ static bool launch_resfuse_persist_c(const GemmArgs& a, hipStream_t stream) {
 #define ZVX_RFP_MODE(NT_) \
     if (a.out) { if (am == 0) { ZVX_RFP(NT_, 0, true); } if (am == 1) { ZVX_RFP(NT_, 1, true); } if (am == 2) { ZVX_RFP(NT_, 2, true); } ZVX_RFP(NT_, 3, true); } \
     else { if (am == 2) { ZVX_RFP(NT_, 2, false); } ZVX_RFP(NT_, 3, false); }
-    switch (a.ntaps) {
-        case 3: ZVX_RFP_MODE(3)
-        case 7: ZVX_RFP_MODE(7)
-        case 11: ZVX_RFP_MODE(11)
+    if (a.ntaps == 3) { ZVX_RFP_MODE(3) }
+    if constexpr (C != 128) {                              // C = 128: only k = 3 keeps its 24 fragments per wave resident
+        if (a.ntaps == 7) { ZVX_RFP_MODE(7) }
+        if (a.ntaps == 11) { ZVX_RFP_MODE(11) }
     }
 #undef ZVX_RFP_MODE
 #undef ZVX_RFP
@@ -1219,6 +1268,7 @@ int launch_resfuse(GemmArgs a, hipStream_t stream) {
         if (a.N == 32 && launch_resfuse_persist_c<32>(a, stream)) return 16;
         // C = 64, k = 11: 44 fragments per wave do not fit beside the epilogue's registers (spills) -> per-tile kernel
         if (a.N == 64 && a.ntaps != 11 && launch_resfuse_persist_c<64>(a, stream)) return 17;
+        if (a.N == 128 && a.ntaps == 3 && launch_resfuse_persist_c<128>(a, stream)) return 13;      // 24 fragments per wave: resident
     }
     if (a.N == 32 && launch_resfuse_c<32, 256, 4, 1, 2>(a, stream)) return 16;
     if (a.N == 64 && launch_resfuse_c<64, 128, 2, 2, 2>(a, stream)) return 17;
@@ -1232,7 +1282,7 @@ static const Variant kVariants[] = {
     {"gemm_f32_256x64", DT_F32, 256, 64},     {"gemm_f32_256x32", DT_F32, 256, 32},
     {"convslab_bf16_128x256", DT_BF16, 128, 256}, {"convslab_bf16_256x128", DT_BF16, 256, 128},
     {"convslab_bf16_256x64", DT_BF16, 256, 64},   {"convslab_bf16_256x32", DT_BF16, 256, 32},
-    {"(unused)", DT_BF16, 0, 0}, {"(unused)", DT_BF16, 0, 0}, {"(unused)", DT_BF16, 0, 0}, {"(unused)", DT_BF16, 0, 0},
+    {"(unused)", DT_BF16, 0, 0}, {"(unused)", DT_BF16, 0, 0}, {"(unused)", DT_BF16, 0, 0}, {"resfuse_bf16_c128", DT_BF16, 64, 128},
     {"convreg_bf16_c32", DT_BF16, 512, 32},       {"convreg_bf16_c64", DT_BF16, 256, 64},
     {"resfuse_bf16_c32", DT_BF16, 256, 32},       {"resfuse_bf16_c64", DT_BF16, 128, 64},
     {"gemm_bf16_64x64", DT_BF16, 64, 64},         {"gemm_f32_64x64", DT_F32, 64, 64},
@@ -1240,10 +1290,26 @@ static const Variant kVariants[] = {
 const char* gemm_variant_name(int id) { return kVariants[id].name; }
 int gemm_num_variants() { return (int)(sizeof(kVariants) / sizeof(kVariants[0])); }
 
-template <int BM, int BN, int WM, int WN, int MINW, int R>
+template <int BM, int BN, int WM, int WN, int MINW, int R, int EPI = -1>
 static void launch_slab_variant(const GemmArgs& a, dim3 grid, size_t lds, hipStream_t stream) {
-    if (a.K % SLAB_KC == 0) hipLaunchKernelGGL((convslab_kernel<BM, BN, WM, WN, true, MINW, R>), grid, dim3(256), lds, stream, a);
-    else hipLaunchKernelGGL((convslab_kernel<BM, BN, WM, WN, false, MINW, R>), grid, dim3(256), lds, stream, a);
+    if (a.K % SLAB_KC == 0) hipLaunchKernelGGL((convslab_kernel<BM, BN, WM, WN, true, MINW, R, EPI>), grid, dim3(256), lds, stream, a);
+    else hipLaunchKernelGGL((convslab_kernel<BM, BN, WM, WN, false, MINW, R, EPI>), grid, dim3(256), lds, stream, a);
+}
+
+// compile-time epilogue mode of a launch (see ZVX_EPI), or -1 when it needs the run-time epilogue
+static int epi_mode_of(const GemmArgs& a) {
+    if (a.alpha != 1.f || a.bias_mode != 1 || !a.bias || a.post_scale || (a.out && a.out_dtype != DT_BF16)) return -1;
+    if (a.act != ACT_NONE && a.act != ACT_LRELU) return -1;
+    if (a.res_mode && (a.res_mode != 2 || a.res_dtype != DT_BF16)) return -1;
+    const int am = a.accum ? a.accum_mode : 0;
+    if (am && a.accum_dtype != DT_BF16) return -1;
+    if (!am && a.out_scale != 1.f) return -1;
+    if (!a.out && !(am & 2)) return -1;
+    const int e = ZVX_EPI(a.res_mode ? 1 : 0, am, a.out ? 1 : 0);
+    switch (e) {
+        case ZVX_EPI(0, 0, 1): case ZVX_EPI(1, 0, 1): case ZVX_EPI(1, 2, 0): case ZVX_EPI(1, 3, 0): case ZVX_EPI(1, 1, 1): return e;
+    }
+    return -1;
 }
 
 static int launch_convslab(GemmArgs a, hipStream_t stream) {
@@ -1280,7 +1346,14 @@ static int launch_convslab(GemmArgs a, hipStream_t stream) {
         case 0: launch_slab_variant<128, 256, 1, 4, 2, 4>(a, grid, lds, stream); break;
         case 1: if (t128r == 4) launch_slab_variant<128, 128, 2, 2, 4, 4>(a, grid, lds, stream);
                 else if (t128r == 8) launch_slab_variant<128, 128, 2, 2, 3, 8>(a, grid, lds, stream);
-                else launch_slab_variant<256, 128, 2, 2, 2, 8>(a, grid, lds, stream);
+                else switch (epi_mode_of(a)) {
+                    case ZVX_EPI(0, 0, 1): launch_slab_variant<256, 128, 2, 2, 2, 8, ZVX_EPI(0, 0, 1)>(a, grid, lds, stream); break;
+                    case ZVX_EPI(1, 0, 1): launch_slab_variant<256, 128, 2, 2, 2, 8, ZVX_EPI(1, 0, 1)>(a, grid, lds, stream); break;
+                    case ZVX_EPI(1, 2, 0): launch_slab_variant<256, 128, 2, 2, 2, 8, ZVX_EPI(1, 2, 0)>(a, grid, lds, stream); break;
+                    case ZVX_EPI(1, 3, 0): launch_slab_variant<256, 128, 2, 2, 2, 8, ZVX_EPI(1, 3, 0)>(a, grid, lds, stream); break;
+                    case ZVX_EPI(1, 1, 1): launch_slab_variant<256, 128, 2, 2, 2, 8, ZVX_EPI(1, 1, 1)>(a, grid, lds, stream); break;
+                    default: launch_slab_variant<256, 128, 2, 2, 2, 8>(a, grid, lds, stream);
+                }
                 break;
         case 2: launch_slab_variant<256, 64, 2, 2, 2, 8>(a, grid, lds, stream); break;
         case 3: launch_slab_variant<256, 32, 4, 1, 2, 8>(a, grid, lds, stream); break;

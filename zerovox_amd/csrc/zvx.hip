@@ -718,7 +718,7 @@ void run_vocoder(zvx_ctx* c, const float* mel, int ldm, int Lmel_max, const int*
                     const Tensor& w1 = c->t(rb + ".c1_" + std::to_string(t) + "_w");
                     const Tensor& w2 = c->t(rb + ".c2_" + std::to_string(t) + "_w");
                     static const char* nofuse = getenv("ZVX_NO_RESFUSE");
-                    fuse = !nofuse && dt == DT_BF16 && (Cout == 32 || Cout == 64) && (k == 3 || k == 7 || k == 11) && dil[t] * (k - 1) / 2 <= 32 &&
+                    fuse = !nofuse && dt == DT_BF16 && (Cout == 32 || Cout == 64 || (Cout == 128 && k == 3)) && (k == 3 || k == 7 || k == 11) && dil[t] * (k - 1) / 2 <= 32 &&
                            c->packed.count(w1.dev) && c->packed.count(w2.dev);
                     if (fuse) {
                         // one launch: xt = lrelu(c1(x_act)+b1) stays in LDS; x' = c2(xt) + b2 + x      hifigan.py:51-55
