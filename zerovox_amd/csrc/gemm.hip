@@ -950,19 +950,19 @@ __global__ __launch_bounds__(256, MINW) void resfuse_kernel(const GemmArgs a) {
 // AM = accum_mode (bit0: += xs, bit1: xs = result), HAS_OUT: a bf16 output is written (act = leaky-relu with a.slope, or none).
 // Compile-time, because a run-time mode switch inside the epilogue makes hipcc merge the paths' `s_waitcnt vmcnt`s
 // (accumulator loads) into every launch, where they then wait for the previous tile's stores.
-template <int C, int NT, int AM, bool HAS_OUT>
+template <int C, int NT, int AM, bool HAS_OUT, int TM>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void resfuse_persist_kernel(const GemmArgs a, int ntm, int ntiles) {
-    constexpr int KS = C / 16, CPR = C / 8, NTL = C / 32, RG = 4 / NTL, TM = 2;
-    constexpr int BM1 = 64 * RG;                          // T1 rows per tile (conv2's input incl. its halo)
+    constexpr int KS = C / 16, CPR = C / 8, NTL = C / 32, RG = 4 / NTL;
+    constexpr int BM1 = 32 * TM * RG;                          // T1 rows per tile (conv2's input incl. its halo)
     constexpr int H2 = (NT - 1) / 2, BMO = BM1 - 2 * H2;  // output rows per tile
     constexpr int P = C * 2 + 16, CPP = CPR + 1;          // padded row pitch (conflict-free b128 reads), 16-byte slots per row
-    constexpr int NW = NT * KS, NRES = NW > 36 ? 28 : NW; // fragments per wave / of those resident in registers (the rest: re-read from L2 per tile)
+    constexpr int NW = NT * KS, NRES = NW;                // fragments per wave / of those resident in registers (the rest: re-read from L2 per tile)
     typedef __attribute__((ext_vector_type(4))) int i32x4;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform -> SGPRs, scalar branches
     const int role = wave >> 2, w4 = wave & 3;
-    const int wc = w4 % NTL, wr = w4 / NTL, wrow = wr * 64;
+    const int wc = w4 % NTL, wr = w4 / NTL, wrow = wr * 32 * TM;
     const int H1 = a.halo_l, SR = BM1 + 2 * H1;
     const int dil = a.dv1[1] - a.dv1[0];
     const float slope1 = a.slope1;
@@ -1206,9 +1206,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     }
 }
 
-template <int C>
+template <int C, int TM = 2>
 static bool launch_resfuse_persist_c(const GemmArgs& a, hipStream_t stream) {
-    constexpr int BM1 = 64 * (4 / (C / 32));
+    // 32*TM rows per wave; C = 64, k = 11 (44 fragments = 176 registers per wave) only fits with one row block per wave
+    constexpr int BM1 = 32 * TM * (4 / (C / 32));
     const int h2 = (a.ntaps - 1) / 2, bmo = BM1 - 2 * h2;
     const int ntm = (a.M + bmo - 1) / bmo, ntiles = ntm * a.nbatch;
     static int ncu = 0;
@@ -1226,14 +1227,18 @@ static bool launch_resfuse_persist_c(const GemmArgs& a, hipStream_t stream) {
     if (!a.accum_mode && a.out_scale != 1.f) return false;
     const int am = a.accum ? a.accum_mode : 0;
     if (!a.out && !(am & 2)) return false;
-#define ZVX_RFP(NT_, AM_, HO_) hipLaunchKernelGGL((resfuse_persist_kernel<C, NT_, AM_, HO_>), grid, dim3(512), lds, stream, a, ntm, ntiles); return true
+#define ZVX_RFP(NT_, AM_, HO_) hipLaunchKernelGGL((resfuse_persist_kernel<C, NT_, AM_, HO_, TM>), grid, dim3(512), lds, stream, a, ntm, ntiles); return true
 #define ZVX_RFP_MODE(NT_) \
     if (a.out) { if (am == 0) { ZVX_RFP(NT_, 0, true); } if (am == 1) { ZVX_RFP(NT_, 1, true); } if (am == 2) { ZVX_RFP(NT_, 2, true); } ZVX_RFP(NT_, 3, true); } \
     else { if (am == 2) { ZVX_RFP(NT_, 2, false); } ZVX_RFP(NT_, 3, false); }
-    if (a.ntaps == 3) { ZVX_RFP_MODE(3) }
-    if constexpr (C != 128) {                              // C = 128: only k = 3 keeps its 24 fragments per wave resident
-        if (a.ntaps == 7) { ZVX_RFP_MODE(7) }
+    if constexpr (TM == 1) {
         if (a.ntaps == 11) { ZVX_RFP_MODE(11) }
+    } else {
+        if (a.ntaps == 3) { ZVX_RFP_MODE(3) }
+        if constexpr (C != 128) {                          // C = 128: only k = 3 keeps its 24 fragments per wave resident
+            if (a.ntaps == 7) { ZVX_RFP_MODE(7) }
+            if constexpr (C == 32) { if (a.ntaps == 11) { ZVX_RFP_MODE(11) } }
+        }
     }
 #undef ZVX_RFP_MODE
 #undef ZVX_RFP
@@ -1266,8 +1271,11 @@ int launch_resfuse(GemmArgs a, hipStream_t stream) {
     static const char* v1 = getenv("ZVX_RESFUSE_V1");
     if (!v1) {
         if (a.N == 32 && launch_resfuse_persist_c<32>(a, stream)) return 16;
-        // C = 64, k = 11: 44 fragments per wave do not fit beside the epilogue's registers (spills) -> per-tile kernel
         if (a.N == 64 && a.ntaps != 11 && launch_resfuse_persist_c<64>(a, stream)) return 17;
+        // C = 64, k = 11 (44 fragments = 176 registers per wave): even with one row block per wave (TM = 1) the persistent
+        // form spills and measures 1.03 ms against 0.97 ms for the per-tile kernel below -> opt-in only
+        static const char* p11 = getenv("ZVX_C64K11_PERSIST");
+        if (p11 && a.N == 64 && a.ntaps == 11 && launch_resfuse_persist_c<64, 1>(a, stream)) return 17;
         if (a.N == 128 && a.ntaps == 3 && launch_resfuse_persist_c<128>(a, stream)) return 13;      // 24 fragments per wave: resident
     }
     if (a.N == 32 && launch_resfuse_c<32, 256, 4, 1, 2>(a, stream)) return 16;
