@@ -17,10 +17,6 @@ ctx.set_int("profile", 2); ctx.reset_stats()
 n = 5
 for _ in range(n): ctx.vocode_mel(mel, Pn)
 st = ctx.stage_times(); ks = ctx.kernel_stats()
-print(f"ZVX_DBG={os.environ.get('ZVX_DBG','0')} vocoder stage {st['vocoder']:.2f} ms  ({B*P*256/st['vocoder']/1e3:.1f} M samples/s)")
+print(f"vocoder stage {st['vocoder']:.2f} ms  ({B*P*256/st['vocoder']/1e3:.1f} M samples/s)")
 for k in sorted(ks, key=lambda k: -k['ms']):
     print(f"   {k['name']:24s} {k['launches']//n:4d} launches/step {k['ms']/n:8.3f} ms/step {k['flops']/k['ms']/1e9:8.1f} TF/s")
-if os.environ.get("ZVX_TS"):
-    ts = ctx.fetch("dbg_ts", (8, 16))
-    print("s_memtime deltas (100 MHz ticks -> us = ticks/100) of sampled workgroups: start, fill0, mma0, fill1, mma1, bar, epi, drained")
-    for r in ts[:8]: print("   ", [round(float(v) / 100.0, 2) for v in r])

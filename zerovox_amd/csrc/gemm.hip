@@ -610,7 +610,7 @@ __global__ __launch_bounds__(256, MINW) void convslab_kernel(const GemmArgs a) {
     const int dvreg = a.dv[lane & (ZVX_MAX_TAPS - 1)];              // lane t holds tap t's row offset (read back with v_readlane)
     const bool loader = wave * CNT < F;
     auto dma = [&](int gs) {
-        if ((a.dbg & 8) || !loader) return;
+        if (!loader) return;
         const int slot = gs & (R - 1);
         const long off = (long)(gs < gtotal ? gs : gtotal - 1) * 64;      // past the end: harmless re-loads keep vmcnt counting uniform
 #pragma unroll
@@ -632,7 +632,7 @@ __global__ __launch_bounds__(256, MINW) void convslab_kernel(const GemmArgs a) {
                 const int row = c >> 3, q = c & 7;
                 const int g = m0 - HL + row, k = kc * SLAB_KC + q * 8;
                 sv[it] = make_uint4(0, 0, 0, 0);
-                if (!(a.dbg & 4) && c < SR * 8 && g >= 0 && g < in_len && k < a.K) sv[it] = *(const uint4*)(Xp + (long)g * a.ldx + k);
+                if (c < SR * 8 && g >= 0 && g < in_len && k < a.K) sv[it] = *(const uint4*)(Xp + (long)g * a.ldx + k);
             }
             if (kc) __syncthreads();              // (after the refill loads are in flight) every wave is done with chunk kc-1's slab
 #pragma unroll
@@ -671,7 +671,6 @@ __global__ __launch_bounds__(256, MINW) void convslab_kernel(const GemmArgs a) {
             const int d = __builtin_amdgcn_readlane(dvreg, tap < ntaps ? tap : ntaps - 1);
             return (unsigned)((xrow0 + d) * SLAB_PITCH + koff);
         };
-        if (a.dbg & 2) continue;
         unsigned rowoff = rowoff_of(0);
         rd(xA, wA, gs0, rowoff, 0);
         for (int tap = 0; tap < ntaps; tap++) {
@@ -695,7 +694,6 @@ __global__ __launch_bounds__(256, MINW) void convslab_kernel(const GemmArgs a) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the speculative reads of the chunk's last step
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // tail DMAs
-    if (a.dbg & 1) { if (acc[0][0][0] == 123.456f) ((float*)a.out)[0] = 1.f; return; }
     __syncthreads();                             // every wave is done with the slab: its LDS becomes the transpose stage
     if (EPI == ZVX_EPI(0, 0, 1))
         epilogue_direct<TM, TN>(a, acc, b, m0 + wr * (BM / WM), n0 + wc * (BN / WN), out_len, lane, slab + wave * (32 * (TN * 64 + 16)));
@@ -972,9 +970,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     unsigned char* const stage = t1base + 2 * TB + w4 * (32 * 80);          // conv2 waves: 32 rows x 32 ch bf16, pitch 80
     float* const bias1_l = (float*)(t1base + 2 * TB + 4 * (32 * 80));
     float* const bias2_l = bias1_l + C;
+    int* const lens_l = (int*)(bias2_l + C);                // [2][128]: out_len, in_len per utterance (nbatch <= 128)
     const unsigned lds_addr0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
     const int G = gridDim.x;
     if (tid < C) { bias1_l[tid] = a.bias1[tid]; bias2_l[tid] = a.bias[tid]; }
+    if (a.nbatch <= 128 && tid < a.nbatch) { lens_l[tid] = a.out_len ? a.out_len[tid] : a.M; lens_l[128 + tid] = a.in_len ? a.in_len[tid] : a.in_len_static; }
 
     // this wave's weights: conv1 <- Wp2, conv2 <- Wp (packed stream [nt32][tap][4 k16 slots], 1 KiB fragments)
     constexpr int NKC = (C + 63) / 64;                      // 64-channel K-chunks of the packed stream [nt32][chunk][tap][4 k16 slots]
@@ -1001,19 +1001,32 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         for (int q = 0; q < 4; q++) asm volatile("" :: "v"(bq[q].x));
     }
     __syncthreads();                                        // bias1_l / bias2_l visible
-    struct Tile { int t, b, m0, in_len, out_len; };
-    // per-utterance lengths through the scalar cache: a vector load here would make hipcc wait vmcnt(0) inside the tile
-    // loop, i.e. for every store (conv2 waves) or slab DMA (conv1 waves) still in flight
+    struct Tile { int t, b, mt, m0, in_len, out_len; };
+    // Tile walk: tile t <-> (utterance b, row tile mt), advanced by G tiles without divisions.  Per-utterance lengths come
+    // from an LDS table (<= 128 utterances) or through the scalar cache: a vector load here would make hipcc wait
+    // vmcnt(0) inside the tile loop, i.e. for every store (conv2 waves) or slab DMA (conv1 waves) still in flight.
+    const bool use_tab = a.nbatch <= 128;
     auto sload = [&](const int* p) { int v; asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory"); return v; };
-    auto load_tile = [&](int t) {
-        Tile q; q.t = -1; q.b = q.m0 = q.in_len = q.out_len = 0;
-        for (; t < ntiles; t += G) {
-            const int b = t / ntm, m0 = (t % ntm) * BMO, ol = a.out_len ? sload(a.out_len + b) : a.M;
-            if (m0 < ol) { q.t = t; q.b = b; q.m0 = m0; q.out_len = ol; q.in_len = a.in_len ? sload(a.in_len + b) : a.in_len_static; break; }
+    auto len_of = [&](const int* g, int which, int b, int dflt) {
+        if (!g) return dflt;
+        return use_tab ? __builtin_amdgcn_readfirstlane(lens_l[which * 128 + b]) : sload(g + b);
+    };
+    const int gq = G / ntm, gr = G % ntm;
+    auto load_tile = [&](int t, int b, int mt) {             // first valid tile at or after (t, b, mt), stepping by G
+        Tile q; q.t = -1; q.b = q.mt = q.m0 = q.in_len = q.out_len = 0;
+        for (; t < ntiles; t += G, b += gq, mt += gr) {
+            if (mt >= ntm) { mt -= ntm; b++; }
+            const int m0 = mt * BMO, ol = len_of(a.out_len, 0, b, a.M);
+            if (m0 < ol) { q.t = t; q.b = b; q.mt = mt; q.m0 = m0; q.out_len = ol; q.in_len = len_of(a.in_len, 1, b, a.in_len_static); break; }
         }
-        q.t = __builtin_amdgcn_readfirstlane(q.t); q.b = __builtin_amdgcn_readfirstlane(q.b); q.m0 = __builtin_amdgcn_readfirstlane(q.m0);
+        q.t = __builtin_amdgcn_readfirstlane(q.t); q.b = __builtin_amdgcn_readfirstlane(q.b); q.mt = __builtin_amdgcn_readfirstlane(q.mt);
+        q.m0 = __builtin_amdgcn_readfirstlane(q.m0);
         q.in_len = __builtin_amdgcn_readfirstlane(q.in_len); q.out_len = __builtin_amdgcn_readfirstlane(q.out_len);
         return q;
+    };
+    auto next_tile = [&](const Tile& q) {
+        int b = q.b + gq, mt = q.mt + gr;
+        return load_tile(q.t + G, b, mt);
     };
     // LDS-DMA of a tile's slab (global rows g0 = m0-H2-H1 ..) into buffer `buf`: piece p = 64 lanes x 16 B, lane-linear in
     // LDS (padded rows: the 9th / 5th 16-byte slot of a row is the pad and fetches nothing).  The buffer descriptor is
@@ -1050,16 +1063,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     };
 
     Tile qA, qB, qC, qD;                                    // q_i-1 (conv2), q_i (T1 epilogue), q_i+1 (conv1 MFMA), q_i+2 (DMA)
-    qA = load_tile(ntiles); qB = qA;
-    qC = load_tile(blockIdx.x);
-    qD = qC.t >= 0 ? load_tile(qC.t + G) : qA;
+    qA = load_tile(ntiles, 0, 0); qB = qA;
+    qC = load_tile(blockIdx.x, blockIdx.x / ntm, blockIdx.x % ntm);
+    qD = qC.t >= 0 ? next_tile(qC) : qA;
     if (role == 0 && qC.t >= 0) dma_slab(qC, 0);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
     const int koff = (lane >> 5) * 16;
     f32x16 acc[1][TM];
     for (int ph = 0; qA.t >= 0 || qB.t >= 0 || qC.t >= 0; ph++) {
         // slab buffer of q_n is n & 3 (q_i+1 <-> ph); T1 buffer of q_i is (ph-1) & 1
-        const Tile qE = qD.t >= 0 ? load_tile(qD.t + G) : qD;      // looked up early: its scalar loads hide behind the iteration
+        const Tile qE = qD.t >= 0 ? next_tile(qD) : qD;      // looked up early: its scalar loads hide behind the iteration
         if (role == 0) {
             if (qD.t >= 0) dma_slab(qD, (ph + 1) & 3);
             if (qB.t >= 0) {
@@ -1219,7 +1232,7 @@ static bool launch_resfuse_persist_c(const GemmArgs& a, hipStream_t stream) {
         if (a.dv[t] != t - h2 || a.dv1[t] != (t - h2) * (a.dv1[1] - a.dv1[0])) return false;
     const size_t sb = ((size_t)(BM1 + 2 * a.halo_l) * (C * 2 + 16) + 1023) & ~(size_t)1023;
     const size_t tb = ((size_t)(BM1 + 2 * h2) * (C * 2 + 16) + 15) & ~(size_t)15;
-    const size_t lds = 4 * sb + 2 * tb + 4 * 32 * 80 + 2 * C * 4;
+    const size_t lds = 4 * sb + 2 * tb + 4 * 32 * 80 + 2 * C * 4 + 2 * 128 * 4;
     if (lds > 160 * 1024) return false;
     // the in-kernel epilogue covers exactly what the vocoder asks for
     if (a.alpha != 1.f || a.bias_mode != 1 || a.post_scale || (a.out && a.out_dtype != DT_BF16) || a.res_mode != 2 || a.ldo % 8 || (a.accum && (a.lda % 8 || a.accum_dtype != DT_BF16))) return false;
@@ -1338,11 +1351,8 @@ static int launch_convslab(GemmArgs a, hipStream_t stream) {
         if (best_cost < 0 || cost < best_cost - 1e-9) { best_cost = cost; best = i; }
     }
     static const int bms[4] = {128, 256, 256, 256};
-    static const char* t128 = getenv("ZVX_T128");
-    static const int t128r = t128 ? atoi(t128) : 0;
-    int ring_slots = best == 0 ? 4 : 8;
-    int bn = bns[best], bm = bms[best];
-    if (t128r && best == 1) { bm = 128; ring_slots = t128r; }
+    const int ring_slots = best == 0 ? 4 : 8;
+    const int bn = bns[best], bm = bms[best];
     const int ntn = (a.N + bn - 1) / bn;
     const int ntm = (a.M + bm - 1) / bm;
     dim3 grid(ntn * ntm, a.nbatch);
@@ -1352,9 +1362,7 @@ static int launch_convslab(GemmArgs a, hipStream_t stream) {
     if (lds < stage) lds = stage;
     switch (best) {
         case 0: launch_slab_variant<128, 256, 1, 4, 2, 4>(a, grid, lds, stream); break;
-        case 1: if (t128r == 4) launch_slab_variant<128, 128, 2, 2, 4, 4>(a, grid, lds, stream);
-                else if (t128r == 8) launch_slab_variant<128, 128, 2, 2, 3, 8>(a, grid, lds, stream);
-                else switch (epi_mode_of(a)) {
+        case 1: switch (epi_mode_of(a)) {
                     case ZVX_EPI(0, 0, 1): launch_slab_variant<256, 128, 2, 2, 2, 8, ZVX_EPI(0, 0, 1)>(a, grid, lds, stream); break;
                     case ZVX_EPI(1, 0, 1): launch_slab_variant<256, 128, 2, 2, 2, 8, ZVX_EPI(1, 0, 1)>(a, grid, lds, stream); break;
                     case ZVX_EPI(1, 2, 0): launch_slab_variant<256, 128, 2, 2, 2, 8, ZVX_EPI(1, 2, 0)>(a, grid, lds, stream); break;

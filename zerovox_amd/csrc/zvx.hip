@@ -106,11 +106,10 @@ struct zvx_ctx {
         DevBuf& d = bufs[name];
         if (bytes > d.cap) {
             if (d.base) { HIPCHK(hipStreamSynchronize(stream)); HIPCHK(hipFree(d.base)); d.base = nullptr; d.p = nullptr; }
-            const size_t skew = 0;
             size_t cap = bytes + bytes / 8 + 256;
-            HIPCHK(hipMalloc(&d.base, cap + skew));
-            HIPCHK(hipMemsetAsync(d.base, 0, cap + skew, stream));
-            d.p = (char*)d.base + skew;
+            HIPCHK(hipMalloc(&d.base, cap));
+            HIPCHK(hipMemsetAsync(d.base, 0, cap, stream));
+            d.p = d.base;
             d.cap = cap;
         }
         return d.p;
@@ -135,8 +134,6 @@ struct zvx_ctx {
 
     void gemm(GemmArgs& a) {
         if (a.flops <= 0) a.flops = 2.0 * (double)a.M * a.nbatch * a.nheads * (double)a.N * (double)a.K * a.ntaps;
-        { static const char* e = getenv("ZVX_DBG"); a.dbg = e ? atoi(e) : 0; }
-        { static const char* e = getenv("ZVX_TS"); if (e && a.M * (long)a.nbatch > 1000000 && a.N == (getenv("ZVX_TS_N") ? atoi(getenv("ZVX_TS_N")) : 128) && a.K == a.N && a.ntaps == atoi(e) && !a.res_mode == (getenv("ZVX_TS_C1") != nullptr)) a.ts = (unsigned long long*)buf("dbg.ts", 8 * 16 * 8); }
         if (!a.Wp && a.dtype == DT_BF16) { auto it = packed.find(a.W); if (it != packed.end()) a.Wp = it->second; }
         GemmEvent ev{};
         const bool prof = profile >= 2;
@@ -671,7 +668,6 @@ void run_vocoder(zvx_ctx* c, const float* mel, int ldm, int Lmel_max, const int*
     void* T1 = c->buf("voc.T1", maxel * es);
     void* PP[2] = {c->buf("voc.PP0", maxel * es), c->buf("voc.PP1", maxel * es)};
     void* XS = c->buf("voc.XS", maxel * es);     // running sum over the resblocks of a stage, in the activation dtype
-    { static const char* sw = getenv("ZVX_SWAP_BUFS"); if (sw) { int m = atoi(sw); if (m & 1) std::swap(T1, PP[0]); if (m & 2) std::swap(T1, A); if (m & 4) std::swap(X0, PP[1]); } }
 
     launch_mel_pad(mel, DT_F32, ldm, Lmel_max, mel_len_d, vin, dt, nm, Pmax, P_d, B, nm, c->stream);     // model.py:331-335
     {   // conv_pre, stored as leaky_relu(x, 0.1) (its only consumer, hifigan.py:115-117)
@@ -1116,7 +1112,6 @@ zvx_status zvx_fetch(zvx_ctx* c, const char* what, float* out, size_t out_floats
         else if (w == "pitch_idx") copy_i("va.pitch_idx", nid);
         else if (w == "energy_idx") copy_i("va.energy_idx", nid);
         else if (w == "duration") copy_i("va.dur", nid);
-        else if (w == "dbg_ts") { std::vector<unsigned long long> t(128); HIPCHK(hipMemcpy(t.data(), c->buf("dbg.ts", 1024), 1024, hipMemcpyDeviceToHost)); for (int i = 0; i < 128 && (size_t)i < out_floats; i++) out[i] = (float)(double)(t[i] - t[0]); }
         else fail(ZVX_E_INVALID, "zvx_fetch: unknown tensor '%s'", what);
     });
 }

@@ -36,8 +36,6 @@ struct GemmArgs {
     int halo_l, halo_r;        // filled by the launcher
     // fused ResBlock1 pair (resfuse kernel): out = epilogue(conv2(lrelu(conv1(X) + bias1)) + bias + inverse_lrelu(X))
     const void* Wp2; const float* bias1; int dv1[ZVX_MAX_TAPS]; int fused; float slope1;   // conv1: Wp2/bias1/dv1 (dilated); conv2: Wp/bias/dv
-    unsigned long long* ts;    // development: per-phase s_memtime stamps of sampled workgroups (NULL = off)
-    int dbg;                   // ablation switches (development only): 1 skip epilogue, 2 skip main loop, 4 skip slab loads
     int dtype;                 // DType of X and W (same)
     int M, N, K;               // M = max rows per z, N cols, K per tap (multiple of 8 elements bf16 / 4 f32)
     int nbatch, nheads;
