@@ -174,6 +174,40 @@ def test_vocoder_alone_against_golden(voc, prec):
 
 
 @pytest.mark.parametrize("prec", ["f32", "bf16"])
+def test_vocoder_v1_ragged_batch_equals_independent_oracle_calls(prec):
+    """HiFi-GAN V1 (every kernel of the benchmarked vocoder: fused ResBlock pairs for C = 128/64/32 with k = 3/7/11, all three
+    running-sum modes) on a ragged batch: each utterance must equal its own batch-1 oracle call."""
+    h, hsd = voc_sd("v1")
+    ctx = ctx_for("styletts", "v1", prec)
+    P = np.array([23, 9, 17], np.int32)
+    rng = np.random.default_rng(11)
+    mel = np.zeros((3, int(P.max()), 80), np.float32)
+    for b in range(3):
+        mel[b, :P[b]] = rng.standard_normal((P[b], 80)).astype(np.float32)
+    wav = ctx.vocode_mel(mel, P)
+    for b in range(3):
+        ref = O.hifigan_generator(mel[b, :P[b]].T, hsd, h)
+        check_wav(wav[b, :P[b] * 256], ref, prec, f"utt {b}", e2e=False)
+
+
+def test_vocoder_many_short_utterances():
+    """130 utterances of 1-4 frames: more utterances than the fused kernel's LDS length table holds (scalar-load path),
+    fewer tiles than CUs, row tiles entirely past an utterance's end."""
+    h, hsd = voc_sd("tiny")
+    ctx = ctx_for("styletts", "tiny", "bf16")
+    rng = np.random.default_rng(5)
+    B = 130
+    P = rng.integers(1, 5, B).astype(np.int32)
+    mel = np.zeros((B, 4, 80), np.float32)
+    for b in range(B):
+        mel[b, :P[b]] = rng.standard_normal((P[b], 80)).astype(np.float32)
+    wav = ctx.vocode_mel(mel, P)
+    for b in range(0, B, 7):
+        ref = O.hifigan_generator(mel[b, :P[b]].T, hsd, h)
+        check_wav(wav[b, :P[b] * 256], ref, "bf16", f"utt {b}", e2e=False)
+
+
+@pytest.mark.parametrize("prec", ["f32", "bf16"])
 def test_decoders_alone_against_golden(prec):
     g = np.load(os.path.join(GOLDEN, "blocks_tts.npz"))
     for kind, key in (("styletts", "dec_styletts_y"), ("fastspeech2", "dec_fs2_y")):
