@@ -16,6 +16,17 @@
 // (all channel tiles of a time tile share that XCD's L2).
 #include "zvx_kernels.h"
 
+#include <hip/hip_ext.h>
+
+// Per-launch timing without marker packets: when the caller has armed a pair of events (gemm_profile_events), the
+// dispatch itself carries them (hipExtLaunchKernelGGL start/stop events = the kernel's own begin/end timestamps).
+static thread_local hipEvent_t g_ev_start = nullptr, g_ev_stop = nullptr;
+static thread_local bool g_dry_run = false;     // gemm_variant_of(): walk the launcher's decisions without dispatching
+#define ZVX_LAUNCH(kernel, grid, block, lds, stream, ...) \
+    do { if (g_dry_run) break; \
+         if (g_ev_start) hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, g_ev_start, g_ev_stop, 0, __VA_ARGS__); \
+         else hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__); } while (0)
+
 namespace zvx {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
@@ -790,9 +801,9 @@ static bool launch_convreg_c(const GemmArgs& a, hipStream_t stream) {
     const size_t stage = (size_t)4 * 32 * (32 * 4 + 16);
     if (lds < stage) lds = stage;
     switch (a.ntaps) {
-        case 3: hipLaunchKernelGGL((convreg_kernel<C, 3, BM, WM, WN, MINW>), grid, dim3(256), lds, stream, a); return true;
-        case 7: hipLaunchKernelGGL((convreg_kernel<C, 7, BM, WM, WN, MINW>), grid, dim3(256), lds, stream, a); return true;
-        case 11: hipLaunchKernelGGL((convreg_kernel<C, 11, BM, WM, WN, MINW>), grid, dim3(256), lds, stream, a); return true;
+        case 3: ZVX_LAUNCH((convreg_kernel<C, 3, BM, WM, WN, MINW>), grid, dim3(256), lds, stream, a); return true;
+        case 7: ZVX_LAUNCH((convreg_kernel<C, 7, BM, WM, WN, MINW>), grid, dim3(256), lds, stream, a); return true;
+        case 11: ZVX_LAUNCH((convreg_kernel<C, 11, BM, WM, WN, MINW>), grid, dim3(256), lds, stream, a); return true;
     }
     return false;
 }
@@ -1240,7 +1251,7 @@ static bool launch_resfuse_persist_c(const GemmArgs& a, hipStream_t stream) {
     if (!a.accum_mode && a.out_scale != 1.f) return false;
     const int am = a.accum ? a.accum_mode : 0;
     if (!a.out && !(am & 2)) return false;
-#define ZVX_RFP(NT_, AM_, HO_) hipLaunchKernelGGL((resfuse_persist_kernel<C, NT_, AM_, HO_, TM>), grid, dim3(512), lds, stream, a, ntm, ntiles); return true
+#define ZVX_RFP(NT_, AM_, HO_) ZVX_LAUNCH((resfuse_persist_kernel<C, NT_, AM_, HO_, TM>), grid, dim3(512), lds, stream, a, ntm, ntiles); return true
 #define ZVX_RFP_MODE(NT_) \
     if (a.out) { if (am == 0) { ZVX_RFP(NT_, 0, true); } if (am == 1) { ZVX_RFP(NT_, 1, true); } if (am == 2) { ZVX_RFP(NT_, 2, true); } ZVX_RFP(NT_, 3, true); } \
     else { if (am == 2) { ZVX_RFP(NT_, 2, false); } ZVX_RFP(NT_, 3, false); }
@@ -1265,9 +1276,9 @@ static bool launch_resfuse_c(const GemmArgs& a, hipStream_t stream) {
     const size_t pitch = C * 2 + 16;
     size_t lds = (((size_t)(BM + 2 * a.halo_l) * pitch + 15) & ~(size_t)15) + (size_t)(BM + 2 * h2 + 32) * pitch;
     switch (a.ntaps) {
-        case 3: hipLaunchKernelGGL((resfuse_kernel<C, 3, BM, WM, WN, MINW>), grid, dim3(256), lds, stream, a); return true;
-        case 7: hipLaunchKernelGGL((resfuse_kernel<C, 7, BM, WM, WN, MINW>), grid, dim3(256), lds, stream, a); return true;
-        case 11: hipLaunchKernelGGL((resfuse_kernel<C, 11, BM, WM, WN, MINW>), grid, dim3(256), lds, stream, a); return true;
+        case 3: ZVX_LAUNCH((resfuse_kernel<C, 3, BM, WM, WN, MINW>), grid, dim3(256), lds, stream, a); return true;
+        case 7: ZVX_LAUNCH((resfuse_kernel<C, 7, BM, WM, WN, MINW>), grid, dim3(256), lds, stream, a); return true;
+        case 11: ZVX_LAUNCH((resfuse_kernel<C, 11, BM, WM, WN, MINW>), grid, dim3(256), lds, stream, a); return true;
     }
     return false;
 }
@@ -1313,8 +1324,8 @@ int gemm_num_variants() { return (int)(sizeof(kVariants) / sizeof(kVariants[0]))
 
 template <int BM, int BN, int WM, int WN, int MINW, int R, int EPI = -1>
 static void launch_slab_variant(const GemmArgs& a, dim3 grid, size_t lds, hipStream_t stream) {
-    if (a.K % SLAB_KC == 0) hipLaunchKernelGGL((convslab_kernel<BM, BN, WM, WN, true, MINW, R, EPI>), grid, dim3(256), lds, stream, a);
-    else hipLaunchKernelGGL((convslab_kernel<BM, BN, WM, WN, false, MINW, R, EPI>), grid, dim3(256), lds, stream, a);
+    if (a.K % SLAB_KC == 0) ZVX_LAUNCH((convslab_kernel<BM, BN, WM, WN, true, MINW, R, EPI>), grid, dim3(256), lds, stream, a);
+    else ZVX_LAUNCH((convslab_kernel<BM, BN, WM, WN, false, MINW, R, EPI>), grid, dim3(256), lds, stream, a);
 }
 
 // compile-time epilogue mode of a launch (see ZVX_EPI), or -1 when it needs the run-time epilogue
@@ -1377,6 +1388,8 @@ static int launch_convslab(GemmArgs a, hipStream_t stream) {
     return 6 + best;
 }
 
+void gemm_profile_events(hipEvent_t start, hipEvent_t stop) { g_ev_start = start; g_ev_stop = stop; }
+
 int launch_gemm(const GemmArgs& a, hipStream_t stream) {
     if (a.N <= 0 || a.M <= 0 || a.nbatch <= 0) return -1;
     if (a.ntaps < 1 || a.ntaps > ZVX_MAX_TAPS) return -2;
@@ -1401,21 +1414,28 @@ int launch_gemm(const GemmArgs& a, hipStream_t stream) {
     if ((long)ntn * ntm * a.nbatch * a.nheads < 512 && a.N >= 64) {
         bm = bn = 64; ntn = (a.N + 63) / 64; ntm = (a.M + 63) / 64;
         dim3 grid(ntn * ntm, a.nbatch * a.nheads), block(256);
-        if (a.dtype == DT_BF16) { hipLaunchKernelGGL((gemm_kernel<DT_BF16, 64, 64, 2, 2>), grid, block, 0, stream, a); return 18; }
-        hipLaunchKernelGGL((gemm_kernel<DT_F32, 64, 64, 2, 2>), grid, block, 0, stream, a);
+        if (a.dtype == DT_BF16) { ZVX_LAUNCH((gemm_kernel<DT_BF16, 64, 64, 2, 2>), grid, block, 0, stream, a); return 18; }
+        ZVX_LAUNCH((gemm_kernel<DT_F32, 64, 64, 2, 2>), grid, block, 0, stream, a);
         return 19;
     }
     dim3 grid(ntn * ntm, a.nbatch * a.nheads), block(256);
     const int base = (a.dtype == DT_BF16) ? 0 : 3;
     const int id = base + best;
     switch (id) {
-        case 0: hipLaunchKernelGGL((gemm_kernel<DT_BF16, 128, 128, 2, 2>), grid, block, 0, stream, a); break;
-        case 1: hipLaunchKernelGGL((gemm_kernel<DT_BF16, 256, 64, 4, 1>), grid, block, 0, stream, a); break;
-        case 2: hipLaunchKernelGGL((gemm_kernel<DT_BF16, 256, 32, 4, 1>), grid, block, 0, stream, a); break;
-        case 3: hipLaunchKernelGGL((gemm_kernel<DT_F32, 128, 128, 2, 2>), grid, block, 0, stream, a); break;
-        case 4: hipLaunchKernelGGL((gemm_kernel<DT_F32, 256, 64, 4, 1>), grid, block, 0, stream, a); break;
-        case 5: hipLaunchKernelGGL((gemm_kernel<DT_F32, 256, 32, 4, 1>), grid, block, 0, stream, a); break;
+        case 0: ZVX_LAUNCH((gemm_kernel<DT_BF16, 128, 128, 2, 2>), grid, block, 0, stream, a); break;
+        case 1: ZVX_LAUNCH((gemm_kernel<DT_BF16, 256, 64, 4, 1>), grid, block, 0, stream, a); break;
+        case 2: ZVX_LAUNCH((gemm_kernel<DT_BF16, 256, 32, 4, 1>), grid, block, 0, stream, a); break;
+        case 3: ZVX_LAUNCH((gemm_kernel<DT_F32, 128, 128, 2, 2>), grid, block, 0, stream, a); break;
+        case 4: ZVX_LAUNCH((gemm_kernel<DT_F32, 256, 64, 4, 1>), grid, block, 0, stream, a); break;
+        case 5: ZVX_LAUNCH((gemm_kernel<DT_F32, 256, 32, 4, 1>), grid, block, 0, stream, a); break;
     }
+    return id;
+}
+
+int gemm_variant_of(const GemmArgs& a) {
+    g_dry_run = true;
+    const int id = a.fused ? launch_resfuse(a, nullptr) : launch_gemm(a, nullptr);
+    g_dry_run = false;
     return id;
 }
 

@@ -74,6 +74,7 @@ struct zvx_ctx {
     bool have_features = false, have_mel = false;
     // profiling
     int profile = 0;
+    int profile_only = -1;                 // >= 0: per-launch events only for this kernel variant (keeps the timed region lean)
     hipEvent_t stage_ev[ZVX_T_COUNT][2];
     bool stage_used[ZVX_T_COUNT];
     float stage_ms[ZVX_T_COUNT];
@@ -136,12 +137,12 @@ struct zvx_ctx {
         if (a.flops <= 0) a.flops = 2.0 * (double)a.M * a.nbatch * a.nheads * (double)a.N * (double)a.K * a.ntaps;
         if (!a.Wp && a.dtype == DT_BF16) { auto it = packed.find(a.W); if (it != packed.end()) a.Wp = it->second; }
         GemmEvent ev{};
-        const bool prof = profile >= 2;
-        if (prof) { ev.a = new_event(); ev.b = new_event(); HIPCHK(hipEventRecord(ev.a, stream)); }
+        const bool prof = profile >= 2 && (profile_only < 0 || gemm_variant_of(a) == profile_only);
+        if (prof) { ev.a = new_event(); ev.b = new_event(); gemm_profile_events(ev.a, ev.b); }
         int id = a.fused ? launch_resfuse(a, stream) : launch_gemm(a, stream);
+        if (prof) gemm_profile_events(nullptr, nullptr);
         if (id < 0) fail(ZVX_E_INVALID, "launch_gemm rejected shape M=%d N=%d K=%d taps=%d", a.M, a.N, a.K, a.ntaps);
         if (prof) {
-            HIPCHK(hipEventRecord(ev.b, stream));
             ev.variant = id; ev.flops = a.flops; ev.rows = (long)a.M * a.nbatch * a.nheads; ev.N = a.N; ev.K = a.K; ev.taps = a.ntaps; ev.res = a.res_mode; ev.fused = a.fused;
             const double esz = dtype_size(a.dtype);
             ev.bytes = ((double)a.M * a.nbatch * a.nheads) * ((double)a.K * esz + (double)a.N * dtype_size(a.out_dtype)) +
@@ -988,6 +989,8 @@ int64_t zvx_get_int(const zvx_ctx* c, const char* key) {
     if (k == "dec_kind") return c->dec_kind;
     if (k == "Lmax") return c->Lmax;
     if (k == "profile") return c->profile;
+    if (k == "profile_only") return c->profile_only;
+    if (k.rfind("variant_id:", 0) == 0) { for (int i = 0; i < gemm_num_variants(); i++) if (k.substr(11) == gemm_variant_name(i)) return i; return -1; }
     auto it = c->cfg.find(k);
     if (it != c->cfg.end()) return atoll(it->second.c_str());
     return -1;
@@ -997,6 +1000,7 @@ zvx_status zvx_set_int(zvx_ctx* c, const char* key, int64_t value) {
     return guarded(c, [&] {
         if (!key) fail(ZVX_E_INVALID, "key is NULL");
         if (std::string(key) == "profile") { c->sync(); c->profile = (int)value; }
+        else if (std::string(key) == "profile_only") { c->sync(); c->profile_only = (int)value; }
         else fail(ZVX_E_INVALID, "unknown option '%s'", key);
     });
 }

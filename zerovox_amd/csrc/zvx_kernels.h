@@ -64,6 +64,11 @@ struct GemmArgs {
 
 // Returns the kernel-variant id used (index into gemm_variant_name) or <0 on error.
 int launch_gemm(const GemmArgs& a, hipStream_t stream);
+// arm (or disarm with nullptrs) a pair of events that the NEXT launch_gemm / launch_resfuse dispatch carries as its own
+// start / stop timestamps (no marker packets on the stream)
+void gemm_profile_events(hipEvent_t start, hipEvent_t stop);
+// the kernel variant launch_gemm / launch_resfuse would pick for these arguments (nothing is dispatched)
+int gemm_variant_of(const GemmArgs& a);
 // fused HiFi-GAN ResBlock1 pair (conv1 -> lrelu -> conv2 -> + x) for C = 32 / 64 bf16; -1 if the shape is not covered
 int launch_resfuse(GemmArgs a, hipStream_t stream);
 // fragment-order packing of a bf16 weight [ntaps][N][K] for the conv-slab kernel
