@@ -66,6 +66,14 @@ zvx_status zvx_set_int(zvx_ctx* ctx, const char* key, int64_t value);
  * (synthesize.py:139-141). */
 zvx_status zvx_spkemb(zvx_ctx* ctx, const float* ref_mels, const int32_t* lens, int B, int Tmax, float* out);
 
+/* Log-mel front end of reference audio: wav [B][Nmax] f32 in [-1, 1] with nsamples[b] valid samples ->
+ * mel [B][Tmax][n_mels] = log(clip(mel_basis . |STFT|, 1e-5)) (reflect padding (n_fft-hop)/2, hann window, center=False)
+ * and frames[b] = 1 + (nsamples[b] + 2*pad - n_fft) / hop.  Rows >= frames[b] are zero.  ZVX_E_INVALID if an utterance is
+ * shorter than pad + 1 samples or has more than Tmax frames.
+ * Replaces get_mel_from_wav (mels.py:357-395) as called by ZeroVoxTTS.speaker_embed (synthesize.py:128-137). */
+zvx_status zvx_melspec(zvx_ctx* ctx, const float* wav, const int32_t* nsamples, int B, int Nmax, float* mel, int Tmax,
+                       int32_t* frames);
+
 /* Phoneme encoder + variance adaptor + length regulator.  duration == NULL -> predicted durations
  * (fs2.py:678-681), else forced (force_duration=True, fs2.py:745).  Writes mel_len[B]; optional
  * log_duration / pitch / energy [B][Tmax].  The expanded features stay in the context.

@@ -376,3 +376,24 @@ def test_stage_times_and_kernel_stats_are_reported():
     ctx.set_int("profile", 0)
     assert st["encoder"] > 0 and st["decoder"] > 0 and st["vocoder"] > 0
     assert ks and all(k["launches"] > 0 and k["ms"] > 0 and k["flops"] > 0 for k in ks)
+
+
+def test_mel_frontend_matches_host_restatement():
+    """zvx_melspec (reflect pad + DFT GEMM + mel GEMM + log-clip on the device) against the NumPy restatement of
+    get_mel_from_wav (zerovox_amd/mels.py; parity of BOTH against librosa is unpinned, see that file) on a ragged batch."""
+    from zerovox_amd.mels import get_mel_from_wav
+    ctx = ctx_for("styletts", "tiny", "bf16")
+    rng = np.random.default_rng(3)
+    sr = 22050
+    wavs = []
+    for n in (22050, 9000, 513, 40000):
+        t = np.arange(n) / sr
+        wavs.append((0.3 * np.sin(2 * np.pi * 220 * t) + 0.1 * np.sin(2 * np.pi * 3100 * t) + 0.05 * rng.standard_normal(n)).astype(np.float32))
+    mel, frames = ctx.melspec(wavs)
+    for b, w in enumerate(wavs):
+        ref, _ = get_mel_from_wav(w, sr, 1024, 256, 1024, 80, 0, 8000)
+        assert int(frames[b]) == ref.shape[1]
+        check_f32(mel[b, :frames[b]], ref.T, f"mel {b}", tol=5e-4)
+        assert not mel[b, frames[b]:].any()
+    with pytest.raises(_lib.ZvxError):
+        ctx.melspec([np.zeros(100, np.float32)])                          # shorter than the reflect padding

@@ -117,6 +117,36 @@ def test_mel_frontend_shapes_and_filterbank():
     assert int(mel.mean(axis=1).argmax()) in range(8, 20)                               # 440 Hz lands in a low mel band
 
 
+def test_mel_scale_matches_librosa_documented_examples():
+    """Slaney mel scale against the worked examples in librosa's own docstrings (hz_to_mel / mel_to_hz, htk=False) and the
+    'slaney' area normalisation against its definition (every triangle integrates to 1 over Hz)."""
+    from zerovox_amd.mels import _hz_to_mel, _mel_to_hz, mel_filterbank
+    assert abs(float(_hz_to_mel(60)) - 0.9) < 1e-12
+    assert np.allclose(_hz_to_mel([110, 220, 440]), [1.65, 3.3, 6.6], atol=1e-12)
+    assert abs(float(_mel_to_hz(3)) - 200.0) < 1e-9
+    assert np.allclose(_mel_to_hz([1, 2, 3, 4, 5]), [66.667, 133.333, 200.0, 266.667, 333.333], atol=1e-3)
+    assert abs(float(_hz_to_mel(1000.0)) - 15.0) < 1e-12 and abs(float(_mel_to_hz(_hz_to_mel(6400.0))) - 6400.0) < 1e-6
+    fb = mel_filterbank(22050, 1024, 80, 0, 8000).astype(np.float64)
+    area = fb.sum(axis=1) * (22050 / 1024)
+    assert np.all(np.abs(area[10:] - 1.0) < 0.08)          # wide triangles: the bin sum approximates the integral
+    assert np.all(fb.argmax(axis=1)[1:] >= fb.argmax(axis=1)[:-1])
+
+
+def test_stft_basis_matches_torch_stft():
+    """The windowed DFT basis behind zvx_melspec, pinned against an independent STFT (torch.stft, periodic hann,
+    center=False) -- the STFT half of get_mel_from_wav (mels.py:383-386); the Slaney mel basis stays unpinned (no librosa)."""
+    import torch
+    from zerovox_amd.mels import stft_basis
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal(1024 + 256 * 9).astype(np.float32)
+    ref = torch.stft(torch.from_numpy(x), n_fft=1024, hop_length=256, win_length=1024, window=torch.hann_window(1024, periodic=True),
+                     center=False, return_complex=True).numpy()            # [513, frames]
+    frames = np.stack([x[i * 256:i * 256 + 1024] for i in range(ref.shape[1])]).astype(np.float64)
+    out = frames @ stft_basis(1024, 1024).T
+    assert np.abs(out[:, :513] - ref.real.T).max() < 2e-3 and np.abs(out[:, 513:1026] - ref.imag.T).max() < 2e-3
+    assert not out[:, 1026:].any()
+
+
 def test_library_exports_every_declared_symbol():
     hdr = open(os.path.join(ROOT, "include", "zvx.h")).read()
     code = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)                  # strip comments

@@ -16,7 +16,7 @@ ZVX_DEVICE_OUT, ZVX_NO_SYNC = 1, 2
 STAGES = ("encoder", "variance", "lenreg", "decoder", "vocoder", "spkemb")
 ZVX_T_COUNT = 8
 
-EXPORTS = ("zvx_create", "zvx_destroy", "zvx_last_error", "zvx_get_int", "zvx_set_int", "zvx_spkemb", "zvx_encode",
+EXPORTS = ("zvx_create", "zvx_destroy", "zvx_last_error", "zvx_get_int", "zvx_set_int", "zvx_spkemb", "zvx_melspec", "zvx_encode",
            "zvx_decode", "zvx_decode_features", "zvx_vocode", "zvx_vocode_mel", "zvx_synthesize", "zvx_fetch",
            "zvx_sync", "zvx_stage_times", "zvx_kernel_stats", "zvx_reset_stats")
 
@@ -54,6 +54,7 @@ def load():
     lib.zvx_get_int.restype = C.c_int64
     lib.zvx_set_int.argtypes = [vp, C.c_char_p, C.c_int64]
     lib.zvx_spkemb.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp]
+    lib.zvx_melspec.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp, C.c_int, vp]
     lib.zvx_encode.argtypes = [vp, vp, vp, vp, vp, C.c_int, C.c_int, vp, vp, vp, vp, vp]
     lib.zvx_decode.argtypes = [vp, vp, C.c_int, C.c_int]
     lib.zvx_decode_features.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp, vp, C.c_int]
@@ -130,6 +131,21 @@ class Context:
         out = np.empty((B, self.hidden), np.float32)
         self._chk(self._lib.zvx_spkemb(self._h, _ptr(ref_mels), _ptr(lens), B, Tmax, _ptr(out)))
         return out
+
+    def melspec(self, wavs):
+        """list of 1-D float waveforms -> (log-mel [B][Tmax][n_mels], frames [B])   (get_mel_from_wav on the device)"""
+        B = len(wavs)
+        n = np.array([len(w) for w in wavs], np.int32)
+        Nmax = int(n.max())
+        wav = np.zeros((B, Nmax), np.float32)
+        for b, w in enumerate(wavs):
+            wav[b, :n[b]] = np.asarray(w, np.float32)
+        pad = (self.get_int("fft_size") - self.hop) // 2
+        Tmax = max(1, 1 + (Nmax + 2 * pad - self.get_int("fft_size")) // self.hop)
+        mel = np.zeros((B, Tmax, self.n_mels), np.float32)
+        frames = np.zeros(B, np.int32)
+        self._chk(self._lib.zvx_melspec(self._h, _ptr(wav), _ptr(n), B, Nmax, _ptr(mel), Tmax, _ptr(frames)))
+        return mel, frames
 
     def encode(self, phoneme, puncts, T, spk, duration=None):
         phoneme = _i32(phoneme)

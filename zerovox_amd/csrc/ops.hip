@@ -496,4 +496,54 @@ __global__ void k_l2norm_rows(float* x, int C) {
 }
 void launch_l2norm_rows(float* x, int B, int C, hipStream_t s) { hipLaunchKernelGGL(k_l2norm_rows, dim3(B), dim3(64), 0, s, x, C); }
 
+// ------------------------------------------------------------------------------------------------
+// log-mel front end (mels.py:357-395): reflect padding, |STFT| from the DFT GEMM's (re, im) columns, log(clip)
+// ------------------------------------------------------------------------------------------------
+__global__ void k_reflect_pad(const float* wav, long w_bs, const int* n, float* out, long o_bs, int pad, int out_cols) {
+    const int b = blockIdx.y, nb = n[b];
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < out_cols; i += gridDim.x * blockDim.x) {
+        float v = 0.f;
+        if (i < nb + 2 * pad) {
+            int src = i - pad;
+            if (src < 0) src = -src;
+            if (src >= nb) src = 2 * (nb - 1) - src;
+            v = wav[b * w_bs + src];
+        }
+        out[b * o_bs + i] = v;
+    }
+}
+void launch_reflect_pad(const float* wav, long w_bs, const int* n, float* out, long o_bs, int pad, int B, int out_cols, hipStream_t s) {
+    dim3 grid((out_cols + 255) / 256 < 1024 ? (out_cols + 255) / 256 : 1024, B);
+    hipLaunchKernelGGL(k_reflect_pad, grid, dim3(256), 0, s, wav, w_bs, n, out, o_bs, pad, out_cols);
+}
+
+__global__ void k_stft_mag(const float* spec, int lds_, float* mag, int ldm, int nf, int Tmax, const int* frames) {
+    const int b = blockIdx.z, t = blockIdx.y;
+    const bool live = t < frames[b];
+    const float* sp = spec + ((long)b * Tmax + t) * lds_;
+    float* mp = mag + ((long)b * Tmax + t) * ldm;
+    for (int f = blockIdx.x * blockDim.x + threadIdx.x; f < ldm; f += gridDim.x * blockDim.x) {
+        float v = 0.f;
+        if (live && f < nf) { const float re = sp[f], im = sp[nf + f]; v = sqrtf(re * re + im * im); }
+        mp[f] = v;
+    }
+}
+void launch_stft_mag(const float* spec, int lds_, float* mag, int ldm, int nf, int B, int Tmax, const int* frames, hipStream_t s) {
+    hipLaunchKernelGGL(k_stft_mag, dim3((ldm + 255) / 256, Tmax, B), dim3(256), 0, s, spec, lds_, mag, ldm, nf, Tmax, frames);
+}
+
+__global__ void k_log_clip(float* x, int ldx, int C, float lo, int Tmax, const int* frames) {
+    const int b = blockIdx.y;
+    const long total = (long)Tmax * C;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int t = (int)(i / C), c = (int)(i % C);
+        float* p = x + ((long)b * Tmax + t) * ldx + c;
+        *p = t < frames[b] ? logf(fmaxf(*p, lo)) : 0.f;
+    }
+}
+void launch_log_clip(float* x, int ldx, int C, float lo, int B, int Tmax, const int* frames, hipStream_t s) {
+    const long total = (long)Tmax * C;
+    hipLaunchKernelGGL(k_log_clip, dim3((unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096), B), dim3(256), 0, s, x, ldx, C, lo, Tmax, frames);
+}
+
 }  // namespace zvx

@@ -892,6 +892,61 @@ void copy_out_rows(zvx_ctx* c, const float* src, int rows_max, int C, float* dst
                             device_out ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, c->stream));
 }
 
+// ------------------------------------------------------------------------------------------------
+// log-mel front end of the reference audio (mels.py:357-395 get_mel_from_wav), f32 throughout:
+// reflect pad -> |STFT| as a GEMM against the windowed DFT basis (rows = hop-strided frames of the padded signal)
+// -> mel basis GEMM -> log(clip(., 1e-5))
+// ------------------------------------------------------------------------------------------------
+void run_melspec(zvx_ctx* c, const float* wav, const int32_t* nsamples, int B, int Nmax, float* mel_out, int Tmax, int32_t* frames_out) {
+    const Tensor& dft = c->t("mel.dft");
+    const Tensor& basis = c->t("mel.basis");
+    const int n_fft = dft.dim(2), NR = dft.dim(1), KP = basis.dim(2), nf = n_fft / 2 + 1, nm = c->n_mels, hop = c->hop;
+    const int pad = (n_fft - hop) / 2;
+    std::vector<int> frames(B);
+    int Tf = 0;
+    for (int b = 0; b < B; b++) {
+        const int n = nsamples[b];
+        if (n > Nmax || n < pad + 1 || n + 2 * pad < n_fft) fail(ZVX_E_INVALID, "zvx_melspec: utterance %d has %d samples (need %d..%d)", b, n, std::max(pad + 1, n_fft - 2 * pad), Nmax);
+        frames[b] = 1 + (n + 2 * pad - n_fft) / hop;
+        Tf = std::max(Tf, frames[b]);
+    }
+    if (Tf > Tmax) fail(ZVX_E_BUFFER, "zvx_melspec: %d frames do not fit Tmax = %d", Tf, Tmax);
+    c->stage_begin(ZVX_T_SPKEMB);
+    const long Npad = ((long)Nmax + 2 * pad + 3) & ~3L;
+    float* wav_d = c->fbuf("mel.wav", (size_t)B * Nmax);
+    HIPCHK(hipMemcpyAsync(wav_d, wav, (size_t)B * Nmax * 4, hipMemcpyHostToDevice, c->stream));
+    int* n_d = c->upload_ints("mel.n", nsamples, B);
+    int* fr_d = c->upload_ints("mel.frames", frames.data(), B);
+    float* padded = c->fbuf("mel.pad", (size_t)B * Npad);
+    launch_reflect_pad(wav_d, Nmax, n_d, padded, Npad, pad, B, (int)Npad, c->stream);
+    float* spec = c->fbuf("mel.spec", (size_t)B * Tf * NR);
+    {
+        GemmArgs a = gemm_base(DT_F32);
+        a.X = padded; a.x_bs = Npad; a.ldx = hop; a.W = dft.dev; a.ldw = n_fft; a.w_ts = (long)NR * n_fft;
+        a.M = Tf; a.N = NR; a.K = n_fft; a.nbatch = B; a.in_len = fr_d; a.out_len = fr_d;
+        a.out = spec; a.o_bs = (long)Tf * NR; a.ldo = NR;
+        c->gemm(a);
+    }
+    float* mag = c->fbuf("mel.mag", (size_t)B * Tf * KP);
+    launch_stft_mag(spec, NR, mag, KP, nf, B, Tf, fr_d, c->stream);
+    float* mel_d = c->fbuf("mel.out", (size_t)B * Tf * nm);
+    {
+        GemmArgs a = gemm_base(DT_F32);
+        a.X = mag; a.x_bs = (long)Tf * KP; a.ldx = KP; a.W = basis.dev; a.ldw = KP; a.w_ts = (long)nm * KP;
+        a.M = Tf; a.N = nm; a.K = KP; a.nbatch = B; a.in_len = fr_d; a.out_len = fr_d;
+        a.out = mel_d; a.o_bs = (long)Tf * nm; a.ldo = nm;
+        c->gemm(a);
+    }
+    launch_log_clip(mel_d, nm, nm, 1e-5f, B, Tf, fr_d, c->stream);
+    c->stage_end(ZVX_T_SPKEMB);
+    if (mel_out) {
+        if (Tmax > Tf) memset(mel_out, 0, (size_t)B * Tmax * nm * 4);
+        copy_out_rows(c, mel_d, Tf, nm, mel_out, Tmax, B, false);
+    }
+    if (frames_out) memcpy(frames_out, frames.data(), B * sizeof(int));
+    c->sync();
+}
+
 void do_vocode(zvx_ctx* c, const int32_t* pad_to, float* wav, int64_t wav_stride, int flags) {
     if (!c->have_mel) fail(ZVX_E_STATE, "zvx_vocode: no mel in the context (call zvx_decode first)");
     const int B = c->B;
@@ -1009,6 +1064,13 @@ zvx_status zvx_spkemb(zvx_ctx* c, const float* ref_mels, const int32_t* lens, in
     return guarded(c, [&] {
         if (!ref_mels || !lens || !out || B <= 0 || Tmax <= 0) fail(ZVX_E_INVALID, "zvx_spkemb: bad arguments");
         run_spkemb(c, ref_mels, lens, B, Tmax, out);
+    });
+}
+
+zvx_status zvx_melspec(zvx_ctx* c, const float* wav, const int32_t* nsamples, int B, int Nmax, float* mel, int Tmax, int32_t* frames) {
+    return guarded(c, [&] {
+        if (!wav || !nsamples || B <= 0 || Nmax <= 0 || Tmax <= 0) fail(ZVX_E_INVALID, "zvx_melspec: bad arguments");
+        run_melspec(c, wav, nsamples, B, Nmax, mel, Tmax, frames);
     });
 }
 

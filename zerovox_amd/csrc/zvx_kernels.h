@@ -159,4 +159,12 @@ void launch_asp_pool(const void* x, int x_dt, const float* logits, int B, int F,
                      float* out, hipStream_t s);
 void launch_l2norm_rows(float* x, int B, int C, hipStream_t s);
 
+// ---- log-mel front end (mels.py:357-395) ----
+// out[b][i] = wav[b][reflect(i - pad)] for i < n[b] + 2*pad (numpy 'reflect': no edge repeat), 0 beyond
+void launch_reflect_pad(const float* wav, long w_bs, const int* n, float* out, long o_bs, int pad, int B, int out_cols, hipStream_t s);
+// mag[b][t][f] = sqrt(re^2 + im^2), re = spec[b][t][f], im = spec[b][t][nf + f]; columns [nf, ldm) and rows >= frames[b] -> 0
+void launch_stft_mag(const float* spec, int lds_, float* mag, int ldm, int nf, int B, int Tmax, const int* frames, hipStream_t s);
+// x[b][t][c] = log(max(x, lo)) for t < frames[b], 0 beyond
+void launch_log_clip(float* x, int ldx, int C, float lo, int B, int Tmax, const int* frames, hipStream_t s);
+
 }  // namespace zvx

@@ -1,9 +1,16 @@
-"""Log-mel front end for reference audio (host side, NumPy): the step in front of the speaker encoder.
+"""Log-mel front end for reference audio: constants for the device path + a host (NumPy) restatement used as its checker.
 
-Restates ``get_mel_from_wav`` (mels.py:357-395): reflect-pad (n_fft-hop)/2, STFT n_fft/hop/hann with
-center=False, magnitude, Slaney mel basis (librosa.filters.mel defaults: htk=False, norm='slaney'),
-log(clip(., 1e-5)).  librosa is not installed in the build image, so parity of this file against
-librosa is UNPINNED; the formulas follow librosa's published definitions.
+``get_mel_from_wav`` (mels.py:357-395): reflect-pad (n_fft-hop)/2, STFT n_fft/hop/hann with center=False, magnitude,
+Slaney mel basis (librosa.filters.mel defaults: htk=False, norm='slaney'), log(clip(., 1e-5)).
+
+The product path is ``zvx_melspec`` (HIP): ``stft_basis`` and ``mel_filterbank`` below only build its two weight matrices
+at pack time; ``trim_silence`` stays on the host (as librosa.effects.trim does in the reference).  ``get_mel_from_wav``
+here is the NumPy restatement the GPU tests compare against.
+
+Parity: librosa is not installed in the build image.  Pinned so far (tests/test_host_api.py): the STFT half against
+torch.stft, the mel scale against librosa's documented hz_to_mel / mel_to_hz examples, the Slaney normalisation against
+its definition.  The filterbank as a whole is NOT checked against librosa.filters.mel output -> still "parity unpinned"
+for that matrix.
 """
 import numpy as np
 
@@ -35,6 +42,22 @@ def mel_filterbank(sr, n_fft, n_mels, fmin, fmax):
     w = np.maximum(0, np.minimum(lower, upper))
     w *= (2.0 / (mel_f[2:n_mels + 2] - mel_f[:n_mels]))[:, None]        # slaney area normalisation
     return w.astype(np.float32)
+
+
+def stft_basis(n_fft, win_length):
+    """Windowed real-DFT basis [2*(n_fft/2+1) rounded up to 4][n_fft] (float64): rows f < nf are hann(t)*cos(2 pi f t / n_fft),
+    rows nf + f are -hann(t)*sin(.), so frames @ basis.T = (Re, Im) of librosa.stft(window='hann', center=False).  This is the
+    `mel.dft` tensor of the device front end (zvx_melspec)."""
+    nf = n_fft // 2 + 1
+    win = np.hanning(win_length + 1)[:-1]                                    # periodic hann (fftbins=True)
+    if win_length < n_fft:
+        lp = (n_fft - win_length) // 2
+        win = np.pad(win, (lp, n_fft - win_length - lp))
+    ang = 2.0 * np.pi * np.outer(np.arange(nf), np.arange(n_fft)) / n_fft
+    basis = np.zeros(((2 * nf + 3) // 4 * 4, n_fft), np.float64)
+    basis[:nf] = np.cos(ang) * win[None, :]
+    basis[nf:2 * nf] = -np.sin(ang) * win[None, :]
+    return basis
 
 
 _basis_cache = {}

@@ -108,6 +108,21 @@ def pack_model(modelcfg: dict, tts_sd: dict, hifigan_cfg: dict, hifigan_sd: dict
         raise ValueError("Undefined encoder")                                # ResNetSE34V2.py:143
     bl.cfg("rn_asp", int(rn["encoder_type"] == "ASP"))
 
+    # ---------------- log-mel front end of the reference audio (mels.py:357-395), always f32 ----------------
+    # |STFT| as one GEMM: rows = frames (hop-strided views of the reflect-padded signal), columns = the windowed DFT basis
+    # (cos rows, then -sin rows), followed by the Slaney mel basis as a second GEMM.
+    a = modelcfg["audio"]
+    n_fft, win_len = int(a["fft_size"]), int(a.get("win_length", a["fft_size"]))
+    nf = n_fft // 2 + 1
+    from .mels import mel_filterbank, stft_basis
+    dft = stft_basis(n_fft, win_len)
+    basis = np.zeros((n_mels, (nf + 3) // 4 * 4), np.float32)
+    basis[:, :nf] = mel_filterbank(a["sampling_rate"], n_fft, n_mels, a["fmin"], a["fmax"])
+    for k, v in (("fft_size", n_fft), ("sampling_rate", a["sampling_rate"])):
+        bl.cfg(k, v)
+    bl.add("mel.dft", "f", dft.astype(np.float32)[None])
+    bl.add("mel.basis", "f", basis[None])
+
     # ---------------- phoneme encoder (always f32: it feeds discrete decisions) ----------------
     pe = "_phoneme_encoder._encoder"
     bl.add("enc.emb", "p", sd[pe + ".src_word_emb.weight"])

@@ -13,7 +13,7 @@ import wave
 import numpy as np
 
 from . import _lib
-from .mels import get_mel_from_wav, trim_silence
+from .mels import trim_silence
 from .model import ZeroVox, load_meldec_weights, load_tts_weights
 from .normalize import ZeroVoxNormalizer
 from .symbols import Symbols
@@ -69,10 +69,8 @@ class ZeroVoxTTS:
     def speaker_embed(self, wav: np.ndarray):
         """wav -> [1, 1, hidden] speaker embedding (synthesize.py:123-143)."""
         wav = trim_silence(wav, top_db=40)
-        mel, _ = get_mel_from_wav(audio=wav, sampling_rate=self._sampling_rate, fft_size=self._fft_size,
-                                  hop_size=self._hop_length, win_length=self._win_length, num_mels=self._num_mels,
-                                  fmin=self._mel_fmin, fmax=self._mel_fmax)
-        return self._model._spkemb(np.array([mel.T], dtype=np.float32))
+        mel, frames = self._model.ctx.melspec([wav])                      # get_mel_from_wav on the device (zvx_melspec)
+        return self._model._spkemb(mel[:, :int(frames[0])])
 
     def speaker_embed_from_mel(self, mel: np.ndarray):
         """[Tr, n_mels] log-mel -> [1, 1, hidden] (precomputed-mel entry used by the benchmarks)."""
