@@ -397,3 +397,26 @@ def test_mel_frontend_matches_host_restatement():
         assert not mel[b, frames[b]:].any()
     with pytest.raises(_lib.ZvxError):
         ctx.melspec([np.zeros(100, np.float32)])                          # shorter than the reflect padding
+
+
+@pytest.mark.parametrize("prec", ["f32", "bf16"])
+def test_streamed_vocoding_equals_whole_utterance(prec):
+    """Chunked vocoding with a 16-frame halo reproduces the whole-utterance waveform: bit-exact in bf16 mode
+    (every output sample sees the same inputs in the same order), to rounding in f32 mode; a halo that is too small does not."""
+    from zerovox_amd.model import ZeroVox
+    ctx = ctx_for("styletts", "v1", prec)
+    zv = ZeroVox.__new__(ZeroVox)
+    zv._ctx, zv._hop_length = ctx, 256
+    rng = np.random.default_rng(21)
+    mel = rng.standard_normal((150, 80)).astype(np.float32)
+    whole = ctx.vocode_mel(mel[None], np.array([150], np.int32))[0]
+    for cpc in (1, 3):
+        parts = list(zv.vocode_stream(mel, chunk_frames=40, chunks_per_call=cpc))
+        assert [len(p) for p in parts] == [40 * 256, 40 * 256, 40 * 256, 30 * 256]
+        got = np.concatenate(parts)
+        if prec == "bf16":
+            assert np.array_equal(got, whole)
+        else:
+            check_f32(got, whole, "streamed wav", tol=1e-5)
+    short = np.concatenate(list(zv.vocode_stream(mel, chunk_frames=40, halo=2)))
+    assert np.abs(short - whole).max() > 1e-4                              # the halo is what makes it exact

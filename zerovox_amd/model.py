@@ -104,6 +104,31 @@ class ZeroVox:
         wav, mel_len, log_duration, _ = self.inference_ex(x=x, style_embed=style_embed, normalize_before=normalize_before)
         return wav, mel_len, log_duration
 
+    # HiFi-GAN's receptive field in mel frames (conv_pre k7: 3; upsample stacks: ~1; ResBlock k=11 dilations 1/3/5 at 8
+    # samples per frame: 60 / 8 = 7.5; later stages < 2 in total): SURVEY.md 8(f-4) quotes 9-13.  A halo of 16 frames on
+    # each side makes a chunk's interior identical to the same samples of a whole-utterance pass.
+    STREAM_HALO = 16
+
+    def vocode_stream(self, mel, chunk_frames=64, halo=STREAM_HALO, chunks_per_call=1):
+        """Chunked vocoding for first-audio latency: mel [L, n_mels] -> yields waveform chunks (np.float32) that
+        concatenate to ``vocode_mel(mel)``.  Every chunk is vocoded with ``halo`` extra frames on each side and only its
+        interior is kept; ``chunks_per_call`` chunks ride in one launch sequence as independent batch rows."""
+        mel = np.asarray(mel, np.float32)
+        L, hop = mel.shape[0], self._hop_length
+        starts = list(range(0, L, chunk_frames))
+        for g in range(0, len(starts), max(1, chunks_per_call)):
+            grp = starts[g:g + max(1, chunks_per_call)]
+            spans = [(max(0, s - halo), min(L, s + chunk_frames + halo)) for s in grp]
+            P = np.array([hi - lo for lo, hi in spans], np.int32)
+            batch = np.zeros((len(grp), int(P.max()), mel.shape[1]), np.float32)
+            for i, (lo, hi) in enumerate(spans):
+                batch[i, :hi - lo] = mel[lo:hi]
+            wav = self._ctx.vocode_mel(batch, P)
+            for i, s in enumerate(grp):
+                lo = spans[i][0]
+                n = min(chunk_frames, L - s)
+                yield wav[i, (s - lo) * hop:(s - lo + n) * hop].copy()
+
     def synthesize_batch(self, phoneme, puncts, T, style_embed, duration=None, pad_to=None, want_mel=True, Lmax_cap=0):
         """B independent utterances in one launch sequence; each equals a batch-1 ``inference_ex`` call with
         ``_min_mel_len == pad_to[b]`` (default: the fresh-model value 689).  Padded [B, Tmax] id arrays."""

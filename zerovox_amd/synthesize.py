@@ -128,6 +128,23 @@ class ZeroVoxTTS:
         wav, phoneme, length, _ = self.tts_ex(text=text, spkemb=spkemb)
         return wav, phoneme, length
 
+    def tts_stream(self, text: str, spkemb, chunk_frames=64, chunks_per_call=1):
+        """Streaming variant of ``tts`` (not in the reference): encoder + mel decoder run once, the vocoder
+        runs chunk by chunk (16-frame halo), yielding float32 waveform pieces that concatenate to ``tts(text, spkemb)[0]``
+        up to the reference's `_min_mel_len` zero-padding of short utterances."""
+        text = text.strip()
+        phone_ids, punct_ids = self.text2phonemeids(text)
+        if not phone_ids:
+            return
+        phoneme, puncts = np.array([phone_ids], np.int32), np.array([punct_ids], np.int32)
+        ctx = self._model.ctx
+        mel_len, _, _, _ = ctx.encode(phoneme, puncts, np.array([len(phone_ids)], np.int32), np.asarray(spkemb, np.float32).reshape(1, -1))
+        ml = int(mel_len[0])
+        if ml < 2:
+            raise ValueError(f"predicted mel length {ml} is too short to synthesise")
+        mel = ctx.decode(1, ml)[0, :ml]
+        yield from self._model.vocode_stream(mel, chunk_frames=chunk_frames, chunks_per_call=chunks_per_call)
+
     @property
     def normalizer(self):
         return self._normalizer
