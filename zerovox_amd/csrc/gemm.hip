@@ -965,7 +965,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     constexpr int BM1 = 32 * TM * RG;                          // T1 rows per tile (conv2's input incl. its halo)
     constexpr int H2 = (NT - 1) / 2, BMO = BM1 - 2 * H2;  // output rows per tile
     constexpr int P = C * 2 + 16, CPP = CPR + 1;          // padded row pitch (conflict-free b128 reads), 16-byte slots per row
-    constexpr int NW = NT * KS, NRES = NW;                // fragments per wave / of those resident in registers (the rest: re-read from L2 per tile)
+    constexpr int NW = NT * KS;
+    constexpr bool LEAN = NW > 36;                        // C = 64, k = 11: 44 fragments per wave -> 36 resident, register-lean epilogue
+    constexpr int NRES = LEAN ? 36 : NW; // fragments per wave / of those resident in registers (the rest: re-read from L2 per tile)
     typedef __attribute__((ext_vector_type(4))) int i32x4;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 
@@ -1159,9 +1161,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 const long rm_off = wc * 32 + (lane & 3) * 8;       // row-major phase: this lane's 8 channels
                 unsigned short* accp = (unsigned short*)a.accum + (long)qA.b * a.a_bs + rm_off;
                 unsigned short* outp = (unsigned short*)a.out + (long)qA.b * a.o_bs + rm_off;
-                float4 bb[4];
+                float4 bb[LEAN ? 1 : 4];
+                if (!LEAN) {
 #pragma unroll
-                for (int q = 0; q < 4; q++) bb[q] = BIAS_REG ? bq[q] : *(const float4*)(bias2_l + wc * 32 + 8 * q + h4);
+                    for (int q = 0; q < 4; q++) bb[LEAN ? 0 : q] = BIAS_REG ? bq[q] : *(const float4*)(bias2_l + wc * 32 + 8 * q + h4);
+                }
                 // running sum xs of the resblocks (bf16, row-major): requested up front, consumed in the copy-out phase
                 constexpr bool XS_EARLY = NW < 28;            // registers permitting, for the whole tile at once
                 uint4 xs[TM][2];
@@ -1184,20 +1188,29 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                         }
                     }
                     // MFMA layout: y = acc + b2 + x;  without xs the activation is applied here, with xs in the row-major phase
-                    uint2 rrj[4];
+                    uint2 rrj[LEAN ? 1 : 4];
+                    if (!LEAN) {
 #pragma unroll
-                    for (int q = 0; q < 4; q++) rrj[q] = *(const uint2*)(resp + j * 32 * P + q * 16);
-                    uint2 pk[4];
+                        for (int q = 0; q < 4; q++) rrj[LEAN ? 0 : q] = *(const uint2*)(resp + j * 32 * P + q * 16);
+                    }
+                    uint2 pk[LEAN ? 1 : 4];
 #pragma unroll
                     for (int q = 0; q < 4; q++) {
-                        f32x2 v01 = (f32x2){acc[0][j][4 * q], acc[0][j][4 * q + 1]} + (f32x2){bb[q].x, bb[q].y} + inv_lrelu2(unpack_bf16x2(rrj[q].x), rinv);
-                        f32x2 v23 = (f32x2){acc[0][j][4 * q + 2], acc[0][j][4 * q + 3]} + (f32x2){bb[q].z, bb[q].w} + inv_lrelu2(unpack_bf16x2(rrj[q].y), rinv);
+                        const float4 bq_ = LEAN ? *(const float4*)(bias2_l + wc * 32 + 8 * q + h4) : bb[LEAN ? 0 : q];
+                        const uint2 rq_ = LEAN ? *(const uint2*)(resp + j * 32 * P + q * 16) : rrj[LEAN ? 0 : q];
+                        f32x2 v01 = (f32x2){acc[0][j][4 * q], acc[0][j][4 * q + 1]} + (f32x2){bq_.x, bq_.y} + inv_lrelu2(unpack_bf16x2(rq_.x), rinv);
+                        f32x2 v23 = (f32x2){acc[0][j][4 * q + 2], acc[0][j][4 * q + 3]} + (f32x2){bq_.z, bq_.w} + inv_lrelu2(unpack_bf16x2(rq_.y), rinv);
                         if (!AM) { v01 = lrelu2(v01, slope); v23 = lrelu2(v23, slope); }      // slope 1 = no activation
-                        pk[q].x = pack_bf16x2(v01.x, v01.y);
-                        pk[q].y = pack_bf16x2(v23.x, v23.y);
+                        uint2 pq;
+                        pq.x = pack_bf16x2(v01.x, v01.y);
+                        pq.y = pack_bf16x2(v23.x, v23.y);
+                        if (LEAN) *(uint2*)(stage + (lane & 31) * 80 + (8 * q + h4) * 2) = pq;
+                        else pk[LEAN ? 0 : q] = pq;
                     }
+                    if (!LEAN) {
 #pragma unroll
-                    for (int q = 0; q < 4; q++) *(uint2*)(stage + (lane & 31) * 80 + (8 * q + h4) * 2) = pk[q];
+                        for (int q = 0; q < 4; q++) *(uint2*)(stage + (lane & 31) * 80 + (8 * q + h4) * 2) = pk[LEAN ? 0 : q];
+                    }
                     // row-major: 16 rows x 64 bytes per instruction
                     uint4 o[2];
 #pragma unroll
@@ -1296,10 +1309,9 @@ int launch_resfuse(GemmArgs a, hipStream_t stream) {
     if (!v1) {
         if (a.N == 32 && launch_resfuse_persist_c<32>(a, stream)) return 16;
         if (a.N == 64 && a.ntaps != 11 && launch_resfuse_persist_c<64>(a, stream)) return 17;
-        // C = 64, k = 11 (44 fragments = 176 registers per wave): even with one row block per wave (TM = 1) the persistent
-        // form spills and measures 1.03 ms against 0.97 ms for the per-tile kernel below -> opt-in only
-        static const char* p11 = getenv("ZVX_C64K11_PERSIST");
-        if (p11 && a.N == 64 && a.ntaps == 11 && launch_resfuse_persist_c<64, 1>(a, stream)) return 17;
+        // C = 64, k = 11 (44 fragments = 176 registers per wave): one 32-row block per wave, 36 fragments resident and 8
+        // re-read from L2 per tile, register-lean epilogue -- 0.85 ms against 0.95 ms for the per-tile kernel
+        if (a.N == 64 && a.ntaps == 11 && launch_resfuse_persist_c<64, 1>(a, stream)) return 17;
         if (a.N == 128 && a.ntaps == 3 && launch_resfuse_persist_c<128>(a, stream)) return 13;      // 24 fragments per wave: resident
     }
     if (a.N == 32 && launch_resfuse_c<32, 256, 4, 1, 2>(a, stream)) return 16;
