@@ -16,7 +16,8 @@ def shard_range(n_items: int, rank: int, world: int):
 
 def gather_waveforms(local_wav, local_len, dst=0, group=None):
     """local_wav [B_local, N] (same B_local, N on every rank), local_len [B_local] int32 tensors on the
-    rank's device.  Returns (wav [B, N], lens [B]) on rank ``dst`` (None elsewhere)."""
+    rank's device.  Returns (wav [B, N], lens [B]) on rank ``dst`` (None elsewhere).  The returned tensors are a landing
+    buffer that the next call with the same shapes overwrites: consume (or clone) them first."""
     import torch
     import torch.distributed as dist
 
@@ -24,9 +25,22 @@ def gather_waveforms(local_wav, local_len, dst=0, group=None):
     rank = dist.get_rank(group)
     if world == 1:
         return local_wav, local_len
+    B = local_wav.shape[0]
+
+    def landing():
+        # the peers' rows land directly in one [world*B, N] buffer (views as the gather list: no concatenation pass);
+        # the buffer is reused across calls of the same shape
+        key = (tuple(local_wav.shape), local_wav.dtype, str(local_wav.device), world)
+        if _cache.get("key") != key:
+            _cache["key"] = key
+            _cache["wav"] = torch.empty((world * B,) + tuple(local_wav.shape[1:]), dtype=local_wav.dtype, device=local_wav.device)
+            _cache["len"] = torch.empty((world * B,), dtype=local_len.dtype, device=local_len.device)
+        return _cache["wav"], _cache["len"]
+
+    full_w = full_l = None
     if rank == dst:
-        wavs = [torch.empty_like(local_wav) for _ in range(world)]
-        lens = [torch.empty_like(local_len) for _ in range(world)]
+        full_w, full_l = landing()
+        wavs, lens = list(full_w.split(B)), list(full_l.split(B))
     else:
         wavs = lens = None
     try:
@@ -34,10 +48,12 @@ def gather_waveforms(local_wav, local_len, dst=0, group=None):
         dist.gather(local_len, lens, dst=dst, group=group)
     except (RuntimeError, NotImplementedError):
         # a backend without gather: fall back to all_gather (every rank receives all rows, only dst keeps them)
-        wavs = [torch.empty_like(local_wav) for _ in range(world)]
-        lens = [torch.empty_like(local_len) for _ in range(world)]
-        dist.all_gather(wavs, local_wav, group=group)
-        dist.all_gather(lens, local_len, group=group)
+        full_w, full_l = landing()
+        dist.all_gather(list(full_w.split(B)), local_wav, group=group)
+        dist.all_gather(list(full_l.split(B)), local_len, group=group)
     if rank == dst:
-        return torch.cat(wavs, 0), torch.cat(lens, 0)
+        return full_w, full_l
     return None, None
+
+
+_cache: dict = {}
