@@ -1167,7 +1167,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     for (int q = 0; q < 4; q++) bb[LEAN ? 0 : q] = BIAS_REG ? bq[q] : *(const float4*)(bias2_l + wc * 32 + 8 * q + h4);
                 }
                 // running sum xs of the resblocks (bf16, row-major): requested up front, consumed in the copy-out phase
-                constexpr bool XS_EARLY = NW < 28;            // registers permitting, for the whole tile at once
+                constexpr bool XS_EARLY = NW < 28 || TM == 1;   // registers permitting, for the whole tile at once
                 uint4 xs[TM][2];
                 if ((AM & 1) && XS_EARLY) {
 #pragma unroll
