@@ -17,6 +17,7 @@
 #include "zvx_kernels.h"
 
 #include <hip/hip_ext.h>
+#include <type_traits>
 
 // Per-launch timing without marker packets: when the caller has armed a pair of events (gemm_profile_events), the
 // dispatch itself carries them (hipExtLaunchKernelGGL start/stop events = the kernel's own begin/end timestamps).
@@ -605,7 +606,12 @@ __global__ __launch_bounds__(256, MINW) void convslab_kernel(const GemmArgs a) {
     // fragment is fetched once per workgroup.  Per step: this wave's counted vmcnt (its pieces of step s+1 have
     // landed) + s_barrier (so have everyone else's; and every wave is done reading slot s-1, which the next
     // request overwrites).  No VGPR staging, no fence: DMAs stay in flight across the barrier.
-    constexpr int F = BN / 32, CNT = F >= 4 ? F / 4 : 1, D = R - 1, WAITN = (D - 2) * CNT;
+    // R == 0 selects the register variant: every wave streams the fragments of ITS OWN channel tiles straight into a
+    // 4-step register ring with plain (saddr-form) global loads -- an LDS-DMA instruction costs the issuing wave 100-300
+    // cycles, a global_load a few, and with no shared ring there is no per-step barrier.  The two waves that share a
+    // channel tile fetch the same lines within a few hundred cycles of each other (L1 hits).
+    constexpr bool WREG = R == 0;
+    constexpr int F = BN / 32, CNT = F >= 4 ? F / 4 : 1, WD = 4, D = WREG ? WD : R - 1, WAITN = WREG ? (WD - 1) * TN : (D - 2) * CNT;
     const int nt32_total = (a.N + 31) >> 5;
     const int nsteps = a.ntaps * 4, gtotal = nkc * nsteps;
     const uint4* wsrc[CNT];
@@ -620,8 +626,22 @@ __global__ __launch_bounds__(256, MINW) void convslab_kernel(const GemmArgs a) {
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)slab;   // LDS byte address of the window
     const int dvreg = a.dv[lane & (ZVX_MAX_TAPS - 1)];              // lane t holds tap t's row offset (read back with v_readlane)
     const bool loader = wave * CNT < F;
+    const unsigned char* wq[TN];                                    // register variant: this wave's channel tiles (wave-uniform)
+#pragma unroll
+    for (int i = 0; i < TN; i++) {
+        const int t32 = (n0 >> 5) + wc * TN + i;
+        wq[i] = (const unsigned char*)a.Wp + (long)(t32 < nt32_total ? t32 : 0) * gtotal * 1024;
+    }
+    const unsigned lane16 = lane * 16;
+    u32x4 wreg[WREG ? WD : 1][TN] = {};                              // 4-step ring: slot = k16 index within the tap
+    auto wload = [&](int gs, int slot) {                            // slot is a literal at every call site
+        const long off = (long)(gs < gtotal ? gs : gtotal - 1) * 1024;  // past the end: harmless re-loads keep vmcnt counting uniform
+#pragma unroll
+        for (int i = 0; i < TN; i++)
+            asm volatile("global_load_dwordx4 %0, %1, %2" : "+v"(wreg[WREG ? slot : 0][i]) : "v"(lane16), "s"(wq[i] + off) : "memory");   // "+v": the ring slot keeps ONE physical register across the tap loop
+    };
     auto dma = [&](int gs) {
-        if (!loader) return;
+        if (WREG || !loader) return;
         const int slot = gs & (R - 1);
         const long off = (long)(gs < gtotal ? gs : gtotal - 1) * 64;      // past the end: harmless re-loads keep vmcnt counting uniform
 #pragma unroll
@@ -630,8 +650,11 @@ __global__ __launch_bounds__(256, MINW) void convslab_kernel(const GemmArgs a) {
                                              (__attribute__((address_space(3))) void*)(ring + (slot * F + wave * CNT + j) * 1024), 16, 0, 0);
     };
     // the first D steps are requested BEFORE the slab fill so that their L2 latency overlaps the fill's
+    if (WREG) { wload(0, 0); wload(1, 1); wload(2, 2); wload(3, 3); }
+    else {
 #pragma unroll
-    for (int s0 = 0; s0 < D; s0++) dma(s0);
+        for (int s0 = 0; s0 < D; s0++) dma(s0);
+    }
 
     for (int kc = 0; kc < nkc; kc++) {
         // ---- stage the slab: rows [m0-HL, m0+BM+HR) x 64 channels of chunk kc (all loads in flight, then the stores) ----
@@ -662,10 +685,12 @@ __global__ __launch_bounds__(256, MINW) void convslab_kernel(const GemmArgs a) {
         const unsigned ring_rd = lds_base + (unsigned)(size_t)(ring - slab) + lane * 16 + wc * TN * 1024;
         const int gs0 = kc * nsteps;
         auto rd = [&](uint4 (&xf)[TM], uint4 (&wf)[TN], int gs, unsigned rowoff, int kk) {
-            const unsigned wa = ring_rd + (gs & (R - 1)) * (F * 1024);
+            if (!WREG) {
+                const unsigned wa = ring_rd + (gs & ((WREG ? 1 : R) - 1)) * (F * 1024);
 #pragma unroll
-            for (int i = 0; i < TN; i++)
-                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(wf[i]) : "v"(wa), "n"(i * 1024));
+                for (int i = 0; i < TN; i++)
+                    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(wf[i]) : "v"(wa), "n"(i * 1024));
+            }
 #pragma unroll
             for (int j = 0; j < TM; j++)
                 asm volatile("ds_read_b128 %0, %1" : "=v"(xf[j]) : "v"(lds_base + rowoff + j * 32 * SLAB_PITCH + kk * 32));
@@ -676,6 +701,14 @@ __global__ __launch_bounds__(256, MINW) void convslab_kernel(const GemmArgs a) {
 #pragma unroll
                 for (int j = 0; j < TM; j++)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[i]),
+                                                                       __builtin_bit_cast(bf16x8, xf[j]), acc[i][j], 0, 0, 0);
+        };
+        auto mma_r = [&](uint4 (&xf)[TM], int slot) {
+#pragma unroll
+            for (int i = 0; i < TN; i++)
+#pragma unroll
+                for (int j = 0; j < TM; j++)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wreg[WREG ? slot : 0][i]),
                                                                        __builtin_bit_cast(bf16x8, xf[j]), acc[i][j], 0, 0, 0);
         };
         auto rowoff_of = [&](int tap) {
@@ -689,22 +722,37 @@ __global__ __launch_bounds__(256, MINW) void convslab_kernel(const GemmArgs a) {
 #pragma unroll
             for (int kk = 0; kk < 4; kk++) {
                 const int gs = gs0 + tap * 4 + kk;
-                // this wave's pieces of step gs+1 have landed: only its requests for steps gs+2 .. gs+D-1 may stay in flight
-                asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(WAITN) : "memory");
+                // ring variant: this wave's pieces of step gs+1 have landed (only its requests for steps gs+2 .. gs+D-1 may stay
+                // in flight) + barrier; register variant: this step's own fragments, requested 4 steps ago
+                if (WREG) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(WAITN) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(WAITN) : "memory");
                 dma(gs + D);
                 if (kk & 1) rd(xA, wA, gs + 1, kk == 3 ? rowoff_next : rowoff, (kk + 1) & 3);
                 else        rd(xB, wB, gs + 1, rowoff, kk + 1);
-                // wait for THIS step's set only: the TM+TN reads just issued may remain outstanding
-                asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(TM + TN) : "memory");
+                // wait for THIS step's set only: the reads just issued may remain outstanding
+                asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(WREG ? TM : TM + TN) : "memory");
                 __builtin_amdgcn_sched_barrier(0);
-                if (FULLK || kk < nk16) { if (kk & 1) mma(xB, wB); else mma(xA, wA); }
+                if (FULLK || kk < nk16) {
+                    if (WREG) { if (kk & 1) mma_r(xB, kk); else mma_r(xA, kk); }
+                    else { if (kk & 1) mma(xB, wB); else mma(xA, wA); }
+                }
                 __builtin_amdgcn_sched_barrier(0);
+                if (WREG) wload(gs + WD, kk);                     // the slot just consumed takes the fragments of step gs + 4
             }
             rowoff = rowoff_next;
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the speculative reads of the chunk's last step
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // tail DMAs
+    if (WREG) {
+        // The ring registers stay allocated THROUGH this wait (tied operands): the last requests are still landing in them,
+        // and hipcc would otherwise hand the (to it: dead) registers to the epilogue's address arithmetic first.
+#pragma unroll
+        for (int sl = 0; sl < (WREG ? WD : 1); sl++)
+#pragma unroll
+            for (int i = 0; i < TN; i++) asm volatile("s_waitcnt vmcnt(0)" : "+v"(wreg[sl][i]) :: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // tail DMAs
+    }
     __syncthreads();                             // every wave is done with the slab: its LDS becomes the transpose stage
     if (EPI == ZVX_EPI(0, 0, 1))
         epilogue_direct<TM, TN>(a, acc, b, m0 + wr * (BM / WM), n0 + wc * (BN / WN), out_len, lane, slab + wave * (32 * (TN * 64 + 16)));
@@ -1374,7 +1422,11 @@ static int launch_convslab(GemmArgs a, hipStream_t stream) {
         if (best_cost < 0 || cost < best_cost - 1e-9) { best_cost = cost; best = i; }
     }
     static const int bms[4] = {128, 256, 256, 256};
-    const int ring_slots = best == 0 ? 4 : 8;
+    // 256x128 tiles take their weights through per-wave register rings (see the kernel); ZVX_WRING=1 restores the shared
+    // LDS-DMA ring for A/B runs
+    static const char* wring = getenv("ZVX_WRING");
+    const bool wreg = !wring && best == 1;
+    const int ring_slots = wreg ? 0 : (best == 0 ? 4 : 8);
     const int bn = bns[best], bm = bms[best];
     const int ntn = (a.N + bn - 1) / bn;
     const int ntm = (a.M + bm - 1) / bm;
@@ -1385,7 +1437,15 @@ static int launch_convslab(GemmArgs a, hipStream_t stream) {
     if (lds < stage) lds = stage;
     switch (best) {
         case 0: launch_slab_variant<128, 256, 1, 4, 2, 4>(a, grid, lds, stream); break;
-        case 1: switch (epi_mode_of(a)) {
+        case 1: if (wreg) { switch (epi_mode_of(a)) {
+                    case ZVX_EPI(0, 0, 1): launch_slab_variant<256, 128, 2, 2, 2, 0, ZVX_EPI(0, 0, 1)>(a, grid, lds, stream); break;
+                    case ZVX_EPI(1, 0, 1): launch_slab_variant<256, 128, 2, 2, 2, 0, ZVX_EPI(1, 0, 1)>(a, grid, lds, stream); break;
+                    case ZVX_EPI(1, 2, 0): launch_slab_variant<256, 128, 2, 2, 2, 0, ZVX_EPI(1, 2, 0)>(a, grid, lds, stream); break;
+                    case ZVX_EPI(1, 3, 0): launch_slab_variant<256, 128, 2, 2, 2, 0, ZVX_EPI(1, 3, 0)>(a, grid, lds, stream); break;
+                    case ZVX_EPI(1, 1, 1): launch_slab_variant<256, 128, 2, 2, 2, 0, ZVX_EPI(1, 1, 1)>(a, grid, lds, stream); break;
+                    default: launch_slab_variant<256, 128, 2, 2, 2, 0>(a, grid, lds, stream);
+                } break; }
+                switch (epi_mode_of(a)) {
                     case ZVX_EPI(0, 0, 1): launch_slab_variant<256, 128, 2, 2, 2, 8, ZVX_EPI(0, 0, 1)>(a, grid, lds, stream); break;
                     case ZVX_EPI(1, 0, 1): launch_slab_variant<256, 128, 2, 2, 2, 8, ZVX_EPI(1, 0, 1)>(a, grid, lds, stream); break;
                     case ZVX_EPI(1, 2, 0): launch_slab_variant<256, 128, 2, 2, 2, 8, ZVX_EPI(1, 2, 0)>(a, grid, lds, stream); break;
