@@ -1009,7 +1009,10 @@ __global__ __launch_bounds__(256, MINW) void resfuse_kernel(const GemmArgs a) {
 // (accumulator loads) into every launch, where they then wait for the previous tile's stores.
 template <int C, int NT, int AM, bool HAS_OUT, int TM>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void resfuse_persist_kernel(const GemmArgs a, int ntm, int ntiles) {
-    constexpr int KS = C / 16, CPR = C / 8, NTL = C / 32, RG = 4 / NTL;
+    // C = 16 / 8 (HiFi-GAN V2's last stages): one half-empty 32-channel tile per wave, and for C = 8 a k16 step whose
+    // second 8-channel half is the (zeroed) pad slot of the row -- these stages are HBM-bound, the idle MFMA rows are free
+    constexpr int KS = C >= 16 ? C / 16 : 1, CPR = C / 8, NTL = C >= 32 ? C / 32 : 1, RG = 4 / NTL;
+    constexpr int QN = C >= 32 ? 4 : C / 8;               // 8-channel groups of the wave's tile that exist
     constexpr int BM1 = 32 * TM * RG;                          // T1 rows per tile (conv2's input incl. its halo)
     constexpr int H2 = (NT - 1) / 2, BMO = BM1 - 2 * H2;  // output rows per tile
     constexpr int P = C * 2 + 16, CPP = CPR + 1;          // padded row pitch (conflict-free b128 reads), 16-byte slots per row
@@ -1034,6 +1037,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     int* const lens_l = (int*)(bias2_l + C);                // [2][128]: out_len, in_len per utterance (nbatch <= 128)
     const unsigned lds_addr0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
     const int G = gridDim.x;
+    if (C < 32) {                                            // row pads are read as operands (C = 8) / never written (T1): start from zeros
+        for (int i = tid * 16; i < 4 * SB + 2 * TB; i += 512 * 16) *(uint4*)(lds + i) = make_uint4(0, 0, 0, 0);
+        __syncthreads();
+    }
     if (tid < C) { bias1_l[tid] = a.bias1[tid]; bias2_l[tid] = a.bias[tid]; }
     if (a.nbatch <= 128 && tid < a.nbatch) { lens_l[tid] = a.out_len ? a.out_len[tid] : a.M; lens_l[128 + tid] = a.in_len ? a.in_len[tid] : a.in_len_static; }
 
@@ -1051,7 +1058,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     float4 bq[4];
     if (BIAS_REG) {
 #pragma unroll
-        for (int q = 0; q < 4; q++) bq[q] = *(const float4*)((role ? a.bias : a.bias1) + wc * 32 + 8 * q + h4);
+        for (int q = 0; q < 4; q++) bq[q] = q < QN ? *(const float4*)((role ? a.bias : a.bias1) + wc * 32 + 8 * q + h4) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     // Settle every load issued so far HERE: a compiler-placed `s_waitcnt vmcnt(n)` at a first use inside the tile loop
     // would also wait for the (hidden, in-order) slab DMAs of the conv1 waves and expose their full latency.
@@ -1145,7 +1152,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     const int g = qB.m0 - H2 + i;
                     const bool inside = g >= 0 && g < qB.in_len;
 #pragma unroll
-                    for (int q = 0; q < 4; q++) {
+                    for (int q = 0; q < QN; q++) {
                         const int co = wc * 32 + 8 * q + h4;
                         const float4 bb = BIAS_REG ? bq[q] : *(const float4*)(bias1_l + co);
                         const f32x2 v01 = lrelu2((f32x2){acc[0][j][4 * q], acc[0][j][4 * q + 1]} + (f32x2){bb.x, bb.y}, slope1);
@@ -1199,7 +1206,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                                                                            acc[0][j], 0, 0, 0);
                     }
                 }
-            const int lim = (qA.m0 + BMO < qA.out_len) ? qA.m0 + BMO : qA.out_len;
+            const int lim_rows = (qA.m0 + BMO < qA.out_len) ? qA.m0 + BMO : qA.out_len;
+            const int lim = (C >= 32 || (lane & 3) < CPR) ? lim_rows : -(1 << 30);   // row-major phase: lanes past the last channel chunk idle
             // ---- epilogue in the MFMA layout (lane = time row, 4 consecutive channels per quad): + b2, + x (inverse lrelu of
             //      the slab rows of this tile: output row j <-> slab row j + H2 + H1), xs accumulation, activation; the bf16
             //      results pass through a per-wave LDS stage only to be stored as whole 64-byte row segments ----
@@ -1212,7 +1220,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 float4 bb[LEAN ? 1 : 4];
                 if (!LEAN) {
 #pragma unroll
-                    for (int q = 0; q < 4; q++) bb[LEAN ? 0 : q] = BIAS_REG ? bq[q] : *(const float4*)(bias2_l + wc * 32 + 8 * q + h4);
+                    for (int q = 0; q < QN; q++) bb[LEAN ? 0 : q] = BIAS_REG ? bq[q] : *(const float4*)(bias2_l + wc * 32 + 8 * q + h4);
                 }
                 // running sum xs of the resblocks (bf16, row-major): requested up front, consumed in the copy-out phase
                 constexpr bool XS_EARLY = NW < 28 || TM == 1;   // registers permitting, for the whole tile at once
@@ -1239,11 +1247,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     uint2 rrj[LEAN ? 1 : 4];
                     if (!LEAN) {
 #pragma unroll
-                        for (int q = 0; q < 4; q++) rrj[LEAN ? 0 : q] = *(const uint2*)(resp + j * 32 * P + q * 16);
+                        for (int q = 0; q < QN; q++) rrj[LEAN ? 0 : q] = *(const uint2*)(resp + j * 32 * P + q * 16);
                     }
                     uint2 pk[LEAN ? 1 : 4];
 #pragma unroll
-                    for (int q = 0; q < 4; q++) {
+                    for (int q = 0; q < QN; q++) {
                         const float4 bq_ = LEAN ? *(const float4*)(bias2_l + wc * 32 + 8 * q + h4) : bb[LEAN ? 0 : q];
                         const uint2 rq_ = LEAN ? *(const uint2*)(resp + j * 32 * P + q * 16) : rrj[LEAN ? 0 : q];
                         f32x2 v01 = (f32x2){acc[0][j][4 * q], acc[0][j][4 * q + 1]} + (f32x2){bq_.x, bq_.y} + inv_lrelu2(unpack_bf16x2(rq_.x), rinv);
@@ -1257,7 +1265,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     }
                     if (!LEAN) {
 #pragma unroll
-                        for (int q = 0; q < 4; q++) *(uint2*)(stage + (lane & 31) * 80 + (8 * q + h4) * 2) = pk[LEAN ? 0 : q];
+                        for (int q = 0; q < QN; q++) *(uint2*)(stage + (lane & 31) * 80 + (8 * q + h4) * 2) = pk[LEAN ? 0 : q];
                     }
                     // row-major: 16 rows x 64 bytes per instruction
                     uint4 o[2];
@@ -1294,7 +1302,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 template <int C, int TM = 2>
 static bool launch_resfuse_persist_c(const GemmArgs& a, hipStream_t stream) {
     // 32*TM rows per wave; C = 64, k = 11 (44 fragments = 176 registers per wave) only fits with one row block per wave
-    constexpr int BM1 = 32 * TM * (4 / (C / 32));
+    constexpr int BM1 = 32 * TM * (4 / (C >= 32 ? C / 32 : 1));
     const int h2 = (a.ntaps - 1) / 2, bmo = BM1 - 2 * h2;
     const int ntm = (a.M + bmo - 1) / bmo, ntiles = ntm * a.nbatch;
     static int ncu = 0;
@@ -1322,7 +1330,7 @@ static bool launch_resfuse_persist_c(const GemmArgs& a, hipStream_t stream) {
         if (a.ntaps == 3) { ZVX_RFP_MODE(3) }
         if constexpr (C != 128) {                          // C = 128: only k = 3 keeps its 24 fragments per wave resident
             if (a.ntaps == 7) { ZVX_RFP_MODE(7) }
-            if constexpr (C == 32) { if (a.ntaps == 11) { ZVX_RFP_MODE(11) } }
+            if constexpr (C <= 32) { if (a.ntaps == 11) { ZVX_RFP_MODE(11) } }
         }
     }
 #undef ZVX_RFP_MODE
@@ -1361,6 +1369,8 @@ int launch_resfuse(GemmArgs a, hipStream_t stream) {
         // re-read from L2 per tile, register-lean epilogue -- 0.85 ms against 0.95 ms for the per-tile kernel
         if (a.N == 64 && a.ntaps == 11 && launch_resfuse_persist_c<64, 1>(a, stream)) return 17;
         if (a.N == 128 && a.ntaps == 3 && launch_resfuse_persist_c<128>(a, stream)) return 13;      // 24 fragments per wave: resident
+        if (a.N == 16 && launch_resfuse_persist_c<16>(a, stream)) return 12;
+        if (a.N == 8 && launch_resfuse_persist_c<8>(a, stream)) return 11;
     }
     if (a.N == 32 && launch_resfuse_c<32, 256, 4, 1, 2>(a, stream)) return 16;
     if (a.N == 64 && launch_resfuse_c<64, 128, 2, 2, 2>(a, stream)) return 17;
@@ -1374,7 +1384,7 @@ static const Variant kVariants[] = {
     {"gemm_f32_256x64", DT_F32, 256, 64},     {"gemm_f32_256x32", DT_F32, 256, 32},
     {"convslab_bf16_128x256", DT_BF16, 128, 256}, {"convslab_bf16_256x128", DT_BF16, 256, 128},
     {"convslab_bf16_256x64", DT_BF16, 256, 64},   {"convslab_bf16_256x32", DT_BF16, 256, 32},
-    {"(unused)", DT_BF16, 0, 0}, {"(unused)", DT_BF16, 0, 0}, {"(unused)", DT_BF16, 0, 0}, {"resfuse_bf16_c128", DT_BF16, 64, 128},
+    {"(unused)", DT_BF16, 0, 0}, {"resfuse_bf16_c8", DT_BF16, 256, 8}, {"resfuse_bf16_c16", DT_BF16, 256, 16}, {"resfuse_bf16_c128", DT_BF16, 64, 128},
     {"convreg_bf16_c32", DT_BF16, 512, 32},       {"convreg_bf16_c64", DT_BF16, 256, 64},
     {"resfuse_bf16_c32", DT_BF16, 256, 32},       {"resfuse_bf16_c64", DT_BF16, 128, 64},
     {"gemm_bf16_64x64", DT_BF16, 64, 64},         {"gemm_f32_64x64", DT_F32, 64, 64},

@@ -242,7 +242,7 @@ void upload_weights(zvx_ctx* c) {
     size_t ptotal = 0;
     for (auto& kv : c->tensors) {
         Tensor& t = kv.second;
-        if (t.kind == 'w' && t.dtype == DT_BF16 && t.dims.size() == 3 && t.dim(2) % 16 == 0)
+        if (t.kind == 'w' && t.dtype == DT_BF16 && t.dims.size() == 3 && t.dim(2) % 8 == 0)
             ptotal += (packed_weight_elems(t.dim(0), t.dim(1), t.dim(2)) * 2 + 255) & ~(size_t)255;
     }
     if (ptotal) {
@@ -250,7 +250,7 @@ void upload_weights(zvx_ctx* c) {
         size_t poff = 0;
         for (auto& kv : c->tensors) {
             Tensor& t = kv.second;
-            if (t.kind == 'w' && t.dtype == DT_BF16 && t.dims.size() == 3 && t.dim(2) % 16 == 0) {
+            if (t.kind == 'w' && t.dtype == DT_BF16 && t.dims.size() == 3 && t.dim(2) % 8 == 0) {
                 launch_pack_weights(t.dev, t.dim(0), t.dim(1), t.dim(2), parena + poff, c->stream);
                 c->packed[t.dev] = parena + poff;
                 poff += (packed_weight_elems(t.dim(0), t.dim(1), t.dim(2)) * 2 + 255) & ~(size_t)255;
@@ -715,7 +715,7 @@ void run_vocoder(zvx_ctx* c, const float* mel, int ldm, int Lmel_max, const int*
                     const Tensor& w1 = c->t(rb + ".c1_" + std::to_string(t) + "_w");
                     const Tensor& w2 = c->t(rb + ".c2_" + std::to_string(t) + "_w");
                     static const char* nofuse = getenv("ZVX_NO_RESFUSE");
-                    fuse = !nofuse && dt == DT_BF16 && (Cout == 32 || Cout == 64 || (Cout == 128 && k == 3)) && (k == 3 || k == 7 || k == 11) && dil[t] * (k - 1) / 2 <= 32 &&
+                    fuse = !nofuse && dt == DT_BF16 && (Cout == 8 || Cout == 16 || Cout == 32 || Cout == 64 || (Cout == 128 && k == 3)) && (k == 3 || k == 7 || k == 11) && dil[t] * (k - 1) / 2 <= 32 &&
                            c->packed.count(w1.dev) && c->packed.count(w2.dev);
                     if (fuse) {
                         // one launch: xt = lrelu(c1(x_act)+b1) stays in LDS; x' = c2(xt) + b2 + x      hifigan.py:51-55
