@@ -266,8 +266,49 @@ void launch_instnorm_stats(const void* x, int x_dt, int ldx, int B, int Lmax, co
                            float* mean, float* rstd, hipStream_t s) {
     hipLaunchKernelGGL(k_colstats, dim3((C + 63) / 64, B), dim3(256), 0, s, x, x_dt, ldx, 1, Lmax, L, C, eps, mean, rstd);
 }
-void launch_se_pool(const void* x, int x_dt, int B, int H, int Wmax, const int* W, int C, float* mean, hipStream_t s) {
-    hipLaunchKernelGGL(k_colstats, dim3((C + 63) / 64, B), dim3(256), 0, s, x, x_dt, C, H, Wmax, W, C, 0.f, mean, (float*)nullptr);
+// SE global average pool over an [H][Wmax][C] map (valid columns w < W[b]): the map can be 20 000+ positions of only 32
+// channels, so the rows are split over S blocks per utterance; partial[b][s][c] holds each block's plain sum and
+// k_se_fc folds the S partial sums in a fixed order (deterministic) before the squeeze-excite MLP.
+__global__ __launch_bounds__(256) void k_se_pool_partial(const void* x, int xdt, int H, int Wmax, const int* W, int C, int rows_per_blk, float* partial) {
+    __shared__ float red[256][9];
+    const int b = blockIdx.y, sblk = blockIdx.x, S = gridDim.x;
+    const int lpr = C >> 3, rpp = 256 / lpr;                  // lanes per row (8 channels each), rows per pass
+    const int c8 = threadIdx.x % lpr, rg = threadIdx.x / lpr;
+    const int Wb = W[b], total = H * Wmax;
+    const long base = (long)b * total * C;
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) acc[e] = 0.f;
+    const int r0 = sblk * rows_per_blk, r1 = min(total, r0 + rows_per_blk);
+    if (rg < rpp)
+        for (int r = r0 + rg; r < r1; r += rpp) {
+            if (r % Wmax >= Wb) continue;
+            const long off = base + (long)r * C + c8 * 8;
+            if (xdt == DT_BF16) {
+                const uint4 t = *(const uint4*)((const unsigned short*)x + off);
+                acc[0] += __uint_as_float(t.x << 16); acc[1] += __uint_as_float(t.x & 0xffff0000u);
+                acc[2] += __uint_as_float(t.y << 16); acc[3] += __uint_as_float(t.y & 0xffff0000u);
+                acc[4] += __uint_as_float(t.z << 16); acc[5] += __uint_as_float(t.z & 0xffff0000u);
+                acc[6] += __uint_as_float(t.w << 16); acc[7] += __uint_as_float(t.w & 0xffff0000u);
+            } else {
+                const float4 t0 = *(const float4*)((const float*)x + off), t1 = *(const float4*)((const float*)x + off + 4);
+                acc[0] += t0.x; acc[1] += t0.y; acc[2] += t0.z; acc[3] += t0.w; acc[4] += t1.x; acc[5] += t1.y; acc[6] += t1.z; acc[7] += t1.w;
+            }
+        }
+#pragma unroll
+    for (int e = 0; e < 8; e++) red[threadIdx.x][e] = acc[e];
+    __syncthreads();
+    if (threadIdx.x < C) {                                    // C <= 256
+        const int cc = threadIdx.x >> 3, e = threadIdx.x & 7;
+        float a = 0.f;
+        for (int g = 0; g < rpp; g++) a += red[g * lpr + cc][e];
+        partial[((long)b * S + sblk) * C + threadIdx.x] = a;
+    }
+}
+int se_pool_splits(int H, int Wmax) { const int total = H * Wmax; int S = (total + 511) / 512; return S < 1 ? 1 : (S > 64 ? 64 : S); }
+void launch_se_pool(const void* x, int x_dt, int B, int H, int Wmax, const int* W, int C, float* partial, hipStream_t s) {
+    const int S = se_pool_splits(H, Wmax), total = H * Wmax;
+    hipLaunchKernelGGL(k_se_pool_partial, dim3(S, B), dim3(256), 0, s, x, x_dt, H, Wmax, W, C, (total + S - 1) / S, partial);
 }
 
 // One wave = 64 x 8-channel vectors of a row (1 KiB of bf16); a block covers 64 rows x 512 channels, each lane keeps the
@@ -396,9 +437,11 @@ void launch_conv_post_tanh(const void* x, int x_dt, int ldx, long x_bs, const fl
 
 // ---------------------------------------------------------------- speaker encoder pieces
 // first layer: InstanceNorm1d(F) over time folded in (mean/rstd given) + Conv2d(1->C0,3x3,p1) + ReLU + BN affine
-__global__ void k_spk_front(const float* mels, int Tmax, const int* lens, int F, const float* mean, const float* rstd,
+// one thread = one (f, t) position x 8 output channels (a 16-byte bf16 store; the C0/8 threads of a position write one contiguous row)
+__global__ __launch_bounds__(256) void k_spk_front(const float* mels, int Tmax, const int* lens, int F, const float* mean, const float* rstd,
                             const float* w, const float* bias, const float* bs, const float* bt, int C0, void* out, int odt) {
-    const int b = blockIdx.z, f = blockIdx.y, t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = blockIdx.z, f = blockIdx.y, cpp = C0 >> 3;
+    const int id = blockIdx.x * blockDim.x + threadIdx.x, t = id / cpp, c0 = (id % cpp) * 8;
     const int Tb = lens[b];
     if (t >= Tb) return;
     float xn[9];
@@ -412,26 +455,45 @@ __global__ void k_spk_front(const float* mels, int Tmax, const int* lens, int F,
                 v = (mels[((long)b * Tmax + tt) * F + ff] - mean[b * F + ff]) * rstd[b * F + ff];
             xn[i * 3 + j] = v;
         }
-    const long o = (((long)b * F + f) * Tmax + t) * C0;
-    for (int c = 0; c < C0; c++) {
+    const long o = (((long)b * F + f) * Tmax + t) * C0 + c0;
+    float r[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+        const int c = c0 + e;
         float a = bias[c];
 #pragma unroll
         for (int k = 0; k < 9; k++) a += xn[k] * w[k * C0 + c];
-        a = fmaxf(a, 0.f) * bs[c] + bt[c];                  // conv -> ReLU -> BN  (ResNetSE34V2.py:184-186)
-        st(out, odt, o + c, a);
+        r[e] = fmaxf(a, 0.f) * bs[c] + bt[c];               // conv -> ReLU -> BN  (ResNetSE34V2.py:184-186)
+    }
+    if (odt == DT_BF16) {
+        uint4 pk;
+        pk.x = tobf(r[0]) | ((unsigned)tobf(r[1]) << 16); pk.y = tobf(r[2]) | ((unsigned)tobf(r[3]) << 16);
+        pk.z = tobf(r[4]) | ((unsigned)tobf(r[5]) << 16); pk.w = tobf(r[6]) | ((unsigned)tobf(r[7]) << 16);
+        *(uint4*)((unsigned short*)out + o) = pk;
+    } else {
+        *(float4*)((float*)out + o) = make_float4(r[0], r[1], r[2], r[3]);
+        *(float4*)((float*)out + o + 4) = make_float4(r[4], r[5], r[6], r[7]);
     }
 }
 void launch_spk_front(const float* mels, int Tmax, const int* lens, int F, const float* mean, const float* rstd,
                       const float* w, const float* bias, const float* bn_scale, const float* bn_shift, int C0,
                       void* out, int o_dt, int B, hipStream_t s) {
-    hipLaunchKernelGGL(k_spk_front, dim3((Tmax + 63) / 64, F, B), dim3(64), 0, s, mels, Tmax, lens, F, mean, rstd, w, bias,
+    const int threads = Tmax * (C0 >> 3);                     // C0 % 8 == 0
+    hipLaunchKernelGGL(k_spk_front, dim3((threads + 255) / 256, F, B), dim3(256), 0, s, mels, Tmax, lens, F, mean, rstd, w, bias,
                        bn_scale, bn_shift, C0, out, o_dt);
 }
 
-__global__ void k_se_fc(const float* mean, const float* w1, const float* b1, const float* w2, const float* b2, int C, int Cr, float* scale) {
-    extern __shared__ float hbuf[];
+__global__ void k_se_fc(const float* partial, int S, int H, const int* W, const float* w1, const float* b1, const float* w2, const float* b2, int C, int Cr, float* scale) {
+    extern __shared__ float hbuf[];                           // [Cr] hidden + [C] mean
     const int b = blockIdx.x;
-    const float* m = mean + (long)b * C;
+    float* m = hbuf + Cr;
+    const float cnt = (float)H * (float)W[b];
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float a = 0.f;
+        for (int i = 0; i < S; i++) a += partial[((long)b * S + i) * C + c];
+        m[c] = a / cnt;
+    }
+    __syncthreads();
     for (int j = threadIdx.x; j < Cr; j += blockDim.x) {
         float a = b1[j];
         for (int c = 0; c < C; c++) a += w1[(long)j * C + c] * m[c];
@@ -444,21 +506,52 @@ __global__ void k_se_fc(const float* mean, const float* w1, const float* b1, con
         scale[(long)b * C + c] = 1.0f / (1.0f + expf(-a));
     }
 }
-void launch_se_fc(const float* mean, const float* w1, const float* b1, const float* w2, const float* b2, int C,
+void launch_se_fc(const float* partial, int S, int H, const int* W, const float* w1, const float* b1, const float* w2, const float* b2, int C,
                   int Cr, float* scale, int B, hipStream_t s) {
-    hipLaunchKernelGGL(k_se_fc, dim3(B), dim3(256), Cr * sizeof(float), s, mean, w1, b1, w2, b2, C, Cr, scale);
+    hipLaunchKernelGGL(k_se_fc, dim3(B), dim3(256), (Cr + C) * sizeof(float), s, partial, S, H, W, w1, b1, w2, b2, C, Cr, scale);
 }
 
-__global__ void k_se_apply(const void* x, const void* res, void* y, int dt, const float* scale, int H, int Wmax, const int* W, int C) {
-    const int b = blockIdx.z, hh = blockIdx.y, w = blockIdx.x;
-    if (w >= W[b]) return;
-    const long o = (((long)b * H + hh) * Wmax + w) * C;
-    for (int c = threadIdx.x; c < C; c += blockDim.x)
-        st(y, dt, o + c, fmaxf(ld(x, dt, o + c) * scale[(long)b * C + c] + ld(res, dt, o + c), 0.f));
+// y = relu(x * scale[b][c] + res): 8 channels (16 bytes of bf16) per thread, grid-stride over the map's vectors
+__global__ __launch_bounds__(256) void k_se_apply(const void* x, const void* res, void* y, int dt, const float* scale, int H, int Wmax, const int* W, int C) {
+    const int b = blockIdx.y, lpr = C >> 3;
+    const long nvec = (long)H * Wmax * lpr;
+    const long base = (long)b * H * Wmax * C;
+    const int Wb = W[b];
+    for (long v = blockIdx.x * (long)blockDim.x + threadIdx.x; v < nvec; v += (long)gridDim.x * blockDim.x) {
+        const long pos = v / lpr; const int c = (int)(v % lpr) * 8;
+        if ((int)(pos % Wmax) >= Wb) continue;
+        const long o = base + pos * C + c;
+        const float4 s0 = *(const float4*)(scale + (long)b * C + c), s1 = *(const float4*)(scale + (long)b * C + c + 4);
+        const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+        float xv[8], rv[8];
+        if (dt == DT_BF16) {
+            const uint4 a = *(const uint4*)((const unsigned short*)x + o), r = *(const uint4*)((const unsigned short*)res + o);
+            const unsigned au[4] = {a.x, a.y, a.z, a.w}, ru[4] = {r.x, r.y, r.z, r.w};
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                xv[2 * i] = __uint_as_float(au[i] << 16); xv[2 * i + 1] = __uint_as_float(au[i] & 0xffff0000u);
+                rv[2 * i] = __uint_as_float(ru[i] << 16); rv[2 * i + 1] = __uint_as_float(ru[i] & 0xffff0000u);
+            }
+            unsigned short ov[8];
+#pragma unroll
+            for (int e = 0; e < 8; e++) ov[e] = tobf(fmaxf(xv[e] * sc[e] + rv[e], 0.f));
+            uint4 out;
+            out.x = ov[0] | ((unsigned)ov[1] << 16); out.y = ov[2] | ((unsigned)ov[3] << 16);
+            out.z = ov[4] | ((unsigned)ov[5] << 16); out.w = ov[6] | ((unsigned)ov[7] << 16);
+            *(uint4*)((unsigned short*)y + o) = out;
+        } else {
+            const float4 a0 = *(const float4*)((const float*)x + o), a1 = *(const float4*)((const float*)x + o + 4);
+            const float4 r0 = *(const float4*)((const float*)res + o), r1 = *(const float4*)((const float*)res + o + 4);
+            *(float4*)((float*)y + o) = make_float4(fmaxf(a0.x * sc[0] + r0.x, 0.f), fmaxf(a0.y * sc[1] + r0.y, 0.f), fmaxf(a0.z * sc[2] + r0.z, 0.f), fmaxf(a0.w * sc[3] + r0.w, 0.f));
+            *(float4*)((float*)y + o + 4) = make_float4(fmaxf(a1.x * sc[4] + r1.x, 0.f), fmaxf(a1.y * sc[5] + r1.y, 0.f), fmaxf(a1.z * sc[6] + r1.z, 0.f), fmaxf(a1.w * sc[7] + r1.w, 0.f));
+        }
+    }
 }
 void launch_se_apply(const void* x, const void* res, void* y, int dt, const float* scale, int B, int H, int Wmax,
                      const int* W, int C, hipStream_t s) {
-    hipLaunchKernelGGL(k_se_apply, dim3(Wmax, H, B), dim3(C < 256 ? C : 256), 0, s, x, res, y, dt, scale, H, Wmax, W, C);
+    const long nvec = (long)H * Wmax * (C >> 3);
+    const long blocks = (nvec + 255) / 256;
+    hipLaunchKernelGGL(k_se_apply, dim3((unsigned)(blocks < 2048 ? blocks : 2048), B), dim3(256), 0, s, x, res, y, dt, scale, H, Wmax, W, C);
 }
 
 // attentive statistics pooling: softmax over time per feature column, weighted mean / std
@@ -544,6 +637,35 @@ __global__ void k_log_clip(float* x, int ldx, int C, float lo, int Tmax, const i
 void launch_log_clip(float* x, int ldx, int C, float lo, int B, int Tmax, const int* frames, hipStream_t s) {
     const long total = (long)Tmax * C;
     hipLaunchKernelGGL(k_log_clip, dim3((unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096), B), dim3(256), 0, s, x, ldx, C, lo, Tmax, frames);
+}
+
+// ------------------------------------------------------------------------------------------------
+// out[b][n] = bias[n] + dot(x[b][0:K], w[n][0:K]) for a handful of rows b and a long K (speaker-encoder head: 50 x 5120 -> 528):
+// one wave per (output column, block of 16 rows), the K axis spread over the lanes (float4).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_fc_rows(const float* x, int ldx, const float* w, int ldw, const float* bias, float* out, int ldo, int B, int N, int K) {
+    const int n = blockIdx.x, b0 = blockIdx.y * 16, lane = threadIdx.x;
+    const float* wn = w + (long)n * ldw;
+    float acc[16];
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[r] = 0.f;
+    for (int k = lane * 4; k < K; k += 256) {                 // K % 4 == 0
+        const float4 wv = *(const float4*)(wn + k);
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int b = b0 + r < B ? b0 + r : B - 1;        // clamp: branch-free loads, surplus rows discarded below
+            const float4 xv = *(const float4*)(x + (long)b * ldx + k);
+            acc[r] += xv.x * wv.x + xv.y * wv.y + xv.z * wv.z + xv.w * wv.w;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const float t = wave_sum(acc[r]);
+        if (lane == 0 && b0 + r < B) out[(long)(b0 + r) * ldo + n] = t + (bias ? bias[n] : 0.f);
+    }
+}
+void launch_fc_rows(const float* x, int ldx, const float* w, int ldw, const float* bias, float* out, int ldo, int B, int N, int K, hipStream_t s) {
+    hipLaunchKernelGGL(k_fc_rows, dim3(N, (B + 15) / 16), dim3(64), 0, s, x, ldx, w, ldw, bias, out, ldo, B, N, K);
 }
 
 }  // namespace zvx

@@ -833,8 +833,10 @@ void run_spkemb(zvx_ctx* c, const float* ref_mels, const int32_t* lens, int B, i
             // conv2 (+ folded BN2)                                           :90-91
             conv3(p + ".c2", o1, planes, Hout, Wout, wout_d, 1, o2, c->pf(p + ".c2_b"), ACT_NONE, nullptr, nullptr, 3);
             // SE: global average pool -> fc -> relu -> fc -> sigmoid        :63-67
-            launch_se_pool(o2, dt, B, Hout, Wout, wout_d, planes, mean, c->stream);
-            launch_se_fc(mean, c->pf(p + ".se_w1"), c->pf(p + ".se_b1"), c->pf(p + ".se_w2"), c->pf(p + ".se_b2"), planes, planes / 8, sescale, B, c->stream);
+            const int nsplit = se_pool_splits(Hout, Wout);
+            float* separt = c->fbuf("spk.separt", (size_t)B * nsplit * planes);
+            launch_se_pool(o2, dt, B, Hout, Wout, wout_d, planes, separt, c->stream);
+            launch_se_fc(separt, nsplit, Hout, wout_d, c->pf(p + ".se_w1"), c->pf(p + ".se_b1"), c->pf(p + ".se_w2"), c->pf(p + ".se_b2"), planes, planes / 8, sescale, B, c->stream);
             const void* resid = x;
             if (c->has(p + ".ds")) {                                          // 1x1 stride-s conv + folded BN   :94-95
                 conv3(p + ".ds", x, Cin, Hin, Win, win_d, stride, rs, c->pf(p + ".ds_b"), ACT_NONE, nullptr, nullptr, 1);
@@ -872,12 +874,8 @@ void run_spkemb(zvx_ctx* c, const float* ref_mels, const int32_t* lens, int B, i
     float* pooled = c->fbuf("spk.pooled", (size_t)B * 2 * D);
     launch_asp_pool(x, dt, logits, B, Fp, Wp, w3_d, C4, pooled, c->stream);
     float* emb = c->fbuf("spk.emb", (size_t)B * H);
-    {
-        GemmArgs a = gemm_base(DT_F32);
-        a.X = pooled; a.ldx = 2 * D; a.W = c->t("spk.fc_w").dev; a.ldw = 2 * D; a.M = B; a.N = H; a.K = 2 * D; a.in_len_static = B;
-        a.bias = c->pf("spk.fc_b"); a.bias_mode = 1; a.out = emb; a.ldo = H;
-        c->gemm(a);
-    }
+    // Linear(2*D -> hidden): a few rows against a 5120-long K -- one wave per output column      ResNetSE34V2.py:207
+    launch_fc_rows(pooled, 2 * D, (const float*)c->t("spk.fc_w").dev, 2 * D, c->pf("spk.fc_b"), emb, H, B, H, 2 * D, c->stream);
     launch_l2norm_rows(emb, B, H, c->stream);                                  // F.normalize   :209-210
     c->stage_end(ZVX_T_SPKEMB);
     HIPCHK(hipMemcpyAsync(out_host, emb, (size_t)B * H * 4, hipMemcpyDeviceToHost, c->stream));

@@ -145,10 +145,12 @@ void launch_conv_post_tanh(const void* x, int x_dt, int ldx, long x_bs, const fl
 void launch_spk_front(const float* mels, int Tmax, const int* lens, int F, const float* mean, const float* rstd,
                       const float* w /*[9][C0]*/, const float* bias, const float* bn_scale, const float* bn_shift,
                       int C0, void* out, int o_dt, int B, hipStream_t s);
-// mean over valid (f, t) per (b, c) of map [b][H][Wmax][C]
-void launch_se_pool(const void* x, int x_dt, int B, int H, int Wmax, const int* W, int C, float* mean, hipStream_t s);
-// s = sigmoid(W2 relu(W1 m + b1) + b2) per clip
-void launch_se_fc(const float* mean, const float* w1, const float* b1, const float* w2, const float* b2, int C,
+// SE global average pool, first half: partial[b][s][c] = sum over the s-th of S = se_pool_splits(H, Wmax) row blocks of the
+// valid (f, t) positions of map [b][H][Wmax][C]   (C % 8 == 0, C <= 256)
+int se_pool_splits(int H, int Wmax);
+void launch_se_pool(const void* x, int x_dt, int B, int H, int Wmax, const int* W, int C, float* partial, hipStream_t s);
+// second half + MLP: m = sum_s partial / (H * W[b]);  scale = sigmoid(W2 relu(W1 m + b1) + b2) per clip
+void launch_se_fc(const float* partial, int S, int H, const int* W, const float* w1, const float* b1, const float* w2, const float* b2, int C,
                   int Cr, float* scale, int B, hipStream_t s);
 // y = relu(x * scale[b][c] + res)
 void launch_se_apply(const void* x, const void* res, void* y, int dt, const float* scale, int B, int H, int Wmax,
@@ -166,5 +168,8 @@ void launch_reflect_pad(const float* wav, long w_bs, const int* n, float* out, l
 void launch_stft_mag(const float* spec, int lds_, float* mag, int ldm, int nf, int B, int Tmax, const int* frames, hipStream_t s);
 // x[b][t][c] = log(max(x, lo)) for t < frames[b], 0 beyond
 void launch_log_clip(float* x, int ldx, int C, float lo, int B, int Tmax, const int* frames, hipStream_t s);
+
+// skinny f32 linear: out[b][n] = bias[n] + dot(x[b], w[n]) for few rows b and long K (K % 4 == 0)
+void launch_fc_rows(const float* x, int ldx, const float* w, int ldw, const float* bias, float* out, int ldo, int B, int N, int K, hipStream_t s);
 
 }  // namespace zvx
