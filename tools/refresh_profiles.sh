@@ -12,6 +12,9 @@ python $ROOT/bench.py > $OUT/bench_n1.json 2> $OUT/bench_n1.err
 CMD="python $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline"
 rm -rf /tmp/kt; timeout 600 rocprofv3 --kernel-trace -d /tmp/kt -o kt -- $CMD > /dev/null 2>&1
 python $ROOT/tools/rocpd_summary.py $(find /tmp/kt -name "*.db" | head -1) > $OUT/kernel_trace_bench_n1.txt
+# the tool's own --stats table of the same command
+rm -rf /tmp/ks; timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks -o ks -- $CMD > /dev/null 2>&1
+cp $(find /tmp/ks -name "*kernel_stats.csv" | head -1) $OUT/rocprofv3_kernel_stats.csv
 for C in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pm_$C; timeout 600 rocprofv3 --pmc $C -d /tmp/pm_$C -o pm -- $CMD > /dev/null 2>&1
   python $ROOT/tools/rocpd_summary.py $(find /tmp/pm_$C -name "*.db" | head -1) --pmc > $OUT/pmc_${C}_bench_n1.txt
