@@ -1,6 +1,13 @@
-// gemm.hip -- gathered-row GEMM ("conv-GEMM") on gfx950 MFMA.  See GemmArgs in zvx_kernels.h.
+// gemm.hip -- the MFMA kernels of the synthesis path on gfx950.  See GemmArgs in zvx_kernels.h.
 //
-// One kernel covers every contraction of the synthesis path: dilated Conv1d (HiFi-GAN ResBlocks,
+//   gemm_kernel             generic gathered-row GEMM (this comment): f32 path, attention products, 2-D taps
+//   convslab_kernel         bf16 1-D convs / linears against static weights: slab in LDS, fragment-packed weight stream
+//   convreg_kernel          single square convs with C <= 64: all weight fragments in registers
+//   resfuse_kernel          fused ResBlock1 pair, one tile per workgroup (fallback)
+//   resfuse_persist_kernel  fused ResBlock1 pair, persistent + wave-specialised (C = 8 .. 128)
+//   epilogue / epilogue_rows / epilogue_direct   MFMA-layout, LDS-transposed row-major, and bf16-staged epilogues
+//
+// The generic kernel covers every contraction shape of the path: dilated Conv1d (HiFi-GAN ResBlocks,
 // hifigan.py:25-86; FFN conv k=9, fs2.py:175-187; StyleTTS k=3 convs, styletts.py:28-29), polyphase
 // ConvTranspose1d (hifigan.py:100-103), Linear (fs2.py:118-128), the attention products (fs2.py:49-56)
 // and the ResNet Conv2d (ResNetSE34V2.py:74-76) via 2-D taps.
@@ -523,11 +530,12 @@ __device__ __forceinline__ void epilogue_direct(const GemmArgs& a, f32x16 (&acc)
 //
 // Each workgroup owns BM time rows x BN channels.  Per 64-channel K-chunk the input slab
 // (BM + halo rows) x 64 ch is staged ONCE into LDS and re-used by every tap (a tap is just a row offset
-// into the slab), instead of being re-staged per tap.  Weights never touch LDS: they are pre-packed at
-// load time into MFMA-fragment order ([channel tile][K-chunk][tap][k16][lane][8 bf16], 1 KiB per
-// fragment) so that a wave streams its own channel tiles with perfectly coalesced 16-byte loads straight
-// into the srcA registers, one tap ahead of the MFMAs.  The main loop has no barrier except the two
-// around each slab refill; several workgroups per CU overlap one block's refill with another's MFMAs.
+// into the slab), instead of being re-staged per tap.  Weights are pre-packed at load time into MFMA-fragment
+// order ([channel tile][K-chunk][tap][k16][lane][8 bf16], 1 KiB per fragment).  Two ways of streaming them
+// (template parameter R): R == 0 -- every wave fetches the fragments of its own channel tiles with coalesced
+// 16-byte global loads straight into a 4-step ring of srcA registers (256x128 tiles: no barrier inside a K-chunk);
+// R > 0 -- one LDS ring per workgroup filled by LDS-DMA, R-1 steps ahead, one barrier per step (other tile shapes).
+// Two workgroups per CU overlap one block's refill / epilogue with the other's MFMAs.
 // ================================================================================================
 #define SLAB_KC 64
 #define SLAB_PITCH 144      // 128 B of channels + 16 B pad: 16 consecutive rows hit 16 distinct 16-B slots
