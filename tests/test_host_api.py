@@ -176,3 +176,23 @@ def test_cpu_device_is_refused():
     with pytest.raises(_lib.ZvxError):
         parse_device("cpu")
     assert parse_device("cuda:3") == 3 and parse_device("cuda") == 0
+
+
+def test_committed_bench_line_follows_the_contract():
+    """The bench line committed under profiles/ (produced by `python bench.py` on the GPU box) carries every field the
+    driver and the judge read."""
+    import json
+    path = os.path.join(ROOT, "profiles", "r01_bench_n1.json")
+    if not os.path.exists(path):
+        pytest.skip("no committed bench line")
+    d = json.loads(open(path).read().strip().splitlines()[-1])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["unit"] == "samples/s" and d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and r["unit"] in ("GB/s", "TFLOP/s")
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
+    assert abs(d["value"] - d["config"]["global_batch"] * d["config"]["samples_per_utt"] / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
