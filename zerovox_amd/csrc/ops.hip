@@ -393,24 +393,38 @@ void launch_copy_rows_f32(const void* src, int s_dt, int lds, long s_bs, float* 
 
 // ---------------------------------------------------------------- conv_post (C -> 1) + tanh      hifigan.py:127-128
 // x is the activated last stage [b][Nmax][ldx]; one thread per output sample, weights broadcast from LDS.
-__global__ void k_conv_post_tanh(const void* x, int xdt, int ldx, long x_bs, const float* w, float bias, int kt, int C,
+// conv_post (C -> 1, k taps) + tanh: a block of 256 samples stages its (256 + k - 1) input rows in LDS once (coalesced
+// 16-byte loads, padded pitch) instead of every thread pulling its k rows through L1; the accumulation order per sample
+// is unchanged (tap-major, then channel groups), so results are bit-identical to the direct form.
+__global__ __launch_bounds__(256) void k_conv_post_tanh(const void* x, int xdt, int ldx, long x_bs, const float* w, float bias, int kt, int C,
                                  float* wav, long wav_bs, const int* in_len, int len_mul, const int* out_len, int out_mul) {
-    extern __shared__ float wl[];
+    extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
+    const int es = xdt == DT_BF16 ? 2 : 4, rowb = C * es, pitch = rowb + 16, half = (kt - 1) / 2, nrows = 256 + kt - 1;
+    float* wl = (float*)(sm + (size_t)nrows * pitch);
     for (int i = threadIdx.x; i < kt * C; i += blockDim.x) wl[i] = w[i];
-    __syncthreads();
     const int b = blockIdx.y;
-    const long n = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long n0 = (long)blockIdx.x * 256;
     const long nin = (long)in_len[b] * len_mul, nout = (long)out_len[b] * out_mul;
+    if (n0 >= nout) return;
+    const int cpr = rowb >> 4;                               // 16-byte chunks per row
+    for (int i = threadIdx.x; i < nrows * cpr; i += 256) {
+        const int r = i / cpr, q = i % cpr;
+        const long m = n0 + r - half;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (m >= 0 && m < nin) v = *(const uint4*)((const unsigned char*)x + (b * x_bs + m * ldx) * es + q * 16);
+        *(uint4*)(sm + r * pitch + q * 16) = v;
+    }
+    __syncthreads();
+    const long n = n0 + threadIdx.x;
     if (n >= nout) return;
-    const int half = (kt - 1) / 2;
     float acc = bias;
     for (int k = 0; k < kt; k++) {
         const long m = n + k - half;
         if (m < 0 || m >= nin) continue;
-        const long o = b * x_bs + m * ldx;
+        const unsigned char* row = sm + (threadIdx.x + k) * pitch;
         if (xdt == DT_BF16) {
             for (int c = 0; c < C; c += 8) {
-                const uint4 t = *(const uint4*)((const unsigned short*)x + o + c);
+                const uint4 t = *(const uint4*)(row + c * 2);
                 const float* ww = wl + k * C + c;
                 acc += __uint_as_float(t.x << 16) * ww[0] + __uint_as_float(t.x & 0xffff0000u) * ww[1]
                      + __uint_as_float(t.y << 16) * ww[2] + __uint_as_float(t.y & 0xffff0000u) * ww[3]
@@ -419,7 +433,7 @@ __global__ void k_conv_post_tanh(const void* x, int xdt, int ldx, long x_bs, con
             }
         } else {
             for (int c = 0; c < C; c += 4) {
-                const float4 t = *(const float4*)((const float*)x + o + c);
+                const float4 t = *(const float4*)(row + c * 4);
                 const float* ww = wl + k * C + c;
                 acc += t.x * ww[0] + t.y * ww[1] + t.z * ww[2] + t.w * ww[3];
             }
@@ -431,7 +445,9 @@ void launch_conv_post_tanh(const void* x, int x_dt, int ldx, long x_bs, const fl
                            int ktaps, int C, float* wav, long wav_bs, int B, int Nmax, const int* in_len,
                            int len_mul, const int* out_len, int out_mul, hipStream_t s) {
     if (Nmax <= 0) return;
-    hipLaunchKernelGGL(k_conv_post_tanh, dim3((Nmax + 255) / 256, B), dim3(256), ktaps * C * sizeof(float), s, x, x_dt, ldx, x_bs, w,
+    const size_t es = x_dt == DT_BF16 ? 2 : 4;
+    const size_t lds = (size_t)(256 + ktaps - 1) * (C * es + 16) + (size_t)ktaps * C * sizeof(float);
+    hipLaunchKernelGGL(k_conv_post_tanh, dim3((Nmax + 255) / 256, B), dim3(256), lds, s, x, x_dt, ldx, x_bs, w,
                        bias, ktaps, C, wav, wav_bs, in_len, len_mul, out_len, out_mul);
 }
 
