@@ -685,16 +685,31 @@ void run_vocoder(zvx_ctx* c, const float* mel, int ldm, int Lmel_max, const int*
         const int u = c->voc_rates[i], ku = c->voc_ksizes[i], Cout = Cin / 2;
         const int rows_in = Pmax * mul, rows = rows_in * u;
         const int* len_in = lens_d + (size_t)(i + 1) * B; const int* len = lens_d + (size_t)(i + 2) * B;
-        {   // ConvTranspose1d as a 3-tap polyphase GEMM: out[t][ph*Cout+co]        hifigan.py:118
+        {   // ConvTranspose1d as a polyphase GEMM: out[t][ph*Cout+co]                  hifigan.py:118
+            const std::string up = "voc.up" + std::to_string(i);
             GemmArgs a = gemm_base(dt);
-            a.X = A; a.x_bs = (long)rows_in * Cin; a.ldx = Cin; a.W = c->t("voc.up" + std::to_string(i) + "_w").dev; a.ldw = Cin;
-            a.w_ts = (long)u * Cout * Cin;
-            a.M = rows_in; a.N = u * Cout; a.K = Cin; a.nbatch = B; a.in_len = len_in; a.out_len = len_in;
-            a.ntaps = 3; a.dv[0] = -1; a.dv[1] = 0; a.dv[2] = 1;
-            a.bias = c->pf("voc.up" + std::to_string(i) + "_b"); a.bias_mode = 1; a.act = ACT_LRELU; a.slope = 0.1f;
-            a.out = X0; a.o_bs = (long)rows_in * u * Cout; a.ldo = u * Cout;
-            a.flops = 2.0 * B * (double)rows_in * Cin * Cout * ku;
-            c->gemm(a);
+            a.X = A; a.x_bs = (long)rows_in * Cin; a.ldx = Cin; a.ldw = Cin;
+            a.M = rows_in; a.K = Cin; a.nbatch = B; a.in_len = len_in; a.out_len = len_in;
+            a.bias_mode = 1; a.act = ACT_LRELU; a.slope = 0.1f;
+            a.o_bs = (long)rows_in * u * Cout; a.ldo = u * Cout;
+            if (dt == DT_BF16 && c->has(up + "_wlo")) {
+                // k = 2u: two 2-tap GEMMs over half the phases each (rows t-1, t / rows t, t+1) instead of one 3-tap GEMM
+                const int hc = (u / 2) * Cout;
+                a.N = hc; a.ntaps = 2; a.w_ts = (long)hc * Cin; a.flops = 2.0 * B * (double)rows_in * Cin * Cout * ku / 2;
+                a.W = c->t(up + "_wlo").dev; a.dv[0] = -1; a.dv[1] = 0;
+                a.bias = c->pf(up + "_b"); a.out = X0;
+                c->gemm(a);
+                a.Wp = nullptr;
+                a.W = c->t(up + "_whi").dev; a.dv[0] = 0; a.dv[1] = 1;
+                a.bias = c->pf(up + "_b") + hc; a.out = (char*)X0 + (size_t)hc * es;
+                c->gemm(a);
+            } else {
+                a.W = c->t(up + "_w").dev; a.w_ts = (long)u * Cout * Cin; a.N = u * Cout;
+                a.ntaps = 3; a.dv[0] = -1; a.dv[1] = 0; a.dv[2] = 1;
+                a.bias = c->pf(up + "_b"); a.out = X0;
+                a.flops = 2.0 * B * (double)rows_in * Cin * Cout * ku;
+                c->gemm(a);
+            }
         }
         const float next_slope = (i == ns - 1) ? 0.01f : 0.1f;          // hifigan.py:126 uses the default slope 0.01
         for (int j = 0; j < nk; j++) {

@@ -275,6 +275,13 @@ def pack_model(modelcfg: dict, tts_sd: dict, hifigan_cfg: dict, hifigan_sd: dict
         assert abs(np.abs(poly).sum() - np.abs(wt).sum()) < 1e-3 * max(1.0, np.abs(wt).sum()), "polyphase taps must cover the kernel"
         bl.add(f"voc.up{i}_w", "w", poly)
         bl.add(f"voc.up{i}_b", "p", np.tile(hsd[f"ups.{i}.bias"], u))
+        if k == 2 * u and u % 2 == 0 and cin >= 256:
+            # k = 2u: phases [0, u/2) only touch rows (t-1, t), phases [u/2, u) only rows (t, t+1) -- two 2-tap GEMMs over
+            # half the output columns each do 2/3 of the 3-tap form's MFMA work (worth it where the GEMM is MFMA-bound)
+            hc = (u // 2) * cout
+            assert not poly[2, :hc].any() and not poly[0, hc:].any()
+            bl.add(f"voc.up{i}_wlo", "w", np.ascontiguousarray(poly[0:2, :hc]))
+            bl.add(f"voc.up{i}_whi", "w", np.ascontiguousarray(poly[1:3, hc:]))
         for j in range(nk):
             p = f"resblocks.{i * nk + j}"
             nd = len(h["resblock_dilation_sizes"][j])
