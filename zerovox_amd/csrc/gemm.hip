@@ -1440,10 +1440,13 @@ static int launch_convslab(GemmArgs a, hipStream_t stream) {
         if (best_cost < 0 || cost < best_cost - 1e-9) { best_cost = cost; best = i; }
     }
     static const int bms[4] = {128, 256, 256, 256};
+    // 1x1 convs (StyleTTS decoder) have no tap reuse of the slab: the wider channel tile halves the re-reads of the input
+    // rows, and 128-row tiles divide the decoder's 896 frames exactly
+    if (a.ntaps == 1 && a.N >= 512) best = 0;
     // 256x128 tiles take their weights through per-wave register rings (see the kernel); ZVX_WRING=1 restores the shared
     // LDS-DMA ring for A/B runs
     static const char* wring = getenv("ZVX_WRING");
-    const bool wreg = !wring && best == 1;
+    const bool wreg = !wring && best <= 1;
     const int ring_slots = wreg ? 0 : (best == 0 ? 4 : 8);
     const int bn = bns[best], bm = bms[best];
     const int ntn = (a.N + bn - 1) / bn;
@@ -1454,7 +1457,7 @@ static int launch_convslab(GemmArgs a, hipStream_t stream) {
     const size_t stage = (size_t)4 * 32 * (tn * 128 + 16);
     if (lds < stage) lds = stage;
     switch (best) {
-        case 0: launch_slab_variant<128, 256, 1, 4, 2, 4>(a, grid, lds, stream); break;
+        case 0: if (wreg) launch_slab_variant<128, 256, 1, 4, 2, 0>(a, grid, lds, stream); else launch_slab_variant<128, 256, 1, 4, 2, 4>(a, grid, lds, stream); break;
         case 1: if (wreg) { switch (epi_mode_of(a)) {
                     case ZVX_EPI(0, 0, 1): launch_slab_variant<256, 128, 2, 2, 2, 0, ZVX_EPI(0, 0, 1)>(a, grid, lds, stream); break;
                     case ZVX_EPI(1, 0, 1): launch_slab_variant<256, 128, 2, 2, 2, 0, ZVX_EPI(1, 0, 1)>(a, grid, lds, stream); break;
