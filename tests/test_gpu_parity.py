@@ -420,3 +420,22 @@ def test_streamed_vocoding_equals_whole_utterance(prec):
             check_f32(got, whole, "streamed wav", tol=1e-5)
     short = np.concatenate(list(zv.vocode_stream(mel, chunk_frames=40, halo=2)))
     assert np.abs(short - whole).max() > 1e-4                              # the halo is what makes it exact
+
+
+@pytest.mark.parametrize("voc", ["v1", "tiny"])
+def test_vocoder_batch_invariance_random_ragged(voc):
+    """Random ragged batches through the vocoder: every utterance's waveform is bit-identical to the one it gets alone
+    (tile walk of the persistent fused kernel, row tiles past an utterance's end, length tables, register-ring slab kernel)."""
+    ctx = ctx_for("styletts", voc, "bf16")
+    rng = np.random.default_rng(77)
+    for trial in range(3):
+        B = int(rng.integers(2, 12))
+        P = rng.integers(1, 41, B).astype(np.int32)
+        mel = np.zeros((B, int(P.max()), 80), np.float32)
+        for b in range(B):
+            mel[b, :P[b]] = rng.standard_normal((P[b], 80)).astype(np.float32)
+        wav = ctx.vocode_mel(mel, P)
+        for b in rng.choice(B, size=min(B, 3), replace=False):
+            alone = ctx.vocode_mel(mel[b:b + 1, :P[b]], P[b:b + 1])
+            assert np.array_equal(wav[b, :P[b] * 256], alone[0, :P[b] * 256]), (trial, int(b), int(P[b]))
+            assert not wav[b, P[b] * 256:].any()
