@@ -41,7 +41,9 @@ enum {
 
 enum {                   /* flags */
     ZVX_DEVICE_OUT = 1,  /* wav (and mel, if given) output pointers are device pointers */
-    ZVX_NO_SYNC = 2      /* do not hipStreamSynchronize before returning (device outputs only) */
+    ZVX_NO_SYNC = 2,     /* do not hipStreamSynchronize before returning (device outputs only) */
+    ZVX_PCM16 = 4        /* wav rows are int16 PCM: (int16)(sample * 32760), truncated like numpy astype (demo.py:29-35,
+                            model.py:44-63); halves the bytes of the multi-GPU waveform gather.  wav_stride stays in samples */
 };
 
 enum {                   /* zvx_stage_times indices (milliseconds, hipEvent-timed on the ctx stream) */
@@ -58,7 +60,9 @@ void       zvx_destroy(zvx_ctx* ctx);
 const char* zvx_last_error(const zvx_ctx* ctx);
 /* "precision" -> 0 bf16 / 1 f32; "hidden", "n_mels", "hop", "device" ... ; -1 if unknown */
 int64_t    zvx_get_int(const zvx_ctx* ctx, const char* key);
-/* "profile" 0/1/2 (0 off, 1 per-stage events, 2 + per-GEMM-launch events) */
+/* "profile" 0/1/2 (0 off, 1 per-stage events, 2 + per-GEMM-launch events); "profile_only" variant id (-1 = all);
+ * "shape_log" 0/1 (one stderr line per timed launch); "max_frames" hard cap on a predicted mel length (default 2^18:
+ * the reference has none, fs2.py:678-681 -- a garbage log-duration must not drive an allocation -> ZVX_E_BUFFER) */
 zvx_status zvx_set_int(zvx_ctx* ctx, const char* key, int64_t value);
 
 /* Speaker encoder: ref_mels [B][Tmax][80] log-mels, lens[B] frames -> out [B][hidden], L2-normalised.
@@ -82,7 +86,8 @@ zvx_status zvx_encode(zvx_ctx* ctx, const int32_t* phoneme, const int32_t* punct
                       const int32_t* T, int B, int Tmax, const float* spk,
                       int32_t* mel_len, float* log_duration, float* pitch, float* energy);
 
-/* Mel decoder on the context's features; mel_out [B][Lstride][n_mels] may be NULL.
+/* Mel decoder on the context's features; mel_out [B][Lstride][n_mels] may be NULL; rows in [mel_len[b], max_b mel_len)
+ * of utterance b are written as zeros.
  * Replaces FS2Decoder.forward (fs2.py:281-315) / StyleTTSDecoder.forward (styletts.py:181-205). */
 zvx_status zvx_decode(zvx_ctx* ctx, float* mel_out, int Lstride, int flags);
 
@@ -92,20 +97,22 @@ zvx_status zvx_decode_features(zvx_ctx* ctx, const float* features, const int32_
 
 /* HiFi-GAN on the context's mel.  pad_to[B]: utterance b is vocoded on max(pad_to[b], mel_len[b]) frames,
  * rows >= mel_len zero (the reference's stateful `_min_mel_len`, model.py:331-335; NULL = no padding);
- * wav row b receives mel_len[b]*hop samples (model.py:347), wav_stride floats between rows.
+ * wav row b receives mel_len[b]*hop samples (model.py:347) followed by ZEROS up to max_b(mel_len[b])*hop -- the bytes
+ * handed back never depend on earlier calls on the context; samples beyond that bound are not touched.  wav_stride
+ * samples between rows; float rows, or int16 rows with ZVX_PCM16.
  * Replaces hifigan.Generator.forward (hifigan.py:114-130). */
-zvx_status zvx_vocode(zvx_ctx* ctx, const int32_t* pad_to, float* wav, int64_t wav_stride, int flags);
+zvx_status zvx_vocode(zvx_ctx* ctx, const int32_t* pad_to, void* wav, int64_t wav_stride, int flags);
 
 /* Stand-alone vocoder: mel [B][Pmax][n_mels], P[B] frames -> wav rows of P[b]*hop samples. */
 zvx_status zvx_vocode_mel(zvx_ctx* ctx, const float* mel, const int32_t* P, int B, int Pmax,
-                          float* wav, int64_t wav_stride, int flags);
+                          void* wav, int64_t wav_stride, int flags);
 
 /* encode + decode + vocode.  mel_out / log_duration may be NULL.  With predicted durations the caller
  * sizes wav for Lmax_cap frames per utterance; ZVX_E_BUFFER if a prediction exceeds it.
  * Replaces ZeroVox.inference_ex (model.py:308-347) over B independent utterances. */
 zvx_status zvx_synthesize(zvx_ctx* ctx, const int32_t* phoneme, const int32_t* puncts, const int32_t* duration,
                           const int32_t* T, int B, int Tmax, const float* spk, const int32_t* pad_to,
-                          int Lmax_cap, float* wav, int64_t wav_stride, int32_t* mel_len,
+                          int Lmax_cap, void* wav, int64_t wav_stride, int32_t* mel_len,
                           float* mel_out, int Lstride, float* log_duration, int flags);
 
 /* Debug/parity taps: copy an intermediate of the last call to host fp32.

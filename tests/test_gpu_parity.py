@@ -439,3 +439,76 @@ def test_vocoder_batch_invariance_random_ragged(voc):
             alone = ctx.vocode_mel(mel[b:b + 1, :P[b]], P[b:b + 1])
             assert np.array_equal(wav[b, :P[b] * 256], alone[0, :P[b] * 256]), (trial, int(b), int(P[b]))
             assert not wav[b, P[b] * 256:].any()
+
+
+@pytest.mark.parametrize("voc", ["v1", "tiny"])
+def test_outputs_do_not_depend_on_context_history(voc):
+    """The bytes handed back never depend on what earlier calls left in the context's reusable device buffers
+    (include/zvx.h: wav row b = mel_len[b]*hop samples, then zeros up to the batch maximum; mel rows >= mel_len[b] zero).
+    A LARGE batch runs first, then a ragged one on the same context, for the stand-alone vocoder and for synthesize()."""
+    ctx = ctx_for("styletts", voc, "bf16")
+    rng = np.random.default_rng(123)
+    big = rng.standard_normal((12, 48, 80)).astype(np.float32)
+    ctx.vocode_mel(big, np.full(12, 48, np.int32))                            # fills the reusable buffers with live samples
+    P = np.array([30, 7, 19, 1], np.int32)
+    mel = np.zeros((4, 30, 80), np.float32)
+    for b in range(4):
+        mel[b, :P[b]] = rng.standard_normal((P[b], 80)).astype(np.float32)
+    wav = ctx.vocode_mel(mel, P)
+    for b in range(4):
+        alone = ctx_for("styletts", voc, "bf16").vocode_mel(mel[b:b + 1, :P[b]], P[b:b + 1])
+        assert np.array_equal(wav[b, :P[b] * 256], alone[0, :P[b] * 256])
+        assert not wav[b, P[b] * 256:].any(), f"utt {b}: stale samples past mel_len*hop"
+    # end-to-end: long utterances first, then a ragged batch; wav AND mel_out tails
+    ph, pu, T, spk, dur = synthetic.batch(6, 24, 300, "uniform")
+    ctx.synthesize(ph, pu, T, spk, dur, np.full(6, 200, np.int32))
+    Ts = np.array([20, 3, 11], np.int32)
+    ph2, pu2, _, spk2, dur2 = synthetic.batch(3, 20, 310, "uniform")
+    for b in range(3):
+        ph2[b, Ts[b]:] = 0; pu2[b, Ts[b]:] = 0; dur2[b, Ts[b]:] = 0
+    out = ctx.synthesize(ph2, pu2, Ts, spk2, dur2, np.full(3, 64, np.int32))
+    for b in range(3):
+        ml = int(out["mel_len"][b])
+        assert ml == int(dur2[b, :Ts[b]].sum())
+        assert not out["wav"][b, ml * 256:].any(), f"utt {b}: stale wav tail"
+        assert not out["mel"][b, ml:].any(), f"utt {b}: stale mel rows"
+        solo = ctx.synthesize(ph2[b:b + 1, :Ts[b]], pu2[b:b + 1, :Ts[b]], Ts[b:b + 1], spk2[b:b + 1], dur2[b:b + 1, :Ts[b]], np.array([64], np.int32))
+        assert np.array_equal(solo["wav"][0, :ml * 256], out["wav"][b, :ml * 256])
+        assert np.array_equal(solo["mel"][0, :ml], out["mel"][b, :ml])
+    # staged API after a bigger call: zvx_decode's mel_out tail
+    mel_len, _, _, _ = ctx.encode(ph2, pu2, Ts, spk2, dur2)
+    m = ctx.decode(3, int(mel_len.max()))
+    for b in range(3):
+        assert not m[b, int(mel_len[b]):].any()
+
+
+@pytest.mark.parametrize("prec", ["f32", "bf16"])
+def test_pcm16_output_equals_scaled_float_output(prec):
+    """ZVX_PCM16: the int16 row is (float_sample * 32760).astype(int16) of the float row, bit for bit (demo.py:29-35)."""
+    ctx = ctx_for("styletts", "tiny", prec)
+    rng = np.random.default_rng(9)
+    P = np.array([17, 5], np.int32)
+    mel = np.zeros((2, 17, 80), np.float32)
+    for b in range(2):
+        mel[b, :P[b]] = 2.0 * rng.standard_normal((P[b], 80)).astype(np.float32)
+    f = ctx.vocode_mel(mel, P)
+    i = ctx.vocode_mel(mel, P, pcm16=True)
+    assert i.dtype == np.int16 and i.shape == f.shape
+    assert np.array_equal(i, (f * np.float32(32760)).astype(np.int16))
+    assert np.abs(i).max() > 100
+
+
+def test_unfusable_resblock_shapes_fall_back_to_two_launches():
+    """A HiFi-GAN config.json the reference accepts but the fused ResBlock kernels do not cover (dilation 9 with k = 11:
+    conv1 halo 45 > the fused kernels' 32 rows; k = 5) must still run -- through the two-launch path -- and match the oracle."""
+    h = {"resblock": "1", "upsample_rates": [8, 8, 2, 2], "upsample_kernel_sizes": [16, 16, 4, 4],
+         "upsample_initial_channel": 128, "resblock_kernel_sizes": [5, 11], "resblock_dilation_sizes": [[1, 2], [1, 9]]}
+    hsd = zw.hifigan_state_dict(h, 2)
+    cfg, sd = tts_sd("styletts")
+    man, blob = pack.pack_model(cfg, sd, h, hsd, "bf16")
+    ctx = _lib.Context(man, blob, 0)
+    rng = np.random.default_rng(4)
+    mel = rng.standard_normal((1, 14, 80)).astype(np.float32)
+    wav = ctx.vocode_mel(mel, np.array([14], np.int32))
+    check_wav(wav[0], O.hifigan_generator(mel[0].T, hsd, h), "bf16", "unfused shapes", e2e=False)
+    ctx.close()

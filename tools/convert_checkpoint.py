@@ -6,7 +6,9 @@
 
 * TTS: a Lightning checkpoint (`state_dict` / `hyper_parameters`, layouts in utils/dump_pkl.py:8-30) is read with
   torch.load; `_meldec.*` keys (a vocoder baked into the checkpoint, utils/edit_meldec_in_checkpoint.py:77-90) are
-  split off; every tensor is written to `<out_dir>/weights.npz` under its reference key; modelcfg.yaml is copied.
+  split off into `<out_dir>/generator.npz` -- zerovox_amd.model.load_meldec_weights PREFERS that file over the external
+  vocoder's weights, as `ZeroVox.load_from_checkpoint(strict=False)` does (the external model then only supplies
+  config.json); every other tensor is written to `<out_dir>/weights.npz` under its reference key; modelcfg.yaml is copied.
   The pickled `hyper_parameters` reference `zerovox.tts.symbols.Symbols`; a stand-in class is registered so that
   unpickling works without the reference package.
 * HiFi-GAN: `generator.ckpt['generator']` (weight-norm parametrised, model.py:111) -> `generator.npz`, config.json copied.
@@ -36,13 +38,27 @@ def _install_symbols_stub():
     sys.modules.update({"zerovox": pkg, "zerovox.tts": tts, "zerovox.tts.symbols": sym})
 
 
+def _safe_load(path):
+    """torch.load restricted to tensors/containers (weights_only=True): a downloaded checkpoint must not be able to run
+    code.  The only non-tensor class a ZeroVOX Lightning checkpoint pickles is `Symbols` (hyper_parameters); the stand-in
+    is allow-listed explicitly."""
+    import torch
+    _install_symbols_stub()
+    sym = sys.modules["zerovox.tts.symbols"].Symbols
+    if hasattr(torch.serialization, "safe_globals"):
+        with torch.serialization.safe_globals([sym]):
+            return torch.load(path, map_location="cpu", weights_only=True)
+    torch.serialization.add_safe_globals([sym])
+    return torch.load(path, map_location="cpu", weights_only=True)
+
+
 def convert_tts(src, modelcfg, out_dir):
     import torch
     _install_symbols_stub()
     if os.path.isdir(src):               # synthesize.py:295-299: newest checkpoints/*.ckpt
         files = glob.glob(os.path.join(src, "checkpoints", "*.ckpt"))
         src = max(files, key=os.path.getctime)
-    ck = torch.load(src, map_location="cpu", weights_only=False)
+    ck = _safe_load(src)
     sd = ck.get("state_dict", ck.get("model", ck))
     tts, voc = {}, {}
     for k, v in sd.items():
@@ -58,7 +74,7 @@ def convert_tts(src, modelcfg, out_dir):
 
 def convert_vocoder(gen_ckpt, config_json, out_dir):
     import torch
-    ck = torch.load(gen_ckpt, map_location="cpu", weights_only=False)
+    ck = _safe_load(gen_ckpt)
     sd = ck["generator"] if "generator" in ck else ck
     os.makedirs(out_dir, exist_ok=True)
     np.savez(os.path.join(out_dir, "generator.npz"), **{k: v.detach().cpu().numpy() for k, v in sd.items()})

@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(HERE, "libzvx.so")
 
 ZVX_OK = 0
 ZVX_E_INVALID, ZVX_E_MANIFEST, ZVX_E_HIP, ZVX_E_STATE, ZVX_E_BUFFER, ZVX_E_UNSUPPORTED = 1, 2, 3, 4, 5, 6
-ZVX_DEVICE_OUT, ZVX_NO_SYNC = 1, 2
+ZVX_DEVICE_OUT, ZVX_NO_SYNC, ZVX_PCM16 = 1, 2, 4
 STAGES = ("encoder", "variance", "lenreg", "decoder", "vocoder", "spkemb")
 ZVX_T_COUNT = 8
 
@@ -163,7 +163,7 @@ class Context:
         return mel_len, logd, pitch, energy
 
     def decode(self, B, Lmax):
-        mel = np.zeros((B, max(Lmax, 1), self.n_mels), np.float32)
+        mel = np.empty((B, max(Lmax, 1), self.n_mels), np.float32) if Lmax > 0 else np.zeros((B, 1, self.n_mels), np.float32)
         self._chk(self._lib.zvx_decode(self._h, _ptr(mel), max(Lmax, 1), 0))
         return mel
 
@@ -173,29 +173,33 @@ class Context:
         assert H == self.hidden
         L = _i32(L, (B,))
         spk = _f32(spk).reshape(B, H)
-        mel = np.zeros((B, Lmax, self.n_mels), np.float32)
+        mel = np.empty((B, Lmax, self.n_mels), np.float32)
         self._chk(self._lib.zvx_decode_features(self._h, _ptr(features), _ptr(L), B, Lmax, _ptr(spk), _ptr(mel), Lmax))
         return mel
 
-    def vocode(self, B, mel_len, pad_to=None):
+    def vocode(self, B, mel_len, pad_to=None, pcm16=False):
+        """wav [B][max(mel_len)*hop]: float32, or int16 PCM (x32760, truncated) with pcm16.  The array is created with
+        np.empty on purpose: the library owns every byte it hands back (valid samples, then zeros)."""
         n = max(int(np.max(mel_len)) * self.hop, 1)
-        wav = np.zeros((B, n), np.float32)
+        wav = np.empty((B, n), np.int16 if pcm16 else np.float32)
         pt = _i32(pad_to, (B,)) if pad_to is not None else None
-        self._chk(self._lib.zvx_vocode(self._h, _ptr(pt), _ptr(wav), n, 0))
+        self._chk(self._lib.zvx_vocode(self._h, _ptr(pt), _ptr(wav), n, ZVX_PCM16 if pcm16 else 0))
         return wav
 
-    def vocode_mel(self, mel, P):
+    def vocode_mel(self, mel, P, pcm16=False):
         mel = _f32(mel)
         B, Pmax, nm = mel.shape
         assert nm == self.n_mels
         P = _i32(P, (B,))
-        n = Pmax * self.hop
-        wav = np.zeros((B, n), np.float32)
-        self._chk(self._lib.zvx_vocode_mel(self._h, _ptr(mel), _ptr(P), B, Pmax, _ptr(wav), n, 0))
+        n = int(P.max()) * self.hop
+        wav = np.empty((B, n), np.int16 if pcm16 else np.float32)
+        self._chk(self._lib.zvx_vocode_mel(self._h, _ptr(mel), _ptr(P), B, Pmax, _ptr(wav), n, ZVX_PCM16 if pcm16 else 0))
+        if n < Pmax * self.hop:                                      # callers index rows up to Pmax*hop
+            wav = np.concatenate([wav, np.zeros((B, Pmax * self.hop - n), wav.dtype)], axis=1)
         return wav
 
     def synthesize(self, phoneme, puncts, T, spk, duration=None, pad_to=None, want_mel=True, Lmax_cap=0,
-                   wav_device_ptr=None, wav_stride=None, no_sync=False):
+                   wav_device_ptr=None, wav_stride=None, no_sync=False, pcm16=False):
         """Batched phoneme -> waveform.  Returns dict(wav [B][N] (None if device output), mel_len, mel, log_duration)."""
         phoneme = _i32(phoneme)
         B, Tmax = phoneme.shape
@@ -213,13 +217,13 @@ class Context:
         mel_len = np.zeros(B, np.int32)
         logd = np.zeros((B, Tmax), np.float32)
         mel = np.zeros((B, max(Lmax, 1), self.n_mels), np.float32) if want_mel else None
-        flags = 0
+        flags = ZVX_PCM16 if pcm16 else 0
         if wav_device_ptr is not None:
             wav, wptr, stride = None, C.c_void_p(int(wav_device_ptr)), int(wav_stride)
             flags |= ZVX_DEVICE_OUT | (ZVX_NO_SYNC if no_sync else 0)
         else:
             stride = max(Lmax * self.hop, 1)
-            wav = np.zeros((B, stride), np.float32)
+            wav = np.zeros((B, stride), np.int16 if pcm16 else np.float32)
             wptr = _ptr(wav)
         self._chk(self._lib.zvx_synthesize(self._h, _ptr(phoneme), _ptr(puncts), _ptr(dur), _ptr(T), B, Tmax, _ptr(spk),
                                            _ptr(pt), Lmax, wptr, stride, _ptr(mel_len), _ptr(mel), max(Lmax, 1),

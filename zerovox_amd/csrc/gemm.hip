@@ -1369,8 +1369,7 @@ int launch_resfuse(GemmArgs a, hipStream_t stream) {
     if (h1 > 32) return -1;
     a.halo_l = a.halo_r = h1;
     a.fused = 1;
-    static const char* v1 = getenv("ZVX_RESFUSE_V1");
-    if (!v1) {
+    {
         if (a.N == 32 && launch_resfuse_persist_c<32>(a, stream)) return 16;
         if (a.N == 64 && a.ntaps != 11 && launch_resfuse_persist_c<64>(a, stream)) return 17;
         // C = 64, k = 11 (44 fragments = 176 registers per wave): one 32-row block per wave, 36 fragments resident and 8
@@ -1426,8 +1425,7 @@ static int launch_convslab(GemmArgs a, hipStream_t stream) {
     int hl = 0, hr = 0;
     for (int i = 0; i < a.ntaps; i++) { hl = a.dv[i] < -hl ? -a.dv[i] : hl; hr = a.dv[i] > hr ? a.dv[i] : hr; }
     a.halo_l = hl; a.halo_r = hr;
-    static const char* noreg = getenv("ZVX_NO_CONVREG");
-    if (!noreg && a.N == a.K && (a.ntaps == 3 || a.ntaps == 7 || a.ntaps == 11)) {
+    if (a.N == a.K && (a.ntaps == 3 || a.ntaps == 7 || a.ntaps == 11)) {
         if (a.N == 32 && launch_convreg_c<32, 512, 4, 1, 2>(a, stream)) return 14;
         if (a.N == 64 && launch_convreg_c<64, 256, 2, 2, 2>(a, stream)) return 15;
     }
@@ -1443,10 +1441,8 @@ static int launch_convslab(GemmArgs a, hipStream_t stream) {
     // 1x1 convs (StyleTTS decoder) have no tap reuse of the slab: the wider channel tile halves the re-reads of the input
     // rows, and 128-row tiles divide the decoder's 896 frames exactly
     if (a.ntaps == 1 && a.N >= 512) best = 0;
-    // 256x128 tiles take their weights through per-wave register rings (see the kernel); ZVX_WRING=1 restores the shared
-    // LDS-DMA ring for A/B runs
-    static const char* wring = getenv("ZVX_WRING");
-    const bool wreg = !wring && best <= 1;
+    // 256x128 / 128x256 tiles take their weights through per-wave register rings (see the kernel)
+    const bool wreg = best <= 1;
     const int ring_slots = wreg ? 0 : (best == 0 ? 4 : 8);
     const int bn = bns[best], bm = bms[best];
     const int ntn = (a.N + bn - 1) / bn;

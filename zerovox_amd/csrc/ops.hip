@@ -158,22 +158,23 @@ void launch_bucket_embed_add(const float* pred, const float* table, int nbins, f
 __global__ void k_durations(const int* forced, const float* logd, int* dur, int* cum, int* mel_len, int Tmax, const int* T) {
     const int b = blockIdx.x, lane = threadIdx.x;
     const int n = T[b];
-    int carry = 0;
+    long long carry = 0;                                        // 64-bit: the sum saturates instead of wrapping
     for (int t0 = 0; t0 < n; t0 += 64) {
         const int t = t0 + lane;
         int d = 0;
         if (t < n) {
-            if (forced) d = max(forced[b * Tmax + t], 0);                                  // fs2.py:452 max(int(d),0)
-            else d = (int)fmaxf(rintf(expf(logd[b * Tmax + t]) - 1.0f), 0.f);               // fs2.py:678-681
+            if (forced) d = min(max(forced[b * Tmax + t], 0), 65536);                     // fs2.py:452 max(int(d),0)
+            else d = (int)fminf(fmaxf(rintf(expf(logd[b * Tmax + t]) - 1.0f), 0.f), 65536.f);   // fs2.py:678-681; NaN -> 0; the upper
+                                                                     // clamp only keeps the int conversion and the prefix sum defined
             dur[b * Tmax + t] = d;
         }
         int v = d;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) { int u = __shfl_up(v, o, 64); if (lane >= o) v += u; }
-        if (t < n) cum[b * Tmax + t] = carry + v;
+        if (t < n) cum[b * Tmax + t] = (int)min(carry + v, 0x7fffffffLL);
         carry += __shfl(v, 63, 64);
     }
-    if (lane == 0) mel_len[b] = carry;
+    if (lane == 0) mel_len[b] = (int)min(carry, 0x7fffffffLL);
 }
 void launch_durations(const int* forced, const float* logd, int* dur, int* cum, int* mel_len, int B, int Tmax,
                       const int* T, hipStream_t s) {
@@ -391,13 +392,27 @@ void launch_copy_rows_f32(const void* src, int s_dt, int lds, long s_bs, float* 
     hipLaunchKernelGGL(k_copy_rows_f32, dim3(rows_max, B), dim3(128), 0, s, src, s_dt, lds, s_bs, dst, ldd, d_bs, rows_max, rows, C);
 }
 
+// rows [rows[b], rows_max) of x [b][rows_max][ldx] (first C columns) := 0 -- outputs handed to the caller never carry
+// what an earlier, longer call left in the reused buffer
+__global__ void k_zero_tail_rows(float* x, int ldx, int rows_max, const int* rows, int C) {
+    const int b = blockIdx.y, r = blockIdx.x;
+    if (r < rows[b]) return;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) x[((long)b * rows_max + r) * ldx + c] = 0.f;
+}
+void launch_zero_tail_rows(float* x, int ldx, int B, int rows_max, const int* rows, int C, hipStream_t s) {
+    if (rows_max <= 0) return;
+    hipLaunchKernelGGL(k_zero_tail_rows, dim3(rows_max, B), dim3(128), 0, s, x, ldx, rows_max, rows, C);
+}
+
 // ---------------------------------------------------------------- conv_post (C -> 1) + tanh      hifigan.py:127-128
 // x is the activated last stage [b][Nmax][ldx]; one thread per output sample, weights broadcast from LDS.
 // conv_post (C -> 1, k taps) + tanh: a block of 256 samples stages its (256 + k - 1) input rows in LDS once (coalesced
 // 16-byte loads, padded pitch) instead of every thread pulling its k rows through L1; the accumulation order per sample
 // is unchanged (tap-major, then channel groups), so results are bit-identical to the direct form.
+// Samples in [out_len*out_mul, Nmax) of every row are written as zeros, so the caller's row never depends on what an
+// earlier call left in a reused buffer.  pcm16: the row is int16 PCM, (short)trunc(tanh(.) * 32760) (demo.py:29-35).
 __global__ __launch_bounds__(256) void k_conv_post_tanh(const void* x, int xdt, int ldx, long x_bs, const float* w, float bias, int kt, int C,
-                                 float* wav, long wav_bs, const int* in_len, int len_mul, const int* out_len, int out_mul) {
+                                 void* wav, long wav_bs, int Nmax, int pcm16, const int* in_len, int len_mul, const int* out_len, int out_mul) {
     extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
     const int es = xdt == DT_BF16 ? 2 : 4, rowb = C * es, pitch = rowb + 16, half = (kt - 1) / 2, nrows = 256 + kt - 1;
     float* wl = (float*)(sm + (size_t)nrows * pitch);
@@ -405,7 +420,14 @@ __global__ __launch_bounds__(256) void k_conv_post_tanh(const void* x, int xdt, 
     const int b = blockIdx.y;
     const long n0 = (long)blockIdx.x * 256;
     const long nin = (long)in_len[b] * len_mul, nout = (long)out_len[b] * out_mul;
-    if (n0 >= nout) return;
+    auto put = [&](long n, float v) {
+        if (pcm16) ((short*)wav)[b * wav_bs + n] = (short)(v * 32760.0f);      // float -> int conversion truncates (numpy astype)
+        else ((float*)wav)[b * wav_bs + n] = v;
+    };
+    if (n0 >= nout) {                                        // whole block past the utterance's end: zero tail
+        if (n0 + threadIdx.x < Nmax) put(n0 + threadIdx.x, 0.f);
+        return;
+    }
     const int cpr = rowb >> 4;                               // 16-byte chunks per row
     for (int i = threadIdx.x; i < nrows * cpr; i += 256) {
         const int r = i / cpr, q = i % cpr;
@@ -416,7 +438,7 @@ __global__ __launch_bounds__(256) void k_conv_post_tanh(const void* x, int xdt, 
     }
     __syncthreads();
     const long n = n0 + threadIdx.x;
-    if (n >= nout) return;
+    if (n >= nout) { if (n < Nmax) put(n, 0.f); return; }
     float acc = bias;
     for (int k = 0; k < kt; k++) {
         const long m = n + k - half;
@@ -439,16 +461,16 @@ __global__ __launch_bounds__(256) void k_conv_post_tanh(const void* x, int xdt, 
             }
         }
     }
-    wav[b * wav_bs + n] = tanhf(acc);
+    put(n, tanhf(acc));
 }
 void launch_conv_post_tanh(const void* x, int x_dt, int ldx, long x_bs, const float* w, float bias,
-                           int ktaps, int C, float* wav, long wav_bs, int B, int Nmax, const int* in_len,
+                           int ktaps, int C, void* wav, long wav_bs, int pcm16, int B, int Nmax, const int* in_len,
                            int len_mul, const int* out_len, int out_mul, hipStream_t s) {
     if (Nmax <= 0) return;
     const size_t es = x_dt == DT_BF16 ? 2 : 4;
     const size_t lds = (size_t)(256 + ktaps - 1) * (C * es + 16) + (size_t)ktaps * C * sizeof(float);
     hipLaunchKernelGGL(k_conv_post_tanh, dim3((Nmax + 255) / 256, B), dim3(256), lds, s, x, x_dt, ldx, x_bs, w,
-                       bias, ktaps, C, wav, wav_bs, in_len, len_mul, out_len, out_mul);
+                       bias, ktaps, C, wav, wav_bs, Nmax, pcm16, in_len, len_mul, out_len, out_mul);
 }
 
 // ---------------------------------------------------------------- speaker encoder pieces

@@ -75,6 +75,8 @@ struct zvx_ctx {
     // profiling
     int profile = 0;
     int profile_only = -1;                 // >= 0: per-launch events only for this kernel variant (keeps the timed region lean)
+    int shape_log = 0;                     // zvx_set_int("shape_log", 1): one stderr line per timed launch (profile 2)
+    int max_frames = 1 << 18;              // hard cap on a predicted mel length (guards the allocation, fs2.py:678-681 has none)
     hipEvent_t stage_ev[ZVX_T_COUNT][2];
     bool stage_used[ZVX_T_COUNT];
     float stage_ms[ZVX_T_COUNT];
@@ -158,7 +160,6 @@ struct zvx_ctx {
         for (auto& e : pending) {
             float ms = 0.f;
             HIPCHK(hipEventElapsedTime(&ms, e.a, e.b));
-            static const char* shape_log = getenv("ZVX_SHAPE_LOG");      // dev aid: one stderr line per launch
             if (shape_log) fprintf(stderr, "launch %-24s rows=%-8ld N=%-4d K=%-4d taps=%-2d res=%d fused=%d  %8.3f ms %8.1f TF/s %8.1f GB/s(alg)\n",
                                    gemm_variant_name(e.variant), e.rows, e.N, e.K, e.taps, e.res, e.fused, ms, e.flops / ms / 1e9, e.bytes / ms / 1e6);
             auto& s = stats[e.variant];
@@ -418,7 +419,7 @@ void variance_predictor(zvx_ctx* c, const char* nm, const float* x, int B, int T
 }
 
 void run_encode(zvx_ctx* c, const int32_t* phoneme, const int32_t* puncts, const int32_t* duration, const int32_t* T,
-                int B, int Tmax, const float* spk) {
+                int B, int Tmax, const float* spk, int32_t* mel_len_out, int Lmax_cap) {
     const int H = c->H;
     c->have_features = false; c->have_mel = false;
     if (B <= 0 || Tmax <= 0) fail(ZVX_E_INVALID, "B and Tmax must be positive");
@@ -484,7 +485,11 @@ void run_encode(zvx_ctx* c, const int32_t* phoneme, const int32_t* puncts, const
     c->mel_len_host.resize(B);
     HIPCHK(hipMemcpyAsync(c->mel_len_host.data(), ml, B * sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));            // the one data-dependent host sync (model.py:325)
+    if (mel_len_out) memcpy(mel_len_out, c->mel_len_host.data(), B * sizeof(int));
     int Lmax = 0; for (int b = 0; b < B; b++) Lmax = std::max(Lmax, c->mel_len_host[b]);
+    // checked BEFORE anything is sized by it: a garbage log-duration must not drive an allocation
+    const int cap = Lmax_cap > 0 ? std::min(Lmax_cap, c->max_frames) : c->max_frames;
+    if (Lmax > cap) fail(ZVX_E_BUFFER, "predicted mel length %d exceeds %s %d", Lmax, Lmax_cap > 0 && Lmax_cap <= c->max_frames ? "Lmax_cap" : "the context's max_frames", cap);
     c->Lmax = Lmax;
     if (Lmax > 0) {
         float* feats = c->fbuf("features", (size_t)B * Lmax * H);
@@ -635,6 +640,7 @@ void run_decode(zvx_ctx* c, const float* feats, const float* spk_d, const int* L
     if (Lmax > 0) {
         if (c->dec_kind == 0) decoder_fs2(c, feats, spk_d, L_d, B, Lmax, mel);
         else decoder_styletts(c, feats, spk_d, L_d, B, Lmax, mel);
+        launch_zero_tail_rows(mel, c->n_mels, B, Lmax, L_d, c->n_mels, c->stream);     // rows >= mel_len[b]: zeros, whatever ran before
     }
     c->stage_end(ZVX_T_DECODER);
     c->have_mel = true;
@@ -646,7 +652,7 @@ void run_decode(zvx_ctx* c, const float* feats, const float* spk_d, const int* L
 // residual is recovered exactly-enough by the inverse map in the consumer's epilogue (res_mode 2).
 // ------------------------------------------------------------------------------------------------
 void run_vocoder(zvx_ctx* c, const float* mel, int ldm, int Lmel_max, const int* mel_len_host, const int* P_host, int B,
-                 float* wav_dev, long wav_stride) {
+                 void* wav_dev, long wav_stride, int pcm16) {
     const int dt = c->dt, nm = c->n_mels;
     const size_t es = c->es();
     int Pmax = 0; for (int b = 0; b < B; b++) Pmax = std::max(Pmax, P_host[b]);
@@ -722,72 +728,81 @@ void run_vocoder(zvx_ctx* c, const float* mel, int ldm, int Lmel_max, const int*
             for (int t = 0; t < nd; t++) {
                 const bool last = (t == nd - 1);
                 const void* cin_buf = cur;
-                GemmArgs a = gemm_base(dt);
-                a.M = rows; a.N = Cout; a.K = Cout; a.nbatch = B; a.in_len = len; a.out_len = len; a.ldw = Cout; a.w_ts = (long)Cout * Cout;
-                a.x_bs = (long)rows * Cout; a.ldx = Cout; a.o_bs = (long)rows * Cout; a.ldo = Cout;
-                bool fuse = false;
+                auto rb_base = [&] {
+                    GemmArgs a = gemm_base(dt);
+                    a.M = rows; a.N = Cout; a.K = Cout; a.nbatch = B; a.in_len = len; a.out_len = len; a.ldw = Cout; a.w_ts = (long)Cout * Cout;
+                    a.x_bs = (long)rows * Cout; a.ldx = Cout; a.o_bs = (long)rows * Cout; a.ldo = Cout;
+                    return a;
+                };
+                // what the LAST conv of the iteration does with its result: + bias + x (raw residual recovered from the activated
+                // input), then either the next iteration's input (activated) or the stage's running sum / mean
+                int pp_next = pp;
+                auto rb_tail = [&](GemmArgs& a) {
+                    a.bias_mode = 1;
+                    a.res = cin_buf; a.r_bs = (long)rows * Cout; a.ldr = Cout; a.res_mode = 2; a.res_inv_slope = 10.0f; a.res_dtype = dt;
+                    if (!last) {
+                        a.act = ACT_LRELU; a.slope = 0.1f; a.out = PP[pp];
+                        pp_next = pp ^ 1;
+                    } else {
+                        // xs (+)= resblock output; last kernel size: x = xs / num_kernels, stored activated for the next stage
+                        a.accum = XS; a.accum_dtype = dt; a.a_bs = (long)rows * Cout; a.lda = Cout;
+                        if (nk == 1) { a.accum_mode = 0; a.accum = nullptr; }
+                        else if (j == 0) a.accum_mode = 2;
+                        else if (j < nk - 1) a.accum_mode = 3;
+                        else a.accum_mode = 1;
+                        if (j == nk - 1) { a.out = A; a.out_scale = 1.0f / nk; a.act = ACT_LRELU; a.slope = next_slope; }
+                        else a.out = nullptr;
+                    }
+                };
+                GemmArgs a = rb_base();
                 if (c->voc_resblock == 1) {
-                    const Tensor& w1 = c->t(rb + ".c1_" + std::to_string(t) + "_w");
-                    const Tensor& w2 = c->t(rb + ".c2_" + std::to_string(t) + "_w");
-                    static const char* nofuse = getenv("ZVX_NO_RESFUSE");
-                    fuse = !nofuse && dt == DT_BF16 && (Cout == 8 || Cout == 16 || Cout == 32 || Cout == 64 || (Cout == 128 && k == 3)) && (k == 3 || k == 7 || k == 11) && dil[t] * (k - 1) / 2 <= 32 &&
-                           c->packed.count(w1.dev) && c->packed.count(w2.dev);
+                    const std::string ts = std::to_string(t);
+                    const Tensor& w1 = c->t(rb + ".c1_" + ts + "_w");
+                    const Tensor& w2 = c->t(rb + ".c2_" + ts + "_w");
+                    bool fuse = dt == DT_BF16 && c->packed.count(w1.dev) && c->packed.count(w2.dev);
                     if (fuse) {
                         // one launch: xt = lrelu(c1(x_act)+b1) stays in LDS; x' = c2(xt) + b2 + x      hifigan.py:51-55
                         a.X = cur; a.W = w2.dev; a.Wp = c->packed[w2.dev]; a.Wp2 = c->packed[w1.dev];
-                        a.bias1 = c->pf(rb + ".c1_" + std::to_string(t) + "_b"); a.slope1 = 0.1f; a.fused = 1;
+                        a.bias1 = c->pf(rb + ".c1_" + ts + "_b"); a.slope1 = 0.1f; a.fused = 1;
                         set_taps_1d(a, k, 1);
-                        for (int i = 0; i < k; i++) a.dv1[i] = (i - (k - 1) / 2) * dil[t];
-                        a.bias = c->pf(rb + ".c2_" + std::to_string(t) + "_b");
+                        for (int q = 0; q < k; q++) a.dv1[q] = (q - (k - 1) / 2) * dil[t];
+                        a.bias = c->pf(rb + ".c2_" + ts + "_b");
                         a.flops = 2.0 * 2.0 * B * (double)rows * Cout * Cout * k;
-                    } else {
-                    // xt = c1(lrelu(x)); stored as lrelu(xt)                       hifigan.py:51-53
-                    a.X = cur; a.W = w1.dev;
-                    set_taps_1d(a, k, dil[t]);
-                    a.bias = c->pf(rb + ".c1_" + std::to_string(t) + "_b"); a.bias_mode = 1; a.act = ACT_LRELU; a.slope = 0.1f;
-                    a.out = T1;
-                    c->gemm(a);
-                    // x = c2(.) + x                                                hifigan.py:54-55
-                    a = gemm_base(dt);
-                    a.M = rows; a.N = Cout; a.K = Cout; a.nbatch = B; a.in_len = len; a.out_len = len; a.ldw = Cout; a.w_ts = (long)Cout * Cout;
-                    a.x_bs = (long)rows * Cout; a.ldx = Cout; a.o_bs = (long)rows * Cout; a.ldo = Cout;
-                    a.X = T1; a.W = w2.dev;
-                    set_taps_1d(a, k, 1);
-                    a.bias = c->pf(rb + ".c2_" + std::to_string(t) + "_b");
+                        rb_tail(a);
+                        // the fused kernels cover a subset of (C, k, dilation, LDS footprint): ask the launcher (dry run) first
+                        fuse = gemm_variant_of(a) >= 0;
+                    }
+                    if (!fuse) {
+                        // xt = c1(lrelu(x)); stored as lrelu(xt)                       hifigan.py:51-53
+                        a = rb_base();
+                        a.X = cur; a.W = w1.dev;
+                        set_taps_1d(a, k, dil[t]);
+                        a.bias = c->pf(rb + ".c1_" + ts + "_b"); a.bias_mode = 1; a.act = ACT_LRELU; a.slope = 0.1f;
+                        a.out = T1;
+                        c->gemm(a);
+                        // x = c2(.) + x                                                hifigan.py:54-55
+                        a = rb_base();
+                        a.X = T1; a.W = w2.dev;
+                        set_taps_1d(a, k, 1);
+                        a.bias = c->pf(rb + ".c2_" + ts + "_b");
+                        rb_tail(a);
                     }
                 } else {
                     // x = c(lrelu(x)) + x                                          hifigan.py:78-81
                     a.X = cur; a.W = c->t(rb + ".c_" + std::to_string(t) + "_w").dev;
                     set_taps_1d(a, k, dil[t]);
                     a.bias = c->pf(rb + ".c_" + std::to_string(t) + "_b");
+                    rb_tail(a);
                 }
-                a.bias_mode = 1;
-                a.res = cin_buf; a.r_bs = (long)rows * Cout; a.ldr = Cout; a.res_mode = 2; a.res_inv_slope = 10.0f; a.res_dtype = dt;
-                if (!last) {
-                    a.act = ACT_LRELU; a.slope = 0.1f; a.out = PP[pp];
-                    c->gemm(a);
-                    cur = PP[pp]; pp ^= 1;
-                } else {
-                    // xs (+)= resblock output; last kernel size: x = xs / num_kernels, stored activated for the next stage
-                    a.accum = XS; a.accum_dtype = dt; a.a_bs = (long)rows * Cout; a.lda = Cout;
-                    if (nk == 1) { a.accum_mode = 0; a.accum = nullptr; }
-                    else if (j == 0) a.accum_mode = 2;
-                    else if (j < nk - 1) a.accum_mode = 3;
-                    else a.accum_mode = 1;
-                    if (j == nk - 1) {
-                        a.out = A; a.out_scale = 1.0f / nk; a.act = ACT_LRELU; a.slope = next_slope;
-                    } else {
-                        a.out = nullptr;
-                    }
-                    c->gemm(a);
-                }
+                c->gemm(a);
+                if (!last) { cur = PP[pp]; pp = pp_next; }
             }
         }
         Cin = Cout; mul *= u;
     }
     // conv_post + tanh on the first mel_len*hop samples            hifigan.py:127-128, model.py:347
     launch_conv_post_tanh(A, dt, Cin, (long)Pmax * mul * Cin, c->pf("voc.post_w"), c->t("voc.post_b").host[0], c->t("voc.post_w").dim(0),
-                          Cin, wav_dev, wav_stride, B, Lmel_max * c->hop, P_d, c->hop, mel_len_d, c->hop, c->stream);
+                          Cin, wav_dev, wav_stride, pcm16, B, Lmel_max * c->hop, P_d, c->hop, mel_len_d, c->hop, c->stream);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -960,7 +975,9 @@ void run_melspec(zvx_ctx* c, const float* wav, const int32_t* nsamples, int B, i
     c->sync();
 }
 
-void do_vocode(zvx_ctx* c, const int32_t* pad_to, float* wav, int64_t wav_stride, int flags) {
+// wav: float rows, or int16 PCM rows with ZVX_PCM16 (stride counted in samples either way).  Row b receives
+// mel_len[b]*hop samples followed by zeros up to max_b(mel_len[b])*hop; nothing beyond that is touched.
+void do_vocode(zvx_ctx* c, const int32_t* pad_to, void* wav, int64_t wav_stride, int flags) {
     if (!c->have_mel) fail(ZVX_E_STATE, "zvx_vocode: no mel in the context (call zvx_decode first)");
     const int B = c->B;
     std::vector<int> P(B);
@@ -968,14 +985,16 @@ void do_vocode(zvx_ctx* c, const int32_t* pad_to, float* wav, int64_t wav_stride
     for (int b = 0; b < B; b++) { P[b] = std::max(pad_to ? pad_to[b] : 0, c->mel_len_host[b]); need = std::max(need, c->mel_len_host[b] * c->hop); }
     if (wav_stride < need) fail(ZVX_E_BUFFER, "wav_stride %lld < %d samples", (long long)wav_stride, need);
     c->stage_begin(ZVX_T_VOCODER);
-    float* wdev; long wstride;
+    void* wdev; long wstride;
     const bool dev_out = flags & ZVX_DEVICE_OUT;
+    const int pcm16 = (flags & ZVX_PCM16) ? 1 : 0;
+    const size_t ss = pcm16 ? 2 : 4;
     if (dev_out) { wdev = wav; wstride = wav_stride; }
-    else { wstride = std::max(need, 1); wdev = c->fbuf("wav", (size_t)B * wstride); }
-    run_vocoder(c, c->fbuf("mel", 0), c->n_mels, c->Lmax, c->mel_len_host.data(), P.data(), B, wdev, wstride);
+    else { wstride = (std::max(need, 1) + 7) & ~7; wdev = c->buf("wav", (size_t)B * wstride * ss); }
+    run_vocoder(c, c->fbuf("mel", 0), c->n_mels, c->Lmax, c->mel_len_host.data(), P.data(), B, wdev, wstride, pcm16);
     c->stage_end(ZVX_T_VOCODER);
     if (!dev_out && need > 0)
-        HIPCHK(hipMemcpy2DAsync(wav, (size_t)wav_stride * 4, wdev, (size_t)wstride * 4, (size_t)need * 4, B, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipMemcpy2DAsync(wav, (size_t)wav_stride * ss, wdev, (size_t)wstride * ss, (size_t)need * ss, B, hipMemcpyDeviceToHost, c->stream));
     if (!(dev_out && (flags & ZVX_NO_SYNC))) c->sync();
 }
 
@@ -1069,6 +1088,8 @@ zvx_status zvx_set_int(zvx_ctx* c, const char* key, int64_t value) {
         if (!key) fail(ZVX_E_INVALID, "key is NULL");
         if (std::string(key) == "profile") { c->sync(); c->profile = (int)value; }
         else if (std::string(key) == "profile_only") { c->sync(); c->profile_only = (int)value; }
+        else if (std::string(key) == "shape_log") c->shape_log = (int)value;
+        else if (std::string(key) == "max_frames") { if (value < 1 || value > (1 << 24)) fail(ZVX_E_INVALID, "max_frames out of range"); c->max_frames = (int)value; }
         else fail(ZVX_E_INVALID, "unknown option '%s'", key);
     });
 }
@@ -1091,9 +1112,8 @@ zvx_status zvx_encode(zvx_ctx* c, const int32_t* phoneme, const int32_t* puncts,
                       int B, int Tmax, const float* spk, int32_t* mel_len, float* log_duration, float* pitch, float* energy) {
     return guarded(c, [&] {
         if (!phoneme || !puncts || !T || !spk) fail(ZVX_E_INVALID, "zvx_encode: NULL input");
-        run_encode(c, phoneme, puncts, duration, T, B, Tmax, spk);
+        run_encode(c, phoneme, puncts, duration, T, B, Tmax, spk, mel_len, 0);
         const size_t nid = (size_t)B * Tmax;
-        if (mel_len) memcpy(mel_len, c->mel_len_host.data(), B * sizeof(int));
         if (log_duration) HIPCHK(hipMemcpyAsync(log_duration, c->fbuf("va.logd", nid), nid * 4, hipMemcpyDeviceToHost, c->stream));
         if (pitch) HIPCHK(hipMemcpyAsync(pitch, c->fbuf("va.pitch", nid), nid * 4, hipMemcpyDeviceToHost, c->stream));
         if (energy) HIPCHK(hipMemcpyAsync(energy, c->fbuf("va.energy", nid), nid * 4, hipMemcpyDeviceToHost, c->stream));
@@ -1118,6 +1138,7 @@ zvx_status zvx_decode_features(zvx_ctx* c, const float* features, const int32_t*
         if (!features || !L || !spk || B <= 0 || Lmax <= 0) fail(ZVX_E_INVALID, "zvx_decode_features: bad arguments");
         for (int b = 0; b < B; b++) if (L[b] < 2 || L[b] > Lmax) fail(ZVX_E_INVALID, "L[%d]=%d out of range (2..%d)", b, L[b], Lmax);
         c->B = B; c->Lmax = Lmax; c->mel_len_host.assign(L, L + B); c->Tmax = 0;
+        c->have_features = false; c->have_mel = false;
         float* f = c->fbuf("features", (size_t)B * Lmax * c->H);
         HIPCHK(hipMemcpyAsync(f, features, (size_t)B * Lmax * c->H * 4, hipMemcpyHostToDevice, c->stream));
         float* spk_d = c->fbuf("in.spk", (size_t)B * c->H);
@@ -1130,18 +1151,19 @@ zvx_status zvx_decode_features(zvx_ctx* c, const float* features, const int32_t*
     });
 }
 
-zvx_status zvx_vocode(zvx_ctx* c, const int32_t* pad_to, float* wav, int64_t wav_stride, int flags) {
+zvx_status zvx_vocode(zvx_ctx* c, const int32_t* pad_to, void* wav, int64_t wav_stride, int flags) {
     return guarded(c, [&] {
         if (!wav) fail(ZVX_E_INVALID, "zvx_vocode: wav is NULL");
         do_vocode(c, pad_to, wav, wav_stride, flags);
     });
 }
 
-zvx_status zvx_vocode_mel(zvx_ctx* c, const float* mel, const int32_t* P, int B, int Pmax, float* wav, int64_t wav_stride, int flags) {
+zvx_status zvx_vocode_mel(zvx_ctx* c, const float* mel, const int32_t* P, int B, int Pmax, void* wav, int64_t wav_stride, int flags) {
     return guarded(c, [&] {
         if (!mel || !P || !wav || B <= 0 || Pmax <= 0) fail(ZVX_E_INVALID, "zvx_vocode_mel: bad arguments");
         for (int b = 0; b < B; b++) if (P[b] < 1 || P[b] > Pmax) fail(ZVX_E_INVALID, "P[%d]=%d out of range (1..%d)", b, P[b], Pmax);
-        c->B = B; c->Lmax = Pmax; c->mel_len_host.assign(P, P + B);
+        c->B = B; c->Lmax = Pmax; c->Tmax = 0; c->mel_len_host.assign(P, P + B);
+        c->have_features = false; c->have_mel = false;             // the context's batch geometry changes: earlier intermediates are void
         float* m = c->fbuf("mel", (size_t)B * Pmax * c->n_mels);
         HIPCHK(hipMemcpyAsync(m, mel, (size_t)B * Pmax * c->n_mels * 4, hipMemcpyHostToDevice, c->stream));
         c->have_mel = true;
@@ -1150,13 +1172,11 @@ zvx_status zvx_vocode_mel(zvx_ctx* c, const float* mel, const int32_t* P, int B,
 }
 
 zvx_status zvx_synthesize(zvx_ctx* c, const int32_t* phoneme, const int32_t* puncts, const int32_t* duration, const int32_t* T,
-                          int B, int Tmax, const float* spk, const int32_t* pad_to, int Lmax_cap, float* wav, int64_t wav_stride,
+                          int B, int Tmax, const float* spk, const int32_t* pad_to, int Lmax_cap, void* wav, int64_t wav_stride,
                           int32_t* mel_len, float* mel_out, int Lstride, float* log_duration, int flags) {
     return guarded(c, [&] {
         if (!phoneme || !puncts || !T || !spk || !wav) fail(ZVX_E_INVALID, "zvx_synthesize: NULL input");
-        run_encode(c, phoneme, puncts, duration, T, B, Tmax, spk);
-        if (mel_len) memcpy(mel_len, c->mel_len_host.data(), B * sizeof(int));
-        if (Lmax_cap > 0 && c->Lmax > Lmax_cap) fail(ZVX_E_BUFFER, "predicted mel length %d exceeds Lmax_cap %d", c->Lmax, Lmax_cap);
+        run_encode(c, phoneme, puncts, duration, T, B, Tmax, spk, mel_len, Lmax_cap);
         if (log_duration) HIPCHK(hipMemcpyAsync(log_duration, c->fbuf("va.logd", 0), (size_t)B * Tmax * 4, hipMemcpyDeviceToHost, c->stream));
         int* L_d = c->upload_ints("dec.L", c->mel_len_host.data(), B);
         run_decode(c, c->fbuf("features", 0), c->fbuf("in.spk", 0), L_d, B, c->Lmax);

@@ -136,9 +136,12 @@ void launch_copy_rows_f32(const void* src, int s_dt, int lds, long s_bs, float* 
                           int B, int rows_max, const int* rows, int C, hipStream_t s);
 
 // conv_post (C -> 1, k taps) + tanh on the activated final stage [b][Nmax][C]: wav[b][n], n < nlen[b]*hop...
+// samples in [out_len*out_mul, Nmax) are written as zeros; pcm16: wav is int16 PCM (x 32760, truncated)
 void launch_conv_post_tanh(const void* x, int x_dt, int ldx, long x_bs, const float* w /*[k][C]*/, float bias,
-                           int ktaps, int C, float* wav, long wav_bs, int B, int Nmax, const int* in_len,
+                           int ktaps, int C, void* wav, long wav_bs, int pcm16, int B, int Nmax, const int* in_len,
                            int len_mul, const int* out_len, int out_mul, hipStream_t s);
+// x[b][r][0:C] = 0 for rows[b] <= r < rows_max
+void launch_zero_tail_rows(float* x, int ldx, int B, int rows_max, const int* rows, int C, hipStream_t s);
 
 // ---- speaker encoder ----
 // InstanceNorm1d(80) over time + Conv2d(1->C0, 3x3, pad 1) + ReLU + BN affine -> map [b][F][Tmax][C0]

@@ -43,17 +43,32 @@ def load_tts_weights(modelpath):
     return cfg, sd
 
 
-def load_meldec_weights(modelspec):
+def load_meldec_weights(modelspec, tts_modelpath=None):
     """-> (hifigan_cfg, state_dict).  ``synthetic:<v1|v2|v3|tiny|tiny2>[:seed]`` or a directory with
-    ``config.json`` (model.py:90-105) + ``generator.npz``."""
+    ``config.json`` (model.py:90-105) + ``generator.npz``.
+
+    A vocoder BAKED INTO the TTS checkpoint (``_meldec.*`` keys, utils/edit_meldec_in_checkpoint.py:77-90; split off
+    by tools/convert_checkpoint.py into ``<tts_modelpath>/generator.npz``) overrides the external weights, exactly as
+    ``ZeroVox.load_from_checkpoint(strict=False)`` loads those keys on top of ``get_meldec()`` (synthesize.py:78-91);
+    the external model then only supplies ``config.json``.  A baked-in state dict whose keys/shapes do not fit that
+    config is an error, not a silent fallback."""
     spec = str(modelspec)
     if spec.startswith("synthetic:"):
         parts = spec.split(":")
         h = zcfg.hifigan_config(parts[1])
-        return h, zw.hifigan_state_dict(h, int(parts[2]) if len(parts) > 2 else 0)
-    with open(os.path.join(spec, "config.json")) as f:
-        h = json.load(f)
-    return h, dict(np.load(os.path.join(spec, "generator.npz")))
+        hsd = zw.hifigan_state_dict(h, int(parts[2]) if len(parts) > 2 else 0)
+    else:
+        with open(os.path.join(spec, "config.json")) as f:
+            h = json.load(f)
+        hsd = dict(np.load(os.path.join(spec, "generator.npz")))
+    baked = None if tts_modelpath is None or str(tts_modelpath).startswith("synthetic:") else os.path.join(str(tts_modelpath), "generator.npz")
+    if baked and os.path.exists(baked):
+        bsd = dict(np.load(baked))
+        bad = sorted(k for k in set(bsd) | set(hsd) if k not in bsd or k not in hsd or bsd[k].shape != hsd[k].shape)
+        if bad:
+            raise ValueError(f"{baked}: baked-in vocoder does not match {spec}/config.json (first mismatching keys: {bad[:4]})")
+        hsd = bsd
+    return h, hsd
 
 
 class ZeroVox:

@@ -172,7 +172,7 @@ class ZeroVoxTTS:
         weights.npz, or ``synthetic:<decoder_kind>[:seed]``; ``meldec_model``: directory with config.json +
         generator.npz, or ``synthetic:<v1|v2|v3|tiny>[:seed]``."""
         modelcfg, sd = load_tts_weights(modelpath)
-        hcfg, hsd = load_meldec_weights(meldec_model)
+        hcfg, hsd = load_meldec_weights(meldec_model, tts_modelpath=modelpath)
         model = ZeroVox(modelcfg, sd, hcfg, hsd, infer_device=infer_device, precision=precision, verbose=verbose)
         a = modelcfg["audio"]
         synth = cls(language=modelcfg["lang"][0], syms=Symbols(modelcfg["model"]["phones"], modelcfg["model"]["puncts"]),
