@@ -6,11 +6,11 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libzvx.so")
-SOURCES = ["gemm.hip", "ops.hip", "zvx.hip"]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+SOURCES = ["gemm.hip", "resstream.hip", "ops.hip", "zvx.hip"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-inline-asm"]
 # gemm.hip: no NaN is ever a legitimate operand of its epilogue min/max (leaky-relu and its inverse); without this flag every
 # fminf/fmaxf input coming from a bit operation (bf16 unpack) gets a canonicalising `v_max x, x, x` in front (IEEE mode)
-EXTRA_FLAGS = {"gemm.hip": ["-fno-honor-nans"]}
+EXTRA_FLAGS = {"gemm.hip": ["-fno-honor-nans"], "resstream.hip": ["-fno-honor-nans"]}
 
 
 def _stale(target, deps):
@@ -22,7 +22,7 @@ def _stale(target, deps):
 
 def build(force: bool = False, verbose: bool = True) -> str:
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    headers = [os.path.join(CSRC, "zvx_kernels.h"), os.path.join(os.path.dirname(HERE), "include", "zvx.h")]
+    headers = [os.path.join(CSRC, "zvx_kernels.h"), os.path.join(CSRC, "mfma_util.h"), os.path.join(os.path.dirname(HERE), "include", "zvx.h")]
     objs = []
     for src in SOURCES:
         s = os.path.join(CSRC, src)

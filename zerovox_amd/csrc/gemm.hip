@@ -1395,6 +1395,7 @@ static const Variant kVariants[] = {
     {"convreg_bf16_c32", DT_BF16, 512, 32},       {"convreg_bf16_c64", DT_BF16, 256, 64},
     {"resfuse_bf16_c32", DT_BF16, 256, 32},       {"resfuse_bf16_c64", DT_BF16, 128, 64},
     {"gemm_bf16_64x64", DT_BF16, 64, 64},         {"gemm_f32_64x64", DT_F32, 64, 64},
+    {"resstream_bf16_c32", DT_BF16, 64, 32},      {"resstream_bf16_c64", DT_BF16, 32, 64},
 };
 const char* gemm_variant_name(int id) { return kVariants[id].name; }
 int gemm_num_variants() { return (int)(sizeof(kVariants) / sizeof(kVariants[0])); }

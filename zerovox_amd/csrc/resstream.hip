@@ -1,0 +1,370 @@
+// resstream.hip -- a whole HiFi-GAN ResBlock1 (hifigan.py:49-56: three times  x += conv_1(lrelu(conv_d(lrelu(x)))) ) as ONE
+// streaming kernel for the narrow stages (C = 32 / 64), where the unfused convolutions are HBM-bound.
+//
+// Idea (the "LDS-ring-buffered 1-D convolution"): the 2*NPAIR convolutions of the chain are a software pipeline along
+// TIME.  A persistent workgroup walks a segment of one utterance in steps of R rows; every convolution ("role") is owned
+// by a fixed group of waves that keep ITS weight fragments in registers for the whole launch, reads its input rows from
+// an LDS ring written by the previous role and writes its output rows to the next ring:
+//
+//     HBM --DMA--> [X0 ring] -conv1_0-> [T0 ring] -conv2_0 (+x from X0)-> [X1 ring] -conv1_1-> [T1] -conv2_1 (+X1)-> [X2] ...
+//                                                                                      ... -conv2_last (+ xs) --> HBM
+//
+// Role r works one block behind role r-1 and its block boundaries are shifted left by the cumulated halo H_r, so the rows
+// it needs (its block plus h_r rows either side) are exactly the rows role r-1 finished one step earlier: one barrier per
+// step, ring r only holds 2R + 2h rows (3R + h1 + h2 for the X rings, which the second-next role re-reads as residual).
+// The stage tensor therefore crosses HBM ONCE per ResBlock instead of once per convolution pair, halo rows are computed
+// once per SEGMENT (not per tile), and no weight is ever re-fetched.
+//
+// Numerics are identical to the pair kernels of gemm.hip (same bf16 roundings of the intermediates, same accumulation
+// order tap-major / k16-minor), so results are bit-equal to the unfused path.
+#include "mfma_util.h"
+#include "zvx_kernels.h"
+
+#include <hip/hip_ext.h>
+
+#include <algorithm>
+
+namespace zvx {
+
+static thread_local hipEvent_t g_rs_ev_start = nullptr, g_rs_ev_stop = nullptr;
+void resstream_profile_events(hipEvent_t start, hipEvent_t stop) { g_rs_ev_start = start; g_rs_ev_stop = stop; }
+
+#define RS_RD 64          // rows per DMA block
+#define RS_PF 2           // DMA blocks are requested this many steps before role 0 needs them
+
+// wave -> (role, sub): waves w, w+4, w+8 share a SIMD; the tables give every SIMD a mix of conv1- and conv2-kind roles
+template <int NR, int WPR>
+__device__ __forceinline__ void role_of_wave(int w, int& role, int& sub) {
+    if (NR == 6 && WPR == 2) { role = (int)((0x452301453210ull >> (4 * w)) & 15); sub = w >= 6; }
+    else if (NR == 4 && WPR == 2) { role = (int)((0x23013210u >> (4 * w)) & 15); sub = w >= 4; }
+    else if (NR == 2 && WPR == 4) { role = (int)((0x01011010u >> (4 * w)) & 15); sub = w >> 1; }
+    else { role = w % NR; sub = w / NR; }
+}
+
+template <int C, int NT, int NPAIR, int RSPLIT, int AM, bool HAS_OUT>
+__global__ __launch_bounds__(128 * NPAIR * (C / 32) * RSPLIT) void resstream_kernel(const StreamArgs a) {
+    constexpr int NR = 2 * NPAIR, NTL = C / 32, WPR = NTL * RSPLIT;
+    constexpr int R = 32 * RSPLIT, KS = C / 16, P = 2 * C + 16, CPP = C / 8 + 1, H2 = (NT - 1) / 2, NW = NT * KS;
+    constexpr int PPB = CPP;                        // 1-KiB DMA pieces per 64-row block (64 rows x CPP 16-byte slots / 64 lanes)
+    constexpr int PPW = (PPB + WPR - 1) / WPR;      // pieces per issuing wave and block (surplus ones repeat the last piece)
+    constexpr int NKC = (C + 63) / 64;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int role, sub;
+    role_of_wave<NR, WPR>(wave, role, sub);
+    role = __builtin_amdgcn_readfirstlane(role); sub = __builtin_amdgcn_readfirstlane(sub);
+    const int pair = role >> 1, kind = role & 1;
+    const int ct = sub % NTL, rs = sub / NTL;
+    const int l32 = lane & 31, koff = (lane >> 5) * 16, h4 = 4 * (lane >> 5);
+    const bool is_final = role == NR - 1;
+
+    // ---- chain geometry (wave-uniform) ----
+    int my_h = 0, my_H = 0, Hsum = 0;
+#pragma unroll
+    for (int r = 0; r < NR; r++) {
+        const int h = (r & 1) ? H2 : a.dil[r >> 1] * H2;
+        Hsum += h;
+        if (r <= role) my_H += h;
+        if (r == role) my_h = h;
+    }
+    const int h0 = a.dil[0] * H2;
+    const int my_dil = kind ? 1 : a.dil[pair];
+    const int NB0 = (Hsum + R - 1) / R;
+    // LDS map: X0 | T0 | X1 | T1 | X2 | T2 | stage (final role) | bias table
+    int offX = 0, offT = 0, dXp = a.dX0, offXn = 0, dXn = 0;
+    {
+        int cur = a.dX0 * P;
+#pragma unroll
+        for (int p = 0; p < NPAIR; p++) {
+            if (p == pair) offT = cur;
+            cur += a.dT * P;
+            if (p + 1 < NPAIR) {
+                if (p + 1 == pair) { offX = cur; dXp = a.dX[p + 1]; }
+                if (p == pair) { offXn = cur; dXn = a.dX[p + 1]; }
+                cur += a.dX[p + 1] * P;
+            }
+        }
+        offXn = __builtin_amdgcn_readfirstlane(offXn); offX = __builtin_amdgcn_readfirstlane(offX); offT = __builtin_amdgcn_readfirstlane(offT);
+        dXp = __builtin_amdgcn_readfirstlane(dXp); dXn = __builtin_amdgcn_readfirstlane(dXn);
+    }
+    int ring_end = a.dX0 * P + NPAIR * a.dT * P;
+#pragma unroll
+    for (int p = 1; p < NPAIR; p++) ring_end += a.dX[p] * P;
+    unsigned char* const stw = lds + ring_end + sub * (32 * 80);                  // final role, per wave: 32 rows x 32 ch bf16, pitch 80
+    float* const bias_l = (float*)(lds + ring_end + WPR * (32 * 80));             // [NR][C]
+    // rings of this role
+    const int in_off = kind ? offT : offX, Din = kind ? a.dT : dXp;               // operand source
+    const int out_off = kind ? offXn : offT, Dout = kind ? dXn : a.dT;            // destination ring (unused by the final role)
+    const int res_off = offX, Dres = dXp;                                         // conv2: residual source = the pair's input stream
+
+    // ---- this wave's weights: conv1 <- W1[pair], conv2 <- W2[pair]; packed stream [nt32][chunk][tap][4 k16 slots], 1 KiB fragments ----
+    const void* wbase = nullptr;
+    const float* bsrc = nullptr;
+#pragma unroll
+    for (int p = 0; p < NPAIR; p++)
+        if (p == pair) { wbase = kind ? a.W2[p] : a.W1[p]; bsrc = kind ? a.b2[p] : a.b1[p]; }
+    const uint4* const Wq = (const uint4*)wbase + ((long)ct * NKC * NT * 4) * 64 + lane;
+    uint4 w[NW];
+#pragma unroll
+    for (int i = 0; i < NW; i++) { const int t = i / KS, kk = i % KS; w[i] = Wq[(((kk >> 2) * NT + t) * 4 + (kk & 3)) * 64]; }
+    if (rs == 0 && lane < 32) bias_l[role * C + ct * 32 + lane] = bsrc[ct * 32 + lane];
+    // settle the loads here: a compiler-placed wait inside the step loop would also wait for the (hidden) slab DMAs
+#pragma unroll
+    for (int i = 0; i < NW; i++) asm volatile("" :: "v"(w[i].x));
+
+    // ---- DMA lane offsets (role 0): piece j of a 64-row block = 16-byte slots [64 j, 64 j + 64) of its padded LDS image ----
+    int vrel[PPW];
+#pragma unroll
+    for (int n = 0; n < PPW; n++) {
+        int j = sub + WPR * n; if (j >= PPB) j = PPB - 1;
+        const int slot = j * 64 + lane, row = slot / CPP, qs = slot % CPP;
+        vrel[n] = qs == CPP - 1 ? -(1 << 30) : (row * a.ldx + (qs << 3)) * 2;         // pad slot: out of range -> zeros
+    }
+    const unsigned lds_addr0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
+    const int nslots = a.dX0 / RS_RD;                                              // DMA blocks the X0 ring holds
+
+    const float slope1 = a.slope1, rinv = a.res_inv_slope, oscale = a.out_scale, oslope = a.slope;
+    __syncthreads();                                                               // bias table visible
+
+    const int nsegs = a.nseg * a.nbatch;
+    for (int seg = blockIdx.x; seg < nsegs; seg += gridDim.x) {
+        const int b = seg / a.nseg, sj = seg - b * a.nseg;
+        int len = a.len ? a.len[b] : a.M;                                          // uniform address: scalar load
+        len = __builtin_amdgcn_readfirstlane(len);
+        const int seg0 = sj * a.S;
+        if (seg0 >= len) continue;
+        const int seg_end = min(seg0 + a.S, len);
+        const int b_last = (seg_end - seg0 + Hsum + R - 1) / R - 1;               // last block of the final role (others run the same count)
+        const int nact = b_last + NB0 + 1;                                         // blocks per role
+        const int nsteps = nact + NR - 1;
+        const int o0 = seg0 - NB0 * R - 2 * h0;                                    // first row of DMA block 0
+        const unsigned short* const Xb = (const unsigned short*)a.X + (long)b * a.x_bs;
+
+        // ring positions at this role's first block (independent of seg0: every segment starts from the same image)
+        int rd_pos = role == 0 ? rs * 32 : (Din - 2 * my_h + rs * 32) % Din;
+        int wr_pos = rs * 32;
+        int rs_pos = pair == 0 ? (h0 - H2 + rs * 32) : ((Dres - (a.dil[pair] * H2 + H2) % Dres + rs * 32) % Dres);
+        int g_out0 = seg0 - NB0 * R - my_H + rs * 32;                              // global row of this wave's first output row
+
+        // ---- DMA issue (role 0 waves) ----
+        int issued = 0, dslot = 0;
+        auto dma_block = [&]() {
+            const int g0 = o0 + issued * RS_RD;
+            const unsigned long long pa = (unsigned long long)(Xb + (long)g0 * a.ldx);
+            int nrec = (len - g0) * a.ldx * 2; if (nrec < 0) nrec = 0;
+            const i32x4 rsrc = {__builtin_amdgcn_readfirstlane((int)(unsigned)pa), __builtin_amdgcn_readfirstlane((int)((pa >> 32) & 0xffff)),
+                                __builtin_amdgcn_readfirstlane(nrec), 0x00020000};
+            const int thr = -g0 * a.ldx * 2;                                       // offsets below this belong to rows before the utterance
+            const unsigned la0 = lds_addr0 + offX + dslot * (RS_RD * P);
+#pragma unroll
+            for (int n = 0; n < PPW; n++) {
+                int j = sub + WPR * n; if (j >= PPB) j = PPB - 1;
+                const int voff = vrel[n] < thr ? -16 : vrel[n];
+                const unsigned la = __builtin_amdgcn_readfirstlane(la0 + j * 1024);
+                asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" :: "s"(la), "v"(voff), "s"(rsrc) : "memory", "m0");
+            }
+            issued++; dslot++; if (dslot == nslots) dslot = 0;
+        };
+        auto need = [&](int s) { return (2 * h0 + (s + 1) * R - 1) / RS_RD; };      // last DMA block role 0 reads in step s
+        auto wait_landed = [&](int nblocks) {                                      // all but the newest `issued - nblocks` blocks have landed
+            const int out = issued - nblocks;
+            if (out <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if (out == 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PPW) : "memory");
+            else if (out == 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * PPW) : "memory");
+            else if (out == 3) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(3 * PPW) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(4 * PPW) : "memory");
+        };
+        if (role == 0) {
+            const int target = need(RS_PF - 1) + 1;
+            while (issued < target) dma_block();
+            wait_landed(need(0) + 1);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+
+        for (int s = 0; s < nsteps; s++) {
+            const int blk = s - role;                                              // 0-based block counter of this role
+            if (role == 0) {
+                const int target = need(s + RS_PF) + 1;
+                while (issued < target) dma_block();
+            }
+            if (blk >= 0 && blk < nact) {
+                // ---- convolution: 32 rows x 32 output channels, operands from the input ring ----
+                f32x16 acc;
+#pragma unroll
+                for (int e = 0; e < 16; e++) acc[e] = 0.f;
+                const unsigned p0 = rd_pos + l32;
+                const unsigned char* const inb = lds + in_off + koff;
+#pragma unroll
+                for (int t = 0; t < NT; t++) {
+                    unsigned pt = p0 + t * my_dil;
+                    pt = min(pt, pt - (unsigned)Din);                              // pt >= Din -> pt - Din (unsigned wrap trick)
+                    const unsigned char* rowp = inb + pt * P;
+#pragma unroll
+                    for (int kk = 0; kk < KS; kk++) {
+                        const uint4 xf = *(const uint4*)(rowp + kk * 32);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w[t * KS + kk]), __builtin_bit_cast(bf16x8, xf), acc, 0, 0, 0);
+                    }
+                }
+                const int g = g_out0 + l32;                                        // this lane's output row
+                const bool inside = g >= 0 && g < len;                            // streams are zero outside the utterance (every conv zero-pads ITS input)
+                const float* const bl = bias_l + role * C + ct * 32 + h4;
+                if (!kind) {
+                    // ---- T = lrelu(acc + b1) -> bf16 -> T ring ----
+                    unsigned wp = wr_pos + l32; wp = min(wp, wp - (unsigned)Dout);
+                    unsigned char* const dst = lds + out_off + wp * P + (ct * 32 + h4) * 2;
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const float4 bb = *(const float4*)(bl + 8 * q);
+                        const f32x2 v01 = lrelu2((f32x2){acc[4 * q], acc[4 * q + 1]} + (f32x2){bb.x, bb.y}, slope1);
+                        const f32x2 v23 = lrelu2((f32x2){acc[4 * q + 2], acc[4 * q + 3]} + (f32x2){bb.z, bb.w}, slope1);
+                        uint2 pk;
+                        pk.x = inside ? pack_bf16x2(v01.x, v01.y) : 0u;
+                        pk.y = inside ? pack_bf16x2(v23.x, v23.y) : 0u;
+                        *(uint2*)(dst + q * 16) = pk;
+                    }
+                } else {
+                    // ---- x' = acc + b2 + x  (x = inverse lrelu of the pair's input stream, same rows) ----
+                    unsigned rp = rs_pos + l32; rp = min(rp, rp - (unsigned)Dres);
+                    const unsigned char* const resp = lds + res_off + rp * P + (ct * 32 + h4) * 2;
+                    uint2 pk[4];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const float4 bb = *(const float4*)(bl + 8 * q);
+                        const uint2 rq = *(const uint2*)(resp + q * 16);
+                        f32x2 v01 = (f32x2){acc[4 * q], acc[4 * q + 1]} + (f32x2){bb.x, bb.y} + inv_lrelu2(unpack_bf16x2(rq.x), rinv);
+                        f32x2 v23 = (f32x2){acc[4 * q + 2], acc[4 * q + 3]} + (f32x2){bb.z, bb.w} + inv_lrelu2(unpack_bf16x2(rq.y), rinv);
+                        if (!is_final) { v01 = lrelu2(v01, slope1); v23 = lrelu2(v23, slope1); }        // next pair's input, activated (slope 0.1 = slope1)
+                        else if (!AM) { v01 = lrelu2(v01, oslope); v23 = lrelu2(v23, oslope); }          // no running sum: activation applied here
+                        pk[q].x = pack_bf16x2(v01.x, v01.y);
+                        pk[q].y = pack_bf16x2(v23.x, v23.y);
+                    }
+                    if (!is_final) {
+                        unsigned wp = wr_pos + l32; wp = min(wp, wp - (unsigned)Dout);
+                        unsigned char* const dst = lds + out_off + wp * P + (ct * 32 + h4) * 2;
+#pragma unroll
+                        for (int q = 0; q < 4; q++) { uint2 o = pk[q]; if (!inside) { o.x = 0u; o.y = 0u; } *(uint2*)(dst + q * 16) = o; }
+                    } else {
+                        // ---- result rows -> per-wave LDS stage -> row-major 64-byte segments -> xs / output in HBM ----
+#pragma unroll
+                        for (int q = 0; q < 4; q++) *(uint2*)(stw + l32 * 80 + (8 * q + h4) * 2) = pk[q];
+                        const int lo = max(seg0, 0), hi = seg_end;
+                        const long rm_off = ct * 32 + (lane & 3) * 8;
+                        unsigned short* const accp = (unsigned short*)a.accum + (long)b * a.a_bs + rm_off;
+                        unsigned short* const outp = (unsigned short*)a.out + (long)b * a.o_bs + rm_off;
+                        uint4 xs[2];
+                        if (AM & 1) {
+#pragma unroll
+                            for (int h = 0; h < 2; h++) {
+                                const int gr = g_out0 + h * 16 + (lane >> 2);
+                                xs[h] = *(const uint4*)(accp + ((gr >= lo && gr < hi) ? (long)gr * a.lda : 0));
+                            }
+                        }
+                        uint4 o[2];
+#pragma unroll
+                        for (int h = 0; h < 2; h++) o[h] = *(const uint4*)(stw + (h * 16 + (lane >> 2)) * 80 + (lane & 3) * 16);
+#pragma unroll
+                        for (int h = 0; h < 2; h++) {
+                            const int gr = g_out0 + h * 16 + (lane >> 2);
+                            const bool ok = gr >= lo && gr < hi;
+                            if (AM) {
+                                f32x2 t[4] = {unpack_bf16x2(o[h].x), unpack_bf16x2(o[h].y), unpack_bf16x2(o[h].z), unpack_bf16x2(o[h].w)};
+                                if (AM & 1) {
+                                    t[0] += unpack_bf16x2(xs[h].x); t[1] += unpack_bf16x2(xs[h].y);
+                                    t[2] += unpack_bf16x2(xs[h].z); t[3] += unpack_bf16x2(xs[h].w);
+                                }
+                                if ((AM & 2) && ok)
+                                    *(u32x4*)(accp + (long)gr * a.lda) = (u32x4){pack_bf16x2(t[0].x, t[0].y), pack_bf16x2(t[1].x, t[1].y),
+                                                                                pack_bf16x2(t[2].x, t[2].y), pack_bf16x2(t[3].x, t[3].y)};
+                                if (HAS_OUT) {
+#pragma unroll
+                                    for (int e = 0; e < 4; e++) t[e] = lrelu2(t[e] * oscale, oslope);
+                                    o[h] = make_uint4(pack_bf16x2(t[0].x, t[0].y), pack_bf16x2(t[1].x, t[1].y), pack_bf16x2(t[2].x, t[2].y), pack_bf16x2(t[3].x, t[3].y));
+                                }
+                            }
+                            if (HAS_OUT && ok) *(uint4*)(outp + (long)gr * a.ldo) = o[h];
+                        }
+                    }
+                }
+                rd_pos += R; if (rd_pos >= Din) rd_pos -= Din;
+                wr_pos += R; if (wr_pos >= Dout && Dout > 0) wr_pos -= Dout;
+                rs_pos += R; if (rs_pos >= Dres) rs_pos -= Dres;
+                g_out0 += R;
+            }
+            if (role == 0) wait_landed(need(s + 1) + 1);                           // what role 0 reads in the next step has landed
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+        if (role == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // surplus requests of the tail: landed before the next segment re-uses X0
+        asm volatile("s_barrier" ::: "memory");
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// launcher
+// ------------------------------------------------------------------------------------------------
+static int g_ncu = 0;
+static int ncu() {
+    if (!g_ncu) { int dev = 0; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&g_ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || g_ncu <= 0) g_ncu = 256; }
+    return g_ncu;
+}
+
+template <int C, int NT, int NPAIR, int RSPLIT>
+static bool launch_rs(StreamArgs& a, hipStream_t stream, bool dry_run) {
+    constexpr int NTL = C / 32, WPR = NTL * RSPLIT, R = 32 * RSPLIT, P = 2 * C + 16, H2 = (NT - 1) / 2, NR = 2 * NPAIR;
+    // ring sizes (rows): see the header comment; X0 also covers the DMA lead and holds whole 64-row DMA blocks
+    int hsum = 0;
+    for (int p = 0; p < NPAIR; p++) hsum += (a.dil[p] + 1) * H2;
+    const int h0 = a.dil[0] * H2;
+    if (2 * h0 + R > 4 * RS_RD) return false;                                       // DMA lead assumed <= 4 blocks in flight
+    for (int p = 0; p < NPAIR; p++) if (a.dil[p] * H2 + H2 > R) return false;       // the residual rows of a block lie within the producer's last two blocks
+    a.dT = 2 * R + 2 * H2;
+    a.dX0 = (((RS_PF + 2) * R + RS_RD + h0 + H2 + 2 * h0) + RS_RD - 1) / RS_RD * RS_RD;
+    size_t rows = a.dX0 + (size_t)NPAIR * a.dT;
+    a.dX[0] = 0;
+    for (int p = 1; p < NPAIR; p++) {
+        const int h1 = a.dil[p] * H2;
+        a.dX[p] = std::max(2 * R + 2 * h1, 3 * R + h1 + H2);
+        rows += a.dX[p];
+    }
+    const size_t lds = rows * P + (size_t)WPR * 32 * 80 + (size_t)NR * C * 4;
+    if (lds > 160 * 1024) return false;
+    // segments: about one per CU, never shorter than 2048 rows (pipeline fill and halo are paid per segment)
+    long total = 0; (void)total;
+    const long rows_all = (long)a.M * a.nbatch;
+    int S = (int)((rows_all + ncu() - 1) / ncu());
+    if (S < 2048) S = 2048;
+    S = (S + R - 1) / R * R;
+    a.S = S; a.nseg = (a.M + S - 1) / S;
+    const int nsegs = a.nseg * a.nbatch;
+    a.flops = 2.0 * 2.0 * NPAIR * (double)rows_all * C * C * NT;
+    if (dry_run) return true;
+    const dim3 grid(nsegs < ncu() ? nsegs : ncu()), block(64 * NR * WPR);
+    const int am = a.accum ? a.accum_mode : 0;
+#define RS_GO(AM_, HO_) do { auto kfn = resstream_kernel<C, NT, NPAIR, RSPLIT, AM_, HO_>; \
+        static bool attr_done = false; \
+        if (!attr_done) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_done = true; } \
+        if (g_rs_ev_start) hipExtLaunchKernelGGL(kfn, grid, block, lds, stream, g_rs_ev_start, g_rs_ev_stop, 0, a); \
+        else hipLaunchKernelGGL(kfn, grid, block, lds, stream, a); return true; } while (0)
+    if (a.out) { if (am == 0) RS_GO(0, true); if (am == 1) RS_GO(1, true); return false; }
+    if (am == 2) RS_GO(2, false);
+    if (am == 3) RS_GO(3, false);
+#undef RS_GO
+    return false;
+}
+
+int launch_resstream(StreamArgs a, hipStream_t stream, bool dry_run) {
+    if (a.npair < 1 || a.npair > 3 || a.ldx % 8 || (a.out && a.ldo % 8) || (a.accum && a.lda % 8)) return -1;
+    if (a.ldx != a.C) return -1;                                                    // DMA image assumes dense rows
+    const int am = a.accum ? a.accum_mode : 0;
+    if (!a.out && !(am & 2)) return -1;
+    if (a.out && am >= 2) return -1;
+    for (int p = 0; p < a.npair; p++) if (a.dil[p] < 1 || !a.W1[p] || !a.W2[p] || !a.b1[p] || !a.b2[p]) return -1;
+#define RS_TRY(C_, NT_, NP_, RSP_) if (a.C == C_ && a.ntaps == NT_ && a.npair == NP_) return launch_rs<C_, NT_, NP_, RSP_>(a, stream, dry_run) ? (C_ == 32 ? 20 : 21) : -1
+    RS_TRY(32, 3, 3, 2); RS_TRY(32, 7, 3, 2); RS_TRY(32, 11, 3, 2);
+    RS_TRY(64, 3, 3, 1); RS_TRY(64, 7, 3, 1);
+    RS_TRY(64, 11, 2, 1); RS_TRY(64, 11, 1, 2);
+#undef RS_TRY
+    return -1;
+}
+
+}  // namespace zvx

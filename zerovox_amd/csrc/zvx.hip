@@ -75,6 +75,7 @@ struct zvx_ctx {
     // profiling
     int profile = 0;
     int profile_only = -1;                 // >= 0: per-launch events only for this kernel variant (keeps the timed region lean)
+    int use_resstream = 1;                 // zvx_set_int("resstream", 0): ResBlocks of the narrow stages as per-pair launches (A/B, bit-equal)
     int shape_log = 0;                     // zvx_set_int("shape_log", 1): one stderr line per timed launch (profile 2)
     int max_frames = 1 << 18;              // hard cap on a predicted mel length (guards the allocation, fs2.py:678-681 has none)
     hipEvent_t stage_ev[ZVX_T_COUNT][2];
@@ -151,6 +152,25 @@ struct zvx_ctx {
                        (double)a.N * a.K * a.ntaps * esz;
             pending.push_back(ev);
         }
+    }
+    // streaming ResBlock chain (resstream.hip); returns false (nothing launched) when the shape is not covered
+    bool run_stream(StreamArgs& a) {
+        const int id = launch_resstream(a, this->stream, true);
+        if (id < 0) return false;
+        GemmEvent ev{};
+        const bool prof = profile >= 2 && (profile_only < 0 || id == profile_only);
+        if (prof) { ev.a = new_event(); ev.b = new_event(); resstream_profile_events(ev.a, ev.b); }
+        const int id2 = launch_resstream(a, this->stream, false);
+        if (prof) resstream_profile_events(nullptr, nullptr);
+        if (id2 < 0) fail(ZVX_E_INVALID, "launch_resstream rejected a shape its dry run accepted (C=%d k=%d pairs=%d)", a.C, a.ntaps, a.npair);
+        if (prof) {
+            const double rows = (double)a.M * a.nbatch;
+            ev.variant = id2; ev.flops = 2.0 * 2.0 * a.npair * rows * a.C * a.C * a.ntaps; ev.rows = (long)rows; ev.N = a.C; ev.K = a.C; ev.taps = a.ntaps;
+            ev.res = a.accum_mode; ev.fused = 10 + a.npair;
+            ev.bytes = rows * a.C * 2.0 * (1 + (a.out ? 1 : 0) + ((a.accum && (a.accum_mode & 1)) ? 1 : 0) + ((a.accum && (a.accum_mode & 2)) ? 1 : 0));
+            pending.push_back(ev);
+        }
+        return true;
     }
     void resolve_events() {
         if (stats.empty()) {
@@ -725,7 +745,49 @@ void run_vocoder(zvx_ctx* c, const float* mel, int ldm, int Lmel_max, const int*
             const std::string rb = "voc.rb" + std::to_string(i * nk + j);
             const void* cur = X0;
             int pp = 0;
-            for (int t = 0; t < nd; t++) {
+            int t_first = 0;
+            if (c->voc_resblock == 1 && dt == DT_BF16 && c->use_resstream && nd >= 1 && nd <= 3) {
+                // whole ResBlock (or its first two pairs + the last one) as streaming launches: the stage tensor crosses HBM once
+                bool packed_ok = true;
+                for (int t = 0; t < nd; t++)
+                    packed_ok = packed_ok && c->packed.count(c->t(rb + ".c1_" + std::to_string(t) + "_w").dev) && c->packed.count(c->t(rb + ".c2_" + std::to_string(t) + "_w").dev);
+                auto chain = [&](int t0, int np, const void* in, bool closes) {
+                    StreamArgs sa;
+                    memset(&sa, 0, sizeof sa);
+                    sa.X = in; sa.x_bs = (long)rows * Cout; sa.ldx = Cout; sa.C = Cout; sa.ntaps = k; sa.npair = np;
+                    for (int q = 0; q < np; q++) {
+                        const std::string ts = std::to_string(t0 + q);
+                        sa.W1[q] = c->packed[c->t(rb + ".c1_" + ts + "_w").dev]; sa.W2[q] = c->packed[c->t(rb + ".c2_" + ts + "_w").dev];
+                        sa.b1[q] = c->pf(rb + ".c1_" + ts + "_b"); sa.b2[q] = c->pf(rb + ".c2_" + ts + "_b");
+                        sa.dil[q] = dil[t0 + q];
+                    }
+                    sa.slope1 = 0.1f; sa.res_inv_slope = 10.0f; sa.out_scale = 1.f; sa.slope = 0.1f;
+                    sa.len = len; sa.M = rows; sa.nbatch = B; sa.o_bs = (long)rows * Cout; sa.ldo = Cout; sa.a_bs = (long)rows * Cout; sa.lda = Cout;
+                    if (!closes) { sa.out = PP[pp]; }
+                    else if (nk == 1) { sa.out = A; sa.slope = next_slope; }
+                    else {
+                        sa.accum = XS; sa.accum_mode = j == 0 ? 2 : (j < nk - 1 ? 3 : 1);
+                        if (j == nk - 1) { sa.out = A; sa.out_scale = 1.0f / nk; sa.slope = next_slope; }
+                    }
+                    return sa;
+                };
+                if (packed_ok) {
+                    StreamArgs whole = chain(0, nd, X0, true);
+                    if (c->run_stream(whole)) t_first = nd;
+                    else if (nd == 3) {
+                        StreamArgs head = chain(0, 2, X0, false);
+                        StreamArgs probe = chain(2, 1, PP[pp], true);
+                        if (launch_resstream(head, c->stream, true) >= 0 && launch_resstream(probe, c->stream, true) >= 0) {
+                            c->run_stream(head);
+                            cur = PP[pp]; pp ^= 1;
+                            StreamArgs tail = chain(2, 1, cur, true);
+                            c->run_stream(tail);
+                            t_first = nd;
+                        }
+                    }
+                }
+            }
+            for (int t = t_first; t < nd; t++) {
                 const bool last = (t == nd - 1);
                 const void* cin_buf = cur;
                 auto rb_base = [&] {
@@ -1089,6 +1151,7 @@ zvx_status zvx_set_int(zvx_ctx* c, const char* key, int64_t value) {
         if (std::string(key) == "profile") { c->sync(); c->profile = (int)value; }
         else if (std::string(key) == "profile_only") { c->sync(); c->profile_only = (int)value; }
         else if (std::string(key) == "shape_log") c->shape_log = (int)value;
+        else if (std::string(key) == "resstream") c->use_resstream = (int)value;
         else if (std::string(key) == "max_frames") { if (value < 1 || value > (1 << 24)) fail(ZVX_E_INVALID, "max_frames out of range"); c->max_frames = (int)value; }
         else fail(ZVX_E_INVALID, "unknown option '%s'", key);
     });

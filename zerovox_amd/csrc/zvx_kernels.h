@@ -78,6 +78,29 @@ const char* gemm_variant_name(int id);
 int gemm_num_variants();
 
 // ------------------------------------------------------------------------------------------------
+// Streaming ResBlock1 chain (resstream.hip): up to three (dilated conv -> lrelu -> conv -> + x) pairs of one HiFi-GAN
+// ResBlock (hifigan.py:49-56) in ONE launch for C = 32 / 64.  Every intermediate tensor lives in LDS ring buffers; the
+// stage tensor is read once and the result (next input, running sum xs, or the stage mean) written once.
+// ------------------------------------------------------------------------------------------------
+struct StreamArgs {
+    const void* X; long x_bs; int ldx;             // stage input [b][M][ldx] bf16, activated domain (lrelu(x))
+    const void* W1[3]; const void* W2[3];          // fragment-packed bf16 weights of pair t: conv1 (dilated), conv2 (dilation 1)
+    const float* b1[3]; const float* b2[3];
+    int dil[3];
+    int C, ntaps, npair;
+    void* out; long o_bs; int ldo;                 // bf16 output, activated with `slope` (NULL: running sum only)
+    void* accum; long a_bs; int lda; int accum_mode;   // bf16 running sum xs: bit0 v += xs, bit1 xs = v
+    float slope1, res_inv_slope, out_scale, slope; // slope1: lrelu between the convs; slope: output activation (1 = none)
+    const int* len; int M, nbatch;                 // valid rows per utterance (NULL -> M)
+    int S, nseg;                                   // filled by the launcher: rows per segment, segments per utterance
+    int dX0, dT, dX[3];                            // filled by the launcher: ring sizes in rows
+    double flops;                                  // filled by the launcher
+};
+// variant id (index into gemm_variant_name) or -1 when the shape is not covered; dry_run: decide only, launch nothing
+int launch_resstream(StreamArgs a, hipStream_t stream, bool dry_run);
+void resstream_profile_events(hipEvent_t start, hipEvent_t stop);     // like gemm_profile_events, for the next launch_resstream
+
+// ------------------------------------------------------------------------------------------------
 // Small kernels (ops.hip).  T-typed pointers are void* + dtype.
 // ------------------------------------------------------------------------------------------------
 void launch_f32_to_bf16(const float* in, bf16_t* out, size_t n, hipStream_t s);
