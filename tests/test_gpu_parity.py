@@ -512,3 +512,23 @@ def test_unfusable_resblock_shapes_fall_back_to_two_launches():
     wav = ctx.vocode_mel(mel, np.array([14], np.int32))
     check_wav(wav[0], O.hifigan_generator(mel[0].T, hsd, h), "bf16", "unfused shapes", e2e=False)
     ctx.close()
+
+
+@pytest.mark.parametrize("voc", ["v1", "v2"])
+def test_streaming_resblock_kernels_equal_per_pair_launches(voc):
+    """resstream.hip (a whole ResBlock as one LDS-ring pipeline, C = 32 / 64) against the per-pair launches it replaces:
+    bit-identical waveforms -- ragged batches, utterances of 1 frame, utterances long enough to be cut into several
+    segments per workgroup (halo recomputation at segment starts), more segments than CUs."""
+    ctx = ctx_for("styletts", voc, "bf16")
+    rng = np.random.default_rng(31)
+    try:
+        for B, Pmax in ((3, 23), (2, 300), (1, 1), (40, 33), (1, 1100)):
+            P = rng.integers(1, Pmax + 1, B).astype(np.int32); P[0] = Pmax
+            mel = np.zeros((B, Pmax, 80), np.float32)
+            for b in range(B):
+                mel[b, :P[b]] = rng.standard_normal((P[b], 80)).astype(np.float32)
+            ctx.set_int("resstream", 0); ref = ctx.vocode_mel(mel, P)
+            ctx.set_int("resstream", 1); got = ctx.vocode_mel(mel, P)
+            assert np.isfinite(got).all() and np.array_equal(got, ref), (voc, B, Pmax)
+    finally:
+        ctx.set_int("resstream", 1)

@@ -36,3 +36,5 @@ for mode in (0, 1):
     for k in sorted(ks, key=lambda k: -k['ms']):
         print(f"   {k['name']:24s} {k['launches']//n:4d} launches {k['ms']/n:8.3f} ms {k['flops']/k['ms']/1e9:8.1f} TF/s {k['bytes']/k['ms']/1e6:8.1f} GB/s(alg)")
 print("ALL BIT-EQUAL" if ok else "MISMATCH")
+ctx.set_int("resstream", 1); ctx.set_int("profile", 2); ctx.set_int("shape_log", 1); ctx.reset_stats()
+ctx.vocode_mel(mel, P); ctx.stage_times()

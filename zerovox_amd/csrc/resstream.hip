@@ -23,6 +23,7 @@
 #include <hip/hip_ext.h>
 
 #include <algorithm>
+#include <type_traits>
 
 namespace zvx {
 
@@ -92,7 +93,6 @@ __global__ __launch_bounds__(128 * NPAIR * (C / 32) * RSPLIT) void resstream_ker
 #pragma unroll
     for (int p = 1; p < NPAIR; p++) ring_end += a.dX[p] * P;
     unsigned char* const stw = lds + ring_end + sub * (32 * 80);                  // final role, per wave: 32 rows x 32 ch bf16, pitch 80
-    float* const bias_l = (float*)(lds + ring_end + WPR * (32 * 80));             // [NR][C]
     // rings of this role
     const int in_off = kind ? offT : offX, Din = kind ? a.dT : dXp;               // operand source
     const int out_off = kind ? offXn : offT, Dout = kind ? dXn : a.dT;            // destination ring (unused by the final role)
@@ -108,25 +108,26 @@ __global__ __launch_bounds__(128 * NPAIR * (C / 32) * RSPLIT) void resstream_ker
     uint4 w[NW];
 #pragma unroll
     for (int i = 0; i < NW; i++) { const int t = i / KS, kk = i % KS; w[i] = Wq[(((kk >> 2) * NT + t) * 4 + (kk & 3)) * 64]; }
+    // bias table [NR][C] in LDS (after the final role's stages): 16 values per lane, re-read per block instead of held in registers
+    float* const bias_l = (float*)(lds + ring_end + WPR * (32 * 80));
     if (rs == 0 && lane < 32) bias_l[role * C + ct * 32 + lane] = bsrc[ct * 32 + lane];
+    __syncthreads();
     // settle the loads here: a compiler-placed wait inside the step loop would also wait for the (hidden) slab DMAs
 #pragma unroll
     for (int i = 0; i < NW; i++) asm volatile("" :: "v"(w[i].x));
 
     // ---- DMA lane offsets (role 0): piece j of a 64-row block = 16-byte slots [64 j, 64 j + 64) of its padded LDS image ----
-    int vrel[PPW];
-#pragma unroll
-    for (int n = 0; n < PPW; n++) {
-        int j = sub + WPR * n; if (j >= PPB) j = PPB - 1;
-        const int slot = j * 64 + lane, row = slot / CPP, qs = slot % CPP;
-        vrel[n] = qs == CPP - 1 ? -(1 << 30) : (row * a.ldx + (qs << 3)) * 2;         // pad slot: out of range -> zeros
-    }
     const unsigned lds_addr0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
     const int nslots = a.dX0 / RS_RD;                                              // DMA blocks the X0 ring holds
 
     const float slope1 = a.slope1, rinv = a.res_inv_slope, oscale = a.out_scale, oslope = a.slope;
-    __syncthreads();                                                               // bias table visible
 
+#ifdef RS_PROFILE
+    unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tlast = 0;
+#define RS_STAMP(k) do { if (a.prof) { const unsigned long long t_ = __builtin_readcyclecounter(); tacc[k] += t_ - tlast; tlast = t_; } } while (0)
+#else
+#define RS_STAMP(k) do {} while (0)
+#endif
     const int nsegs = a.nseg * a.nbatch;
     for (int seg = blockIdx.x; seg < nsegs; seg += gridDim.x) {
         const int b = seg / a.nseg, sj = seg - b * a.nseg;
@@ -137,7 +138,7 @@ __global__ __launch_bounds__(128 * NPAIR * (C / 32) * RSPLIT) void resstream_ker
         const int seg_end = min(seg0 + a.S, len);
         const int b_last = (seg_end - seg0 + Hsum + R - 1) / R - 1;               // last block of the final role (others run the same count)
         const int nact = b_last + NB0 + 1;                                         // blocks per role
-        const int nsteps = nact + NR - 1;
+        const int nsteps = nact + NR - 1;                                          // role r works on block i in step i + r
         const int o0 = seg0 - NB0 * R - 2 * h0;                                    // first row of DMA block 0
         const unsigned short* const Xb = (const unsigned short*)a.X + (long)b * a.x_bs;
 
@@ -146,6 +147,7 @@ __global__ __launch_bounds__(128 * NPAIR * (C / 32) * RSPLIT) void resstream_ker
         int wr_pos = rs * 32;
         int rs_pos = pair == 0 ? (h0 - H2 + rs * 32) : ((Dres - (a.dil[pair] * H2 + H2) % Dres + rs * 32) % Dres);
         int g_out0 = seg0 - NB0 * R - my_H + rs * 32;                              // global row of this wave's first output row
+        f32x16 acc;
 
         // ---- DMA issue (role 0 waves) ----
         int issued = 0, dslot = 0;
@@ -160,7 +162,9 @@ __global__ __launch_bounds__(128 * NPAIR * (C / 32) * RSPLIT) void resstream_ker
 #pragma unroll
             for (int n = 0; n < PPW; n++) {
                 int j = sub + WPR * n; if (j >= PPB) j = PPB - 1;
-                const int voff = vrel[n] < thr ? -16 : vrel[n];
+                const int slot = j * 64 + lane, row = slot / CPP, qs = slot % CPP;
+                const int vrel = qs == CPP - 1 ? -(1 << 30) : (row * a.ldx + (qs << 3)) * 2;          // pad slot: out of range -> zeros
+                const int voff = vrel < thr ? -16 : vrel;
                 const unsigned la = __builtin_amdgcn_readfirstlane(la0 + j * 1024);
                 asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" :: "s"(la), "v"(voff), "s"(rsrc) : "memory", "m0");
             }
@@ -182,121 +186,168 @@ __global__ __launch_bounds__(128 * NPAIR * (C / 32) * RSPLIT) void resstream_ker
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 
+        // final role: the store phase of a block (stage -> xs / output in HBM) runs at the START of the next step, beside the
+        // other roles' MFMAs; its xs rows are requested a step early
+        bool pend = false; int pend_g0 = 0;
+        uint4 xs[2];
+        const int lo = max(seg0, 0), hi = seg_end;
+        const long rm_off = ct * 32 + (lane & 3) * 8;
+        unsigned short* const accp = (unsigned short*)a.accum + (long)b * a.a_bs + rm_off;
+        unsigned short* const outp = (unsigned short*)a.out + (long)b * a.o_bs + rm_off;
+        auto store_phase = [&]() {
+            uint4 o[2];
+#pragma unroll
+            for (int h = 0; h < 2; h++) o[h] = *(const uint4*)(stw + (h * 16 + (lane >> 2)) * 80 + (lane & 3) * 16);
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const int gr = pend_g0 + h * 16 + (lane >> 2);
+                const bool ok = gr >= lo && gr < hi;
+                if (AM) {
+                    f32x2 t[4] = {unpack_bf16x2(o[h].x), unpack_bf16x2(o[h].y), unpack_bf16x2(o[h].z), unpack_bf16x2(o[h].w)};
+                    if (AM & 1) {
+                        t[0] += unpack_bf16x2(xs[h].x); t[1] += unpack_bf16x2(xs[h].y);
+                        t[2] += unpack_bf16x2(xs[h].z); t[3] += unpack_bf16x2(xs[h].w);
+                    }
+                    if ((AM & 2) && ok)
+                        *(u32x4*)(accp + (long)gr * a.lda) = (u32x4){pack_bf16x2(t[0].x, t[0].y), pack_bf16x2(t[1].x, t[1].y),
+                                                                    pack_bf16x2(t[2].x, t[2].y), pack_bf16x2(t[3].x, t[3].y)};
+                    if (HAS_OUT) {
+#pragma unroll
+                        for (int e = 0; e < 4; e++) t[e] = lrelu2(t[e] * oscale, oslope);
+                        o[h] = make_uint4(pack_bf16x2(t[0].x, t[0].y), pack_bf16x2(t[1].x, t[1].y), pack_bf16x2(t[2].x, t[2].y), pack_bf16x2(t[3].x, t[3].y));
+                    }
+                }
+                if (HAS_OUT && ok) *(uint4*)(outp + (long)gr * a.ldo) = o[h];
+            }
+        };
+
+        // One block of one role.  KIND 0: conv1 (-> T ring), 1: conv2 feeding the next pair (-> X ring), 2: the chain's last conv2.
+        // Every LDS read is inline asm with counted lgkmcnt waits (LDS operations complete in order): the B fragments are
+        // requested PD ahead of the MFMA that consumes them.
+        auto mma_block = [&]() {
+            constexpr int PD = NW <= 6 ? NW : (NW >= 40 ? 4 : 6);
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[e] = 0.f;
+            const unsigned p0 = rd_pos + l32;
+            const unsigned in_addr = lds_addr0 + in_off + koff;
+            uint4 xf[PD + 1];
+            unsigned ta = 0;                                                       // LDS byte address of this lane's row for the tap being requested
+            auto request = [&](int i) {                                            // i is a literal at every call site (fully unrolled)
+                if (i % KS == 0) {
+                    unsigned pt = p0 + (i / KS) * my_dil;
+                    pt = min(pt, pt - (unsigned)Din);                              // pt >= Din -> pt - Din (unsigned wrap trick)
+                    ta = in_addr + pt * P;
+                }
+                switch (i % KS) {                                                  // the offset must be an immediate
+                    case 0: asm volatile("ds_read_b128 %0, %1" : "=v"(xf[i % (PD + 1)]) : "v"(ta)); break;
+                    case 1: asm volatile("ds_read_b128 %0, %1 offset:32" : "=v"(xf[i % (PD + 1)]) : "v"(ta)); break;
+                    case 2: asm volatile("ds_read_b128 %0, %1 offset:64" : "=v"(xf[i % (PD + 1)]) : "v"(ta)); break;
+                    default: asm volatile("ds_read_b128 %0, %1 offset:96" : "=v"(xf[i % (PD + 1)]) : "v"(ta)); break;
+                }
+            };
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                     // nothing else in the LGKM queue while waits are counted
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < PD; i++) request(i);
+#pragma unroll
+            for (int i = 0; i < NW; i++) {
+                if (i + PD < NW) request(i + PD);
+                const int rem = NW - 1 - i;                                        // reads requested after read i
+                if (rem >= PD) asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(PD) : "memory");
+                else if (rem == 5) asm volatile("s_waitcnt lgkmcnt(5)" ::: "memory");
+                else if (rem == 4) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+                else if (rem == 3) asm volatile("s_waitcnt lgkmcnt(3)" ::: "memory");
+                else if (rem == 2) asm volatile("s_waitcnt lgkmcnt(2)" ::: "memory");
+                else if (rem == 1) asm volatile("s_waitcnt lgkmcnt(1)" ::: "memory");
+                else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w[i]), __builtin_bit_cast(bf16x8, xf[i % (PD + 1)]), acc, 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            rd_pos += R; if (rd_pos >= Din) rd_pos -= Din;
+        };
+        auto epilogue_block = [&](auto kind_c) {
+            constexpr int KIND = decltype(kind_c)::value;
+            const int g = g_out0 + l32;                                            // this lane's output row
+            const bool inside = g >= 0 && g < len;                                 // streams are zero outside the utterance (every conv zero-pads ITS input)
+            float4 bq[4];
+            uint2 rq[4] = {};
+            const unsigned ba = lds_addr0 + (unsigned)((unsigned char*)bias_l - lds) + (role * C + ct * 32 + h4) * 4;
+            asm volatile("ds_read_b128 %0, %1" : "=v"(bq[0]) : "v"(ba));
+            asm volatile("ds_read_b128 %0, %1 offset:32" : "=v"(bq[1]) : "v"(ba));
+            asm volatile("ds_read_b128 %0, %1 offset:64" : "=v"(bq[2]) : "v"(ba));
+            asm volatile("ds_read_b128 %0, %1 offset:96" : "=v"(bq[3]) : "v"(ba));
+            if (KIND >= 1) {                                                       // x = the pair's input stream, same rows
+                unsigned rp = rs_pos + l32; rp = min(rp, rp - (unsigned)Dres);
+                const unsigned ra = lds_addr0 + res_off + rp * P + (ct * 32 + h4) * 2;
+                asm volatile("ds_read_b64 %0, %1" : "=v"(rq[0]) : "v"(ra));
+                asm volatile("ds_read_b64 %0, %1 offset:16" : "=v"(rq[1]) : "v"(ra));
+                asm volatile("ds_read_b64 %0, %1 offset:32" : "=v"(rq[2]) : "v"(ra));
+                asm volatile("ds_read_b64 %0, %1 offset:48" : "=v"(rq[3]) : "v"(ra));
+            }
+            unsigned char* dst;
+            if (KIND <= 1) { unsigned wp = wr_pos + l32; wp = min(wp, wp - (unsigned)Dout); dst = lds + out_off + wp * P + (ct * 32 + h4) * 2; }
+            else dst = stw + l32 * 80 + h4 * 2;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                f32x2 v01 = (f32x2){acc[4 * q], acc[4 * q + 1]} + (f32x2){bq[q].x, bq[q].y};
+                f32x2 v23 = (f32x2){acc[4 * q + 2], acc[4 * q + 3]} + (f32x2){bq[q].z, bq[q].w};
+                if (KIND >= 1) { v01 += inv_lrelu2(unpack_bf16x2(rq[q].x), rinv); v23 += inv_lrelu2(unpack_bf16x2(rq[q].y), rinv); }
+                if (KIND <= 1) { v01 = lrelu2(v01, slope1); v23 = lrelu2(v23, slope1); }                  // T, or the next pair's activated input
+                else if (!AM) { v01 = lrelu2(v01, oslope); v23 = lrelu2(v23, oslope); }                  // no running sum: the output activation is applied here
+                uint2 pk;
+                pk.x = pack_bf16x2(v01.x, v01.y); pk.y = pack_bf16x2(v23.x, v23.y);
+                if (KIND <= 1 && !inside) { pk.x = 0u; pk.y = 0u; }
+                *(uint2*)(dst + q * 16) = pk;
+            }
+            if (KIND == 2) {
+                pend = true; pend_g0 = g_out0;
+                if (AM & 1) {                                                      // xs rows of this block: requested now, used by the store phase next step
+#pragma unroll
+                    for (int h = 0; h < 2; h++) {
+                        const int gr = g_out0 + h * 16 + (lane >> 2);
+                        xs[h] = *(const uint4*)(accp + ((gr >= lo && gr < hi) ? (long)gr * a.lda : 0));
+                    }
+                }
+            }
+            wr_pos += R; if (wr_pos >= Dout && Dout > 0) wr_pos -= Dout;
+            rs_pos += R; if (rs_pos >= Dres) rs_pos -= Dres;
+            g_out0 += R;
+        };
+
         for (int s = 0; s < nsteps; s++) {
-            const int blk = s - role;                                              // 0-based block counter of this role
+            RS_STAMP(0);
+            const int blk = s - role;                                              // this role's block in this step
             if (role == 0) {
                 const int target = need(s + RS_PF) + 1;
                 while (issued < target) dma_block();
             }
+            if (is_final && pend) { store_phase(); pend = false; }
+            RS_STAMP(1);
             if (blk >= 0 && blk < nact) {
-                // ---- convolution: 32 rows x 32 output channels, operands from the input ring ----
-                f32x16 acc;
-#pragma unroll
-                for (int e = 0; e < 16; e++) acc[e] = 0.f;
-                const unsigned p0 = rd_pos + l32;
-                const unsigned char* const inb = lds + in_off + koff;
-#pragma unroll
-                for (int t = 0; t < NT; t++) {
-                    unsigned pt = p0 + t * my_dil;
-                    pt = min(pt, pt - (unsigned)Din);                              // pt >= Din -> pt - Din (unsigned wrap trick)
-                    const unsigned char* rowp = inb + pt * P;
-#pragma unroll
-                    for (int kk = 0; kk < KS; kk++) {
-                        const uint4 xf = *(const uint4*)(rowp + kk * 32);
-                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w[t * KS + kk]), __builtin_bit_cast(bf16x8, xf), acc, 0, 0, 0);
-                    }
-                }
-                const int g = g_out0 + l32;                                        // this lane's output row
-                const bool inside = g >= 0 && g < len;                            // streams are zero outside the utterance (every conv zero-pads ITS input)
-                const float* const bl = bias_l + role * C + ct * 32 + h4;
-                if (!kind) {
-                    // ---- T = lrelu(acc + b1) -> bf16 -> T ring ----
-                    unsigned wp = wr_pos + l32; wp = min(wp, wp - (unsigned)Dout);
-                    unsigned char* const dst = lds + out_off + wp * P + (ct * 32 + h4) * 2;
-#pragma unroll
-                    for (int q = 0; q < 4; q++) {
-                        const float4 bb = *(const float4*)(bl + 8 * q);
-                        const f32x2 v01 = lrelu2((f32x2){acc[4 * q], acc[4 * q + 1]} + (f32x2){bb.x, bb.y}, slope1);
-                        const f32x2 v23 = lrelu2((f32x2){acc[4 * q + 2], acc[4 * q + 3]} + (f32x2){bb.z, bb.w}, slope1);
-                        uint2 pk;
-                        pk.x = inside ? pack_bf16x2(v01.x, v01.y) : 0u;
-                        pk.y = inside ? pack_bf16x2(v23.x, v23.y) : 0u;
-                        *(uint2*)(dst + q * 16) = pk;
-                    }
-                } else {
-                    // ---- x' = acc + b2 + x  (x = inverse lrelu of the pair's input stream, same rows) ----
-                    unsigned rp = rs_pos + l32; rp = min(rp, rp - (unsigned)Dres);
-                    const unsigned char* const resp = lds + res_off + rp * P + (ct * 32 + h4) * 2;
-                    uint2 pk[4];
-#pragma unroll
-                    for (int q = 0; q < 4; q++) {
-                        const float4 bb = *(const float4*)(bl + 8 * q);
-                        const uint2 rq = *(const uint2*)(resp + q * 16);
-                        f32x2 v01 = (f32x2){acc[4 * q], acc[4 * q + 1]} + (f32x2){bb.x, bb.y} + inv_lrelu2(unpack_bf16x2(rq.x), rinv);
-                        f32x2 v23 = (f32x2){acc[4 * q + 2], acc[4 * q + 3]} + (f32x2){bb.z, bb.w} + inv_lrelu2(unpack_bf16x2(rq.y), rinv);
-                        if (!is_final) { v01 = lrelu2(v01, slope1); v23 = lrelu2(v23, slope1); }        // next pair's input, activated (slope 0.1 = slope1)
-                        else if (!AM) { v01 = lrelu2(v01, oslope); v23 = lrelu2(v23, oslope); }          // no running sum: activation applied here
-                        pk[q].x = pack_bf16x2(v01.x, v01.y);
-                        pk[q].y = pack_bf16x2(v23.x, v23.y);
-                    }
-                    if (!is_final) {
-                        unsigned wp = wr_pos + l32; wp = min(wp, wp - (unsigned)Dout);
-                        unsigned char* const dst = lds + out_off + wp * P + (ct * 32 + h4) * 2;
-#pragma unroll
-                        for (int q = 0; q < 4; q++) { uint2 o = pk[q]; if (!inside) { o.x = 0u; o.y = 0u; } *(uint2*)(dst + q * 16) = o; }
-                    } else {
-                        // ---- result rows -> per-wave LDS stage -> row-major 64-byte segments -> xs / output in HBM ----
-#pragma unroll
-                        for (int q = 0; q < 4; q++) *(uint2*)(stw + l32 * 80 + (8 * q + h4) * 2) = pk[q];
-                        const int lo = max(seg0, 0), hi = seg_end;
-                        const long rm_off = ct * 32 + (lane & 3) * 8;
-                        unsigned short* const accp = (unsigned short*)a.accum + (long)b * a.a_bs + rm_off;
-                        unsigned short* const outp = (unsigned short*)a.out + (long)b * a.o_bs + rm_off;
-                        uint4 xs[2];
-                        if (AM & 1) {
-#pragma unroll
-                            for (int h = 0; h < 2; h++) {
-                                const int gr = g_out0 + h * 16 + (lane >> 2);
-                                xs[h] = *(const uint4*)(accp + ((gr >= lo && gr < hi) ? (long)gr * a.lda : 0));
-                            }
-                        }
-                        uint4 o[2];
-#pragma unroll
-                        for (int h = 0; h < 2; h++) o[h] = *(const uint4*)(stw + (h * 16 + (lane >> 2)) * 80 + (lane & 3) * 16);
-#pragma unroll
-                        for (int h = 0; h < 2; h++) {
-                            const int gr = g_out0 + h * 16 + (lane >> 2);
-                            const bool ok = gr >= lo && gr < hi;
-                            if (AM) {
-                                f32x2 t[4] = {unpack_bf16x2(o[h].x), unpack_bf16x2(o[h].y), unpack_bf16x2(o[h].z), unpack_bf16x2(o[h].w)};
-                                if (AM & 1) {
-                                    t[0] += unpack_bf16x2(xs[h].x); t[1] += unpack_bf16x2(xs[h].y);
-                                    t[2] += unpack_bf16x2(xs[h].z); t[3] += unpack_bf16x2(xs[h].w);
-                                }
-                                if ((AM & 2) && ok)
-                                    *(u32x4*)(accp + (long)gr * a.lda) = (u32x4){pack_bf16x2(t[0].x, t[0].y), pack_bf16x2(t[1].x, t[1].y),
-                                                                                pack_bf16x2(t[2].x, t[2].y), pack_bf16x2(t[3].x, t[3].y)};
-                                if (HAS_OUT) {
-#pragma unroll
-                                    for (int e = 0; e < 4; e++) t[e] = lrelu2(t[e] * oscale, oslope);
-                                    o[h] = make_uint4(pack_bf16x2(t[0].x, t[0].y), pack_bf16x2(t[1].x, t[1].y), pack_bf16x2(t[2].x, t[2].y), pack_bf16x2(t[3].x, t[3].y));
-                                }
-                            }
-                            if (HAS_OUT && ok) *(uint4*)(outp + (long)gr * a.ldo) = o[h];
-                        }
-                    }
-                }
-                rd_pos += R; if (rd_pos >= Din) rd_pos -= Din;
-                wr_pos += R; if (wr_pos >= Dout && Dout > 0) wr_pos -= Dout;
-                rs_pos += R; if (rs_pos >= Dres) rs_pos -= Dres;
-                g_out0 += R;
+                mma_block();
+                if (!kind) epilogue_block(std::integral_constant<int, 0>{});
+                else if (!is_final) epilogue_block(std::integral_constant<int, 1>{});
+                else epilogue_block(std::integral_constant<int, 2>{});
             }
+            RS_STAMP(2);
             if (role == 0) wait_landed(need(s + 1) + 1);                           // what role 0 reads in the next step has landed
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            RS_STAMP(3);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            RS_STAMP(4);
+            asm volatile("s_barrier" ::: "memory");
+            RS_STAMP(5);
         }
+        if (is_final && pend) store_phase();
         if (role == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // surplus requests of the tail: landed before the next segment re-uses X0
         asm volatile("s_barrier" ::: "memory");
     }
+#ifdef RS_PROFILE
+    if (a.prof && blockIdx.x == 0 && lane == 0)
+        for (int k = 0; k < 6; k++) a.prof[(wave * 8 + k)] = (long long)tacc[k], a.prof[wave * 8 + 6] = role, a.prof[wave * 8 + 7] = sub;
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -360,8 +411,11 @@ int launch_resstream(StreamArgs a, hipStream_t stream, bool dry_run) {
     if (a.out && am >= 2) return -1;
     for (int p = 0; p < a.npair; p++) if (a.dil[p] < 1 || !a.W1[p] || !a.W2[p] || !a.b1[p] || !a.b2[p]) return -1;
 #define RS_TRY(C_, NT_, NP_, RSP_) if (a.C == C_ && a.ntaps == NT_ && a.npair == NP_) return launch_rs<C_, NT_, NP_, RSP_>(a, stream, dry_run) ? (C_ == 32 ? 20 : 21) : -1
+    // 12 waves (whole ResBlock, 168 registers per wave) where the weight fragments leave room; otherwise 8 waves (256
+    // registers): the first two pairs as one chain, the last pair on its own with the rows split over more waves
     RS_TRY(32, 3, 3, 2); RS_TRY(32, 7, 3, 2); RS_TRY(32, 11, 3, 2);
-    RS_TRY(64, 3, 3, 1); RS_TRY(64, 7, 3, 1);
+    RS_TRY(64, 3, 3, 1);
+    RS_TRY(64, 7, 2, 1); RS_TRY(64, 7, 1, 2);
     RS_TRY(64, 11, 2, 1); RS_TRY(64, 11, 1, 2);
 #undef RS_TRY
     return -1;

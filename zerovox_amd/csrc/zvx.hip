@@ -75,6 +75,7 @@ struct zvx_ctx {
     // profiling
     int profile = 0;
     int profile_only = -1;                 // >= 0: per-launch events only for this kernel variant (keeps the timed region lean)
+    int rs_prof = 0;                       // zvx_set_int("rs_prof", 1): per-wave cycle counters of the streaming kernels (library built with -DRS_PROFILE)
     int use_resstream = 1;                 // zvx_set_int("resstream", 0): ResBlocks of the narrow stages as per-pair launches (A/B, bit-equal)
     int shape_log = 0;                     // zvx_set_int("shape_log", 1): one stderr line per timed launch (profile 2)
     int max_frames = 1 << 18;              // hard cap on a predicted mel length (guards the allocation, fs2.py:678-681 has none)
@@ -761,6 +762,7 @@ void run_vocoder(zvx_ctx* c, const float* mel, int ldm, int Lmel_max, const int*
                         sa.b1[q] = c->pf(rb + ".c1_" + ts + "_b"); sa.b2[q] = c->pf(rb + ".c2_" + ts + "_b");
                         sa.dil[q] = dil[t0 + q];
                     }
+                    if (c->rs_prof) sa.prof = (long long*)c->buf("rs.prof." + rb + "." + std::to_string(t0), 16 * 8 * 8);   // RS_PROFILE builds only
                     sa.slope1 = 0.1f; sa.res_inv_slope = 10.0f; sa.out_scale = 1.f; sa.slope = 0.1f;
                     sa.len = len; sa.M = rows; sa.nbatch = B; sa.o_bs = (long)rows * Cout; sa.ldo = Cout; sa.a_bs = (long)rows * Cout; sa.lda = Cout;
                     if (!closes) { sa.out = PP[pp]; }
@@ -1152,6 +1154,7 @@ zvx_status zvx_set_int(zvx_ctx* c, const char* key, int64_t value) {
         else if (std::string(key) == "profile_only") { c->sync(); c->profile_only = (int)value; }
         else if (std::string(key) == "shape_log") c->shape_log = (int)value;
         else if (std::string(key) == "resstream") c->use_resstream = (int)value;
+        else if (std::string(key) == "rs_prof") c->rs_prof = (int)value;
         else if (std::string(key) == "max_frames") { if (value < 1 || value > (1 << 24)) fail(ZVX_E_INVALID, "max_frames out of range"); c->max_frames = (int)value; }
         else fail(ZVX_E_INVALID, "unknown option '%s'", key);
     });
@@ -1274,6 +1277,13 @@ zvx_status zvx_fetch(zvx_ctx* c, const char* what, float* out, size_t out_floats
         else if (w == "pitch_idx") copy_i("va.pitch_idx", nid);
         else if (w == "energy_idx") copy_i("va.energy_idx", nid);
         else if (w == "duration") copy_i("va.dur", nid);
+        else if (w.rfind("buf:", 0) == 0) {                              // raw bytes of a named context buffer (development aid)
+            auto it = c->bufs.find(w.substr(4));
+            if (it == c->bufs.end()) fail(ZVX_E_INVALID, "zvx_fetch: no buffer '%s'", what);
+            const size_t nb = std::min(out_floats * 4, it->second.cap);
+            HIPCHK(hipMemcpyAsync(out, it->second.p, nb, hipMemcpyDeviceToHost, c->stream));
+            c->sync();
+        }
         else fail(ZVX_E_INVALID, "zvx_fetch: unknown tensor '%s'", what);
     });
 }

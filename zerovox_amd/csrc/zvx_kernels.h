@@ -95,6 +95,7 @@ struct StreamArgs {
     int S, nseg;                                   // filled by the launcher: rows per segment, segments per utterance
     int dX0, dT, dX[3];                            // filled by the launcher: ring sizes in rows
     double flops;                                  // filled by the launcher
+    long long* prof;                               // RS_PROFILE builds: per-wave cycle counters of workgroup 0
 };
 // variant id (index into gemm_variant_name) or -1 when the shape is not covered; dry_run: decide only, launch nothing
 int launch_resstream(StreamArgs a, hipStream_t stream, bool dry_run);
