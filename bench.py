@@ -1,19 +1,24 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark: audio samples/s (+ RTF) for 128-phoneme zero-shot synthesis @22.05 kHz.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--config 2|4|5]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-A "step" = one pass of the whole hot path (phoneme encoder + variance adaptor + length regulator + mel
-decoder + HiFi-GAN) over one batch of 32 synthetic 128-phoneme utterances per GPU (BASELINE.json
-configs[1]; weak scaling: configs[2] is 8 such shards), forced durations = 7 -> 896 frames -> 229 376
-samples (10.40 s) per utterance, tts_medium_styledec dims + HiFi-GAN V1, seeded synthetic weights.
-For N>1 every step ends with the one collective of the path: the RCCL waveform gather to rank 0.
-Timing: W untimed steps, then exactly K steps bracketed by barrier + device synchronize; MAX over ranks.
-Rank 0 prints ONE JSON line.
+--config 2 (default, BASELINE.json configs[1]; N > 1 = configs[2]): a "step" = one pass of the whole hot path (phoneme
+    encoder + variance adaptor + length regulator + mel decoder + HiFi-GAN) over 32 synthetic 128-phoneme utterances per
+    GPU, forced durations = 7 -> 896 frames -> 229 376 samples (10.40 s) each, tts_medium_styledec + HiFi-GAN V1, seeded
+    synthetic weights.  Weak scaling: every rank synthesises its own shard; each step ends with the ONE collective of the
+    path, the waveform gather to rank 0 (RCCL send/recv issued inside libzvx, overlapped with the next step's synthesis).
+--config 4 (configs[3]): HiFi-GAN V1 alone on device-resident 1024-frame N(0,1) mels (seed 7), --batch utterances per step.
+--config 5 (configs[4]): ResNetSE34V2 speaker encoder on 1000 device-resident 3 s mels; a step = one batch of 50 clips.
+
+Timing: W untimed steps, then exactly K steps bracketed by a barrier + full device drain on both sides; MAX over ranks.
+Rank 0 prints ONE JSON line.  No GPU runtime other than libzvx is loaded (no torch on the hot path; for N > 1 the 128-byte
+RCCL id travels through torch.distributed's TCPStore, nothing else).
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -26,101 +31,180 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 MFMA_PEAK = {"bf16": 2500.0, "f32": 157.3}   # dense TFLOP/s (MI355X_MICROARCH.md)
+F32_STAGES = ("encoder", "variance")         # computed in f32 in both precision modes (they feed discrete decisions)
 
 
-def cpu_baseline(cfg, sd, hcfg, hsd, T, pad_to):
-    """The NumPy oracle (a port of the reference's PyTorch CPU path) on ONE utterance of the workload, timed on
-    this box's host cores.  Bounded sample: ~10-30 s of CPU work."""
-    from oracle import zvx_oracle as O            # checker / baseline only -- never on the product path
-    from zerovox_amd import synthetic
-    from threadpoolctl import threadpool_limits
-    # OpenBLAS stops scaling on these skinny conv GEMMs: measured on the 256-thread GPU box, 8-16 threads are
-    # fastest and 64+ are 1.6x slower (tools/cpu_threads_probe.py), so the baseline is pinned to 16 threads.
-    cores = min(16, os.cpu_count() or 1)
-    ph, pu, spk, dur = synthetic.utterance(T, 0, "const7")
-    with threadpool_limits(limits=cores):
-        O.hifigan_generator(np.zeros((80, 8), np.float32), hsd, hcfg)      # BLAS thread-pool warm-up
+def src_sha16():
+    """Identity of the benched binary's sources: profiles/traffic.json must carry the same value to be quoted."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "zerovox_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h")):
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def exchange_comm_id(rank, world, make_id):
+    """rank 0's RCCL id -> every rank, through the TCPStore at MASTER_ADDR:MASTER_PORT (under torchrun that store is hosted
+    by the elastic agent; stand-alone, rank 0 hosts it).  Rendezvous plumbing only."""
+    from torch.distributed import TCPStore
+    addr, port = os.environ.get("MASTER_ADDR", "127.0.0.1"), int(os.environ.get("MASTER_PORT", "29500"))
+    agent = os.environ.get("TORCHELASTIC_USE_AGENT_STORE", "") == "True"
+    store = TCPStore(addr, port, world, is_master=(rank == 0 and not agent), wait_for_workers=False)
+    key = "zvx_comm_id/" + os.environ.get("TORCHELASTIC_RESTART_COUNT", "0")
+    if rank == 0:
+        store.set(key, make_id())
+    cid = bytes(store.get(key))
+    store.add(key + "/got", 1)
+    if rank == 0:                                  # keep a self-hosted store alive until everyone has read the id
         t0 = time.time()
-        out = O.inference_ex(sd, hsd, cfg, hcfg, ph, pu, spk, duration=dur, pad_to=pad_to)
-        dt = time.time() - t0
-    return {"value": len(out["wav"]) / dt, "unit": "samples/s", "cores": int(cores), "kind": "port",
-            "sample": f"1 utterance of the workload ({T} phonemes -> {out['mel_len']} frames -> {len(out['wav'])} "
-                      f"samples) through oracle/zvx_oracle.py (NumPy/BLAS fp32) in {dt:.1f} s",
-            "rtf_ref": (len(out["wav"]) / cfg["audio"]["sampling_rate"]) / dt}
+        while int(store.add(key + "/got", 0)) < world and time.time() - t0 < 120:
+            time.sleep(0.01)
+    return cid, store
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=32, help="utterances per GPU")
-    ap.add_argument("--phonemes", type=int, default=128)
-    ap.add_argument("--decoder", default="styletts", choices=["styletts", "fastspeech2"])
-    ap.add_argument("--vocoder", default="v1")
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "f32"])
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--profile", type=int, default=2, help="0 none, 1 stage events, 2 + per-launch GEMM events")
-    args = ap.parse_args()
-
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-
-    import torch
-    import torch.distributed as dist
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X (no CPU fallback on the product path)")
-    torch.cuda.set_device(local_rank)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-
-    from zerovox_amd import _lib, config as zcfg, pack, synthetic, weights as zw
-    from zerovox_amd.dist import gather_waveforms
-
+def default_ctx_factory(args, local_rank):
+    from zerovox_amd import _lib, config as zcfg, pack, weights as zw
     cfg = zcfg.medium_modelcfg(args.decoder)
     sd = zw.tts_state_dict(cfg, 0)
     hcfg = zcfg.hifigan_config(args.vocoder)
     hsd = zw.hifigan_state_dict(hcfg, 0)
     manifest, blob = pack.pack_model(cfg, sd, hcfg, hsd, args.precision)
-    ctx = _lib.Context(manifest, blob, local_rank)
+    return _lib.Context(manifest, blob, local_rank), (cfg, sd, hcfg, hsd)
 
-    B, T = args.batch, args.phonemes
-    ph, pu, Tlen, spk, dur = synthetic.batch(B, T, first_utt=rank * B, dur_mode="const7")
-    L = int(dur[0].sum())
+
+def cpu_baseline(config, model, T, pad_to):
+    """The NumPy oracle (a port of the reference's PyTorch CPU path) on a BOUNDED sample of the workload, timed on this box's
+    host cores (about 10-30 s).  Checker / baseline only -- never on the product path."""
+    from oracle import zvx_oracle as O
+    from zerovox_amd import synthetic
+    from threadpoolctl import threadpool_limits
+    cfg, sd, hcfg, hsd = model
+    cores = min(16, os.cpu_count() or 1)            # OpenBLAS stops scaling on these skinny conv GEMMs beyond ~16 threads
+    with threadpool_limits(limits=cores):
+        O.hifigan_generator(np.zeros((80, 8), np.float32), hsd, hcfg)      # BLAS thread-pool warm-up
+        t0 = time.time()
+        if config == 2:
+            ph, pu, spk, dur = synthetic.utterance(T, 0, "const7")
+            out = O.inference_ex(sd, hsd, cfg, hcfg, ph, pu, spk, duration=dur, pad_to=pad_to)
+            n, unit, what = len(out["wav"]), "samples/s", f"1 utterance of the workload ({T} phonemes -> {out['mel_len']} frames -> {len(out['wav'])} samples)"
+        elif config == 4:
+            mel = np.random.default_rng(7).standard_normal((80, 1024)).astype(np.float32)
+            n, unit, what = len(O.hifigan_generator(mel, hsd, hcfg)), "samples/s", "1 utterance of the workload (1024-frame mel -> 262144 samples)"
+        else:
+            mels = np.random.default_rng(8).standard_normal((4, 258, 80)).astype(np.float32)
+            for m in mels:
+                O.resnet_se34v2(m, sd, cfg)
+            n, unit, what = 4, "clips/s", "4 clips of the workload (258-frame mels)"
+        dt = time.time() - t0
+    return {"value": n / dt, "unit": unit, "cores": int(cores), "kind": "port",
+            "sample": f"{what} through oracle/zvx_oracle.py (NumPy/BLAS fp32) in {dt:.1f} s"}
+
+
+def main(argv=None, ctx_factory=default_ctx_factory):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", type=int, default=2, choices=[2, 4, 5])
+    ap.add_argument("--batch", type=int, default=None, help="units per GPU and step (default: 32 utterances / 50 clips)")
+    ap.add_argument("--phonemes", type=int, default=128)
+    ap.add_argument("--decoder", default="styletts", choices=["styletts", "fastspeech2"])
+    ap.add_argument("--vocoder", default="v1")
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--pcm16", action="store_true", help="int16 PCM waveform rows (halves the gather payload)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile", type=int, default=2, help="0 none, 1 stage events, 2 + per-launch events on the dominant kernel")
+    args = ap.parse_args(argv)
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world > 1 and args.config != 2:
+        raise SystemExit("configs 4 / 5 are single-GPU isolation benchmarks")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+    from zerovox_amd import synthetic
+    ctx, model = ctx_factory(args, local_rank)       # raises when libzvx.so / a GPU is missing: there is no CPU fallback
+    cfg = model[0]
     hop, sr = cfg["audio"]["hop_size"], cfg["audio"]["sampling_rate"]
-    N = L * hop
-    pad_to = np.full(B, max(689, L), np.int32)          # fresh-model semantics of model.py:331-335
-    wav = torch.zeros((B, N), dtype=torch.float32, device=f"cuda:{local_rank}")
-    lens_t = torch.full((B,), L, dtype=torch.int32, device=f"cuda:{local_rank}")
+    store = None
+    if world > 1:
+        cid, store = exchange_comm_id(rank, world, ctx.comm_unique_id)
+        ctx.comm_init(cid, rank, world)
+    else:
+        ctx.comm_init(None, 0, 1)
 
-    def step():
-        out = ctx.synthesize(ph, pu, Tlen, spk, dur, pad_to, want_mel=False, wav_device_ptr=wav.data_ptr(), wav_stride=N)
-        if world > 1:
-            gather_waveforms(wav, lens_t, dst=0)
-        return out
+    T = args.phonemes
+    ss = 2 if args.pcm16 else 4
+    wdt = np.int16 if args.pcm16 else np.float32
+    if args.config == 2:
+        B = args.batch or 32
+        ph, pu, Tlen, spk, dur = synthetic.batch(B, T, first_utt=rank * B, dur_mode="const7")
+        L = int(dur[0].sum()); N = L * hop
+        pad_to = np.full(B, max(689, L), np.int32)          # fresh-model semantics of model.py:331-335
+        row_bytes = N * ss
+        wav = [ctx.dev_alloc(B * row_bytes) for _ in range(2)]                       # double-buffered: the gather of step i overlaps step i + 1
+        gathered = ctx.dev_alloc(world * B * row_bytes) if (world > 1 and rank == 0) else 0
+        units_per_step, unit = B * N, "samples/s"
+        it = [0]
+
+        def step():
+            buf = wav[it[0] & 1]; it[0] += 1
+            ctx.synthesize(ph, pu, Tlen, spk, dur, pad_to, want_mel=False, wav_device_ptr=buf, wav_stride=N, no_sync=True, pcm16=args.pcm16)
+            if world > 1:
+                ctx.comm_gather(buf, B * row_bytes, gathered, root=0, no_sync=True)
+        workload = (f"batch={B}/GPU x {T}-phoneme utterances, precomputed spk-embed, forced durations=7 -> {L} frames -> {N} samples each; "
+                    f"tts_medium_{'styledec' if args.decoder == 'styletts' else 'fs2'} + HiFi-GAN {args.vocoder.upper()}, end-to-end phoneme->waveform"
+                    + (f", RCCL waveform gather ({'int16' if args.pcm16 else 'f32'}) to rank 0 each step" if world > 1 else ""))
+        cfg_extra = {"global_batch": B * world, "phonemes": T, "frames": L, "samples_per_utt": N, "decoder": args.decoder,
+                     "vocoder": args.vocoder, "pad_to": int(pad_to[0]), "wav_dtype": "int16" if args.pcm16 else "f32"}
+    elif args.config == 4:
+        B = args.batch or 32
+        P = 1024; N = P * hop
+        mel = np.random.default_rng(7).standard_normal((B, P, 80)).astype(np.float32)
+        mel_d = ctx.dev_alloc(mel.nbytes); ctx.dev_from_host(mel_d, mel)
+        wav = [ctx.dev_alloc(B * N * ss)]
+        Pn = np.full(B, P, np.int32)
+        units_per_step, unit = B * N, "samples/s"
+
+        def step():
+            ctx.vocode_mel_device(mel_d, Pn, P, wav[0], N, no_sync=True, pcm16=args.pcm16)
+        workload = f"HiFi-GAN {args.vocoder.upper()} generator alone: batch={B} x 1024-frame N(0,1) mels (seed 7, device-resident) -> {N} samples each"
+        cfg_extra = {"global_batch": B, "frames": P, "samples_per_utt": N, "vocoder": args.vocoder}
+    else:
+        B = args.batch or 50
+        Tr = 258
+        mels = np.random.default_rng(8).standard_normal((B, Tr, 80)).astype(np.float32)
+        mel_d = ctx.dev_alloc(mels.nbytes); ctx.dev_from_host(mel_d, mels)
+        emb_d = ctx.dev_alloc(B * ctx.hidden * 4)
+        lens = np.full(B, Tr, np.int32)
+        units_per_step, unit = B, "clips/s"
+
+        def step():
+            ctx.spkemb_device(mel_d, lens, B, Tr, emb_d, no_sync=True)
+        workload = (f"ResNetSE34V2 speaker encoder: batches of {B} device-resident 3 s reference mels [258, 80] "
+                    f"({args.steps} steps = {args.steps * B} clips; BASELINE configs[4] = 1000 clips = 20 steps of 50)")
+        cfg_extra = {"global_batch": B, "ref_frames": Tr}
 
     def fence():
-        if world > 1:
-            dist.barrier()
-        ctx.sync()
-        torch.cuda.synchronize()
+        ctx.comm_barrier()                            # drains both streams of every rank, then all ranks arrive (world 1: just the drain)
 
     for _ in range(args.warmup):
         step()
-    # One extra untimed step with per-launch events on every GEMM-family launch finds the dominant kernel variant; inside
-    # the timed region only that variant's launches carry events (each timed launch costs ~4 us of serialisation, so
-    # timing all ~130 launches of a step would take 2 % off `value`).
-    kstats_all = []
+    # One extra untimed step with events on every launch gives the per-stage roofline split and finds the dominant kernel
+    # variant; inside the timed region only that variant's launches carry events (each timed launch costs ~4 us).
+    kstats_all, tstats = [], []
     if args.profile >= 2:
+        fence()
         ctx.set_int("profile", 2)
+        ctx.set_int("profile_only", -1)
         ctx.reset_stats()
         step()
         fence()
-        kstats_all = ctx.kernel_stats()
+        kstats_all, tstats = ctx.kernel_stats(), ctx.tag_stats()
         if kstats_all:
             dom_name = max(kstats_all, key=lambda k: k["ms"])["name"]
             ctx.set_int("profile_only", ctx.get_int("variant_id:" + dom_name))
@@ -135,61 +219,83 @@ def main():
     stage_ms = ctx.stage_times()
     kstats = ctx.kernel_stats()
     ctx.set_int("profile", 0)
+    elapsed = ctx.comm_max(elapsed)                  # MAX over ranks
 
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    # sanity on the produced audio (not timed)
-    w = wav[0].cpu().numpy()
-    finite = bool(np.isfinite(w).all()) and float(np.abs(w).max()) <= 1.0 and float(np.abs(w).max()) > 0
+    # sanity on the produced data (not timed)
+    if args.config == 5:
+        e = ctx.dev_to_host(emb_d, (B, ctx.hidden), np.float32)
+        ok = bool(np.isfinite(e).all()) and float(np.abs(np.linalg.norm(e, axis=1) - 1).max()) < 1e-3
+    else:
+        if world > 1 and rank == 0:
+            g = ctx.dev_to_host(gathered, (world * B, N), wdt)
+            own = ctx.dev_to_host(wav[(it[0] - 1) & 1], (B, N), wdt)
+            ok = bool(np.array_equal(g[:B], own)) and all(bool(np.abs(g[r * B:(r + 1) * B].astype(np.float32)).max() > 0) for r in range(world))
+        else:
+            ok = True
+        w = ctx.dev_to_host(wav[0], (B, N), wdt)[0].astype(np.float32) / (32760.0 if args.pcm16 else 1.0)
+        ok = ok and bool(np.isfinite(w).all()) and 0 < float(np.abs(w).max()) <= 1.0
 
     if rank == 0:
-        total_samples = float(world) * B * N * args.steps
-        value = total_samples / elapsed
-        audio_s = total_samples / sr
+        total = float(world) * units_per_step * args.steps
+        value = total / elapsed
         res = {
-            "metric": "audio samples/sec + RTF, 128-phoneme zero-shot synth @22.05kHz, 1/2/4/8 GPU",
-            "value": value, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "metric": "audio samples/sec + RTF, 128-phoneme zero-shot synth @22.05kHz, 1/2/4/8 GPU" if args.config == 2 else
+                      ("audio samples/sec, HiFi-GAN generator alone (BASELINE configs[3])" if args.config == 4 else
+                       "speaker embeddings/sec, ResNetSE34V2 on 3 s reference mels (BASELINE configs[4])"),
+            "value": value, "unit": unit, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
-            "config": {"workload": f"batch={B}/GPU x {T}-phoneme utterances, precomputed spk-embed, forced durations=7 "
-                                   f"-> {L} frames -> {N} samples each; tts_medium_{'styledec' if args.decoder == 'styletts' else 'fs2'} "
-                                   f"+ HiFi-GAN {args.vocoder.upper()}, end-to-end phoneme->waveform"
-                                   + (", RCCL waveform gather to rank 0 each step" if world > 1 else ""),
-                       "global_batch": B * world, "phonemes": T, "frames": L, "samples_per_utt": N,
-                       "decoder": args.decoder, "vocoder": args.vocoder, "pad_to": int(pad_to[0])},
-            "rtf_ref_audio_s_per_s": audio_s / elapsed, "rtf_s_per_audio_s": elapsed / audio_s,
-            "stage_ms_last_step": stage_ms, "output_ok": finite,
+            "config": {"workload": workload, **cfg_extra},
+            "stage_ms_last_step": stage_ms, "output_ok": ok, "src_sha16": src_sha16(),
         }
+        if unit == "samples/s":
+            audio_s = total / sr
+            res["rtf_ref_audio_s_per_s"] = audio_s / elapsed
+            res["rtf_s_per_audio_s"] = elapsed / audio_s
         if kstats:
             dom = max(kstats, key=lambda k: k["ms"])
             avg_ms = dom["ms"] / dom["launches"]
             achieved = dom["flops"] / dom["launches"] / (avg_ms * 1e-3) / 1e12
-            peak = MFMA_PEAK[args.precision]
-            traffic = None
-            try:    # per-launch HBM bytes of this kernel from the committed rocprofv3 PMC passes of the same command
+            f32_dom = dom["name"].startswith("gemm_f32")
+            peak = MFMA_PEAK["f32" if (args.precision == "f32" or f32_dom) else "bf16"]
+            traffic = traffic_note = None
+            try:    # per-launch HBM bytes of this kernel from the rocprofv3 PMC passes of the SAME sources (tools/refresh_profiles.sh)
                 tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-                traffic = tj.get(dom["name"], {}).get("hbm_bytes_per_launch")
+                if tj.get("src_sha16") == res["src_sha16"] and tj.get("config", 2) == args.config:
+                    traffic = tj.get(dom["name"], {}).get("hbm_bytes_per_launch")
+                else:
+                    traffic_note = "profiles/traffic.json was collected on different sources/config: not quoted"
             except Exception:
-                pass
+                traffic_note = "profiles/traffic.json missing"
             res["roofline"] = {"bound": "mfma", "kernel": dom["name"], "achieved": achieved, "peak": peak,
                                "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
                                "launches": dom["launches"], "avg_launch_ms": avg_ms,
                                "flops_per_launch": dom["flops"] / dom["launches"],
                                "alg_bytes_per_launch": dom["bytes"] / dom["launches"],
                                "alg_GBps": dom["bytes"] / (dom["ms"] * 1e-3) / 1e9}
-            # per-variant split of ONE (untimed, fully instrumented) step, for orientation
+            if traffic_note:
+                res["roofline"]["traffic_note"] = traffic_note
+            # per-variant and per-stage split of ONE (untimed, fully instrumented) step
             res["kernels_one_step"] = [{"name": k["name"], "launches": k["launches"], "ms": round(k["ms"], 3),
                                         "TFLOPs": round(k["flops"] / (k["ms"] * 1e-3) / 1e12, 2) if k["ms"] > 0 else None}
                                        for k in sorted(kstats_all, key=lambda k: -k["ms"])]
+            per_stage = []
+            for t in sorted(tstats, key=lambda t: -t["ms"]):
+                if t["ms"] <= 0:
+                    continue
+                pk = MFMA_PEAK["f32" if (args.precision == "f32" or t["name"] in F32_STAGES) else "bf16"]
+                tf, gb = t["flops"] / (t["ms"] * 1e-3) / 1e12, t["bytes"] / (t["ms"] * 1e-3) / 1e9
+                per_stage.append({"stage": t["name"], "launches": t["launches"], "ms": round(t["ms"], 4), "TFLOPs": round(tf, 2),
+                                  "alg_GBps": round(gb, 1), "frac_mfma": round(tf / pk, 4), "frac_hbm": round(gb / HBM_PEAK_GBS, 4),
+                                  "mfma_peak": pk})
+            res["roofline_per_stage"] = per_stage
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(cfg, sd, hcfg, hsd, T, int(pad_to[0]))
+            res["cpu_baseline"] = cpu_baseline(args.config, model, T, 896 if args.config == 2 else 0)
         print(json.dumps(res), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
+    fence()
+    ctx.close()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -42,6 +42,7 @@ enum {
 enum {                   /* flags */
     ZVX_DEVICE_OUT = 1,  /* wav (and mel, if given) output pointers are device pointers */
     ZVX_NO_SYNC = 2,     /* do not hipStreamSynchronize before returning (device outputs only) */
+    ZVX_DEVICE_IN = 8,   /* the bulk input (zvx_vocode_mel: mel, zvx_spkemb_ex: ref_mels) is a device pointer */
     ZVX_PCM16 = 4        /* wav rows are int16 PCM: (int16)(sample * 32760), truncated like numpy astype (demo.py:29-35,
                             model.py:44-63); halves the bytes of the multi-GPU waveform gather.  wav_stride stays in samples */
 };
@@ -69,6 +70,8 @@ zvx_status zvx_set_int(zvx_ctx* ctx, const char* key, int64_t value);
  * Replaces ResNetSE34V2.forward (ResNetSE34V2.py:176-212) as called by ZeroVoxTTS.speaker_embed
  * (synthesize.py:139-141). */
 zvx_status zvx_spkemb(zvx_ctx* ctx, const float* ref_mels, const int32_t* lens, int B, int Tmax, float* out);
+/* same with flags: ZVX_DEVICE_IN (ref_mels on the device), ZVX_DEVICE_OUT (out on the device), ZVX_NO_SYNC */
+zvx_status zvx_spkemb_ex(zvx_ctx* ctx, const float* ref_mels, const int32_t* lens, int B, int Tmax, float* out, int flags);
 
 /* Log-mel front end of reference audio: wav [B][Nmax] f32 in [-1, 1] with nsamples[b] valid samples ->
  * mel [B][Tmax][n_mels] = log(clip(mel_basis . |STFT|, 1e-5)) (reflect padding (n_fft-hop)/2, hann window, center=False)
@@ -120,6 +123,32 @@ zvx_status zvx_synthesize(zvx_ctx* ctx, const int32_t* phoneme, const int32_t* p
  *       "mel" [B][Lmax][n_mels], "pitch_idx"/"energy_idx"/"duration" [B][Tmax] (as float). */
 zvx_status zvx_fetch(zvx_ctx* ctx, const char* what, float* out, size_t out_floats);
 
+/* ---- multi-GPU: utterances shard across ranks with no data-path exchange; the ONE collective is the gather of the
+ * finished waveform rows to one rank, issued here directly on RCCL (grouped ncclSend / ncclRecv: every peer -> root
+ * transfer rides its own xGMI link).  The reference has no distributed layer; one process per GPU,
+ * one context per process.  librccl.so is dlopen'ed by zvx_comm_unique_id / zvx_comm_init only. ---- */
+#define ZVX_COMM_ID_BYTES 128
+/* rank 0 creates the communicator id (ncclGetUniqueId) and ships the 128 bytes to the other ranks out of band */
+zvx_status zvx_comm_unique_id(void* id_out);
+zvx_status zvx_comm_init(zvx_ctx* ctx, const void* id, int rank, int world);
+/* Every rank contributes `bytes` bytes at device pointer `local`; rank `root` receives them in rank order at device
+ * pointer `recv` (world * bytes; ignored elsewhere).  Enqueued on the context's communication stream behind everything
+ * issued so far on its compute stream, so with ZVX_NO_SYNC it overlaps the next synthesis call; a later
+ * ZVX_DEVICE_OUT synthesis into `local` waits on the device for this gather to have read it.  world == 1: a copy. */
+zvx_status zvx_comm_gather(zvx_ctx* ctx, const void* local, size_t bytes, void* recv, int root, int flags);
+/* all ranks: returns after every rank has drained both of its streams and arrived (ncclAllReduce of one word) */
+zvx_status zvx_comm_barrier(zvx_ctx* ctx);
+/* *value = max over ranks (bench.py: MAX-over-ranks elapsed time) */
+zvx_status zvx_comm_max_f64(zvx_ctx* ctx, double* value);
+void       zvx_comm_destroy(zvx_ctx* ctx);
+
+/* Device buffers for ZVX_DEVICE_OUT outputs / zvx_comm_gather without any other GPU runtime in the process. */
+zvx_status zvx_dev_alloc(zvx_ctx* ctx, size_t bytes, void** out);
+zvx_status zvx_dev_free(zvx_ctx* ctx, void* p);
+zvx_status zvx_dev_from_host(zvx_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
+zvx_status zvx_dev_to_host(zvx_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
+
+/* drains the compute AND the communication stream */
 zvx_status zvx_sync(zvx_ctx* ctx);
 zvx_status zvx_stage_times(zvx_ctx* ctx, float ms[ZVX_T_COUNT]);
 
@@ -133,6 +162,10 @@ typedef struct {
     double bytes;
 } zvx_kernel_stat;
 int        zvx_kernel_stats(zvx_ctx* ctx, zvx_kernel_stat* out, int max_out);
+/* The same counters grouped by pipeline stage ("encoder", "variance", "lenreg", "decoder", "decoder.norm", "voc.pre",
+ * "voc.up1".."voc.res4", "voc.post", "spkemb"; name = stage): every launch of the stage, including the HBM-bound helper
+ * kernels, while "profile" == 2 and "profile_only" == -1.  Feeds the per-stage roofline fractions of bench.py. */
+int        zvx_tag_stats(zvx_ctx* ctx, zvx_kernel_stat* out, int max_out);
 zvx_status zvx_reset_stats(zvx_ctx* ctx);
 
 #ifdef __cplusplus

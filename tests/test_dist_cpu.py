@@ -1,4 +1,13 @@
-"""world_size-2 gloo test of the multi-GPU path: utterance sharding + the single waveform gather."""
+"""world_size-2 tests of the multi-GPU path on CPU.
+
+1. `shard_range` + the host/gloo `gather_waveforms` transport (zerovox_amd/dist.py).
+2. bench.py's OWN control flow for N > 1 -- env parsing, the RCCL-id rendezvous through the TCPStore, the double-buffered
+   synthesize -> gather step, barrier / MAX-over-ranks timing, rank 0's JSON line -- driven through `bench.main` with a stub
+   context: the stub implements the libzvx calls bench.py makes (synthesize into "device" buffers, comm_init / comm_gather /
+   comm_barrier / comm_max, dev_alloc / dev_to_host) on host memory with gloo as the transport, so everything except the
+   kernels and RCCL itself is the code the driver runs on 8 GPUs.
+"""
+import json
 import os
 import sys
 
@@ -34,17 +43,136 @@ def _worker(rank, world, port, B_total, N, q):
     dist.destroy_process_group()
 
 
-def test_shard_and_gather_world2_equals_single_rank():
-    B_total, N, world = 8, 16, 2
+def _spawn(target, world, extra):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 29500 + (os.getpid() % 2000)
-    procs = [ctx.Process(target=_worker, args=(r, world, port, B_total, N, q)) for r in range(world)]
+    procs = [ctx.Process(target=target, args=(r, world, port) + extra + (q,)) for r in range(world)]
     for p in procs:
         p.start()
-    gw, gl = q.get(timeout=120)
+    out = q.get(timeout=180)
     for p in procs:
-        p.join(timeout=120)
+        p.join(timeout=180)
         assert p.exitcode == 0
+    return out
+
+
+def test_shard_and_gather_world2_equals_single_rank():
+    B_total, N, world = 8, 16, 2
+    gw, gl = _spawn(_worker, world, (B_total, N))
     ref_w, ref_l = _fake_synth(0, B_total, N)
     assert np.array_equal(gw, ref_w.numpy()) and np.array_equal(gl, ref_l.numpy())
+
+
+# ------------------------------------------------------------------------------------------------
+# bench.py control flow with a stub context
+# ------------------------------------------------------------------------------------------------
+class StubContext:
+    """Host-memory stand-in for zerovox_amd._lib.Context with gloo as the gather transport."""
+    hidden, n_mels, hop = 528, 80, 256
+
+    def __init__(self):
+        self._bufs, self._next, self.calls = {}, 1, []
+        self.rank, self.world = 0, 1
+
+    # device memory
+    def dev_alloc(self, nbytes):
+        p = self._next; self._next += 1
+        self._bufs[p] = np.zeros(nbytes, np.uint8)
+        return p
+
+    def dev_to_host(self, ptr, shape, dtype):
+        return self._bufs[ptr][: int(np.prod(shape)) * np.dtype(dtype).itemsize].view(dtype).reshape(shape).copy()
+
+    # synthesis: row b of the shard = (first utterance id + b + 1) / 1000 everywhere (a pure function of the global index)
+    def synthesize(self, ph, pu, T, spk, dur, pad_to, want_mel=True, wav_device_ptr=None, wav_stride=None, no_sync=False, pcm16=False):
+        B = ph.shape[0]
+        ids = self._first + np.arange(B, dtype=np.float32)
+        self._bufs[wav_device_ptr].view(np.float32).reshape(B, wav_stride)[:] = ((ids + 1) / 1000.0)[:, None]
+        self.calls.append(("synthesize", wav_device_ptr))
+
+    @staticmethod
+    def comm_unique_id():
+        return bytes(range(128))
+
+    def comm_init(self, cid, rank, world):
+        assert world == 1 or cid == bytes(range(128)), "every rank must receive rank 0's id"
+        self.rank, self.world = rank, world
+        if world > 1:
+            dist.init_process_group("gloo", rank=rank, world_size=world,
+                                    init_method=f"tcp://127.0.0.1:{int(os.environ['MASTER_PORT']) + 1}")
+
+    def comm_gather(self, local_ptr, nbytes, recv_ptr, root=0, no_sync=False):
+        local = torch.from_numpy(self._bufs[local_ptr][:nbytes])
+        if self.rank == root:
+            parts = list(torch.from_numpy(self._bufs[recv_ptr])[: self.world * nbytes].split(nbytes))
+            dist.gather(local, parts, dst=root)
+        else:
+            dist.gather(local, None, dst=root)
+        self.calls.append(("gather", local_ptr))
+
+    def comm_barrier(self):
+        if self.world > 1:
+            dist.barrier()
+
+    def comm_max(self, v):
+        if self.world == 1:
+            return v
+        t = torch.tensor([v], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    # profiling surface (nothing to report)
+    def set_int(self, *a): pass
+    def get_int(self, *a): return -1
+    def reset_stats(self): pass
+    def kernel_stats(self): return []
+    def tag_stats(self): return []
+    def stage_times(self): return {}
+    def sync(self): pass
+
+    def close(self):
+        if self.world > 1:
+            dist.destroy_process_group()
+
+
+def _bench_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import contextlib, io
+    import bench
+    from zerovox_amd import config as zcfg
+    stub = StubContext()
+    stub._first = rank * 4
+
+    def factory(args, local_rank):
+        assert local_rank == rank
+        return stub, (zcfg.medium_modelcfg("styletts"), None, None, None)
+
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        rc = bench.main(["--gpus", str(world), "--steps", "3", "--warmup", "1", "--batch", "4", "--phonemes", "8", "--profile", "0",
+                         "--no-cpu-baseline"], ctx_factory=factory)
+    assert rc == 0
+    # double buffering: consecutive steps alternate between the two waveform buffers, every step is followed by its gather
+    synth = [c for c in stub.calls if c[0] == "synthesize"]
+    gath = [c for c in stub.calls if c[0] == "gather"]
+    assert len(synth) == 4 and len(gath) == 4 and [s[1] for s in synth] == [g[1] for g in gath]
+    assert synth[0][1] != synth[1][1] and synth[0][1] == synth[2][1]
+    if rank == 0:
+        q.put(buf.getvalue())
+    else:
+        assert buf.getvalue() == ""                     # only rank 0 prints
+
+
+def test_bench_control_flow_world2_with_stub_context():
+    out = _spawn(_bench_worker, 2, ())
+    lines = [l for l in out.splitlines() if l.strip()]
+    assert len(lines) == 1                              # ONE JSON line
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["steps"] == 3 and r["warmup"] == 1 and r["scaling"] == "weak" and r["unit"] == "samples/s"
+    assert r["config"]["global_batch"] == 8 and r["config"]["samples_per_utt"] == 8 * 7 * 256
+    assert r["output_ok"] is True                       # rank 0 checked: its own rows landed first, rank 1's rows are present
+    total = 2 * 4 * r["config"]["samples_per_utt"] * 3
+    assert abs(r["value"] * r["ms_per_step"] * 1e-3 * 3 - total) < 1e-6 * total
+    assert r["higher_is_better"] is True and r["vs_baseline"] is None

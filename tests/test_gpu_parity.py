@@ -532,3 +532,31 @@ def test_streaming_resblock_kernels_equal_per_pair_launches(voc):
             assert np.isfinite(got).all() and np.array_equal(got, ref), (voc, B, Pmax)
     finally:
         ctx.set_int("resstream", 1)
+
+
+def test_rccl_gather_path_on_a_one_rank_communicator():
+    """The multi-GPU gather inside libzvx (dlopen of librccl, ncclCommInitRank, grouped ncclSend/ncclRecv on the communication
+    stream, the device-side fence that orders a later synthesis behind the gather) exercised on ONE GPU through a real
+    one-rank communicator; the 8-GPU run itself belongs to the driver."""
+    cfg, sd = tts_sd("styletts")
+    h, hsd = voc_sd("tiny")
+    man, blob = pack.pack_model(cfg, sd, h, hsd, "bf16")
+    ctx = _lib.Context(man, blob, 0)
+    try:
+        cid = _lib.Context.comm_unique_id()
+        assert len(cid) == 128 and any(cid)
+        ctx.comm_init(cid, 0, 1)
+        ph, pu, T, spk, dur = synthetic.batch(3, 10, 0, "uniform")
+        L = int(dur.sum(axis=1).max()); N = L * 256
+        ref = ctx.synthesize(ph, pu, T, spk, dur, np.full(3, 64, np.int32), want_mel=False)["wav"]
+        wav_d, recv_d = ctx.dev_alloc(3 * N * 4), ctx.dev_alloc(3 * N * 4)
+        for _ in range(3):                                                   # repeated: the next synthesis into wav_d queues behind the gather
+            ctx.synthesize(ph, pu, T, spk, dur, np.full(3, 64, np.int32), want_mel=False, wav_device_ptr=wav_d, wav_stride=N, no_sync=True)
+            ctx.comm_gather(wav_d, 3 * N * 4, recv_d, root=0, no_sync=True)
+        ctx.comm_barrier()
+        got = ctx.dev_to_host(recv_d, (3, N), np.float32)
+        assert np.array_equal(got, ref)
+        assert ctx.comm_max(1.25) == 1.25
+        ctx.dev_free(wav_d); ctx.dev_free(recv_d)
+    finally:
+        ctx.close()

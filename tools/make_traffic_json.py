@@ -12,6 +12,7 @@ NAMES = {  # rocprof kernel name pattern -> bench variant name
     r"resfuse_persist_kernel<128,": "resfuse_bf16_c128", r"gemm_kernel<0, 64, 64": "gemm_f32_64x64", r"gemm_kernel<1, 64, 64": "gemm_bf16_64x64",
     r"convreg_kernel<64,": "convreg_bf16_c64", r"convreg_kernel<32,": "convreg_bf16_c32",
     r"gemm_kernel<1, 128, 128": "gemm_bf16_128x128", r"gemm_kernel<0, 128, 128": "gemm_f32_128x128",
+    r"resstream_kernel<32,": "resstream_bf16_c32", r"resstream_kernel<64,": "resstream_bf16_c64",
 }
 
 
@@ -31,5 +32,8 @@ for name in fetch:
     n, f = fetch[name]; w = write.get(name, [n, 0.0])[1]
     res[name] = {"launches": n, "fetch_KiB_per_launch_raw": f / n, "write_KiB_per_launch": w / n,
                  "hbm_bytes_per_launch": (2 * f + w) * 1024 / n}
-json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on `python bench.py --steps 3 --warmup 1`", **res}, open(sys.argv[3], "w"), indent=1)
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
+from bench import src_sha16
+json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on `python bench.py --steps 3 --warmup 1 --no-cpu-baseline`",
+           "src_sha16": src_sha16(), "config": int(sys.argv[4]) if len(sys.argv) > 4 else 2, **res}, open(sys.argv[3], "w"), indent=1)
 print(json.dumps(res, indent=1))

@@ -12,13 +12,16 @@ LIB_PATH = os.path.join(HERE, "libzvx.so")
 
 ZVX_OK = 0
 ZVX_E_INVALID, ZVX_E_MANIFEST, ZVX_E_HIP, ZVX_E_STATE, ZVX_E_BUFFER, ZVX_E_UNSUPPORTED = 1, 2, 3, 4, 5, 6
-ZVX_DEVICE_OUT, ZVX_NO_SYNC, ZVX_PCM16 = 1, 2, 4
+ZVX_DEVICE_OUT, ZVX_NO_SYNC, ZVX_PCM16, ZVX_DEVICE_IN = 1, 2, 4, 8
 STAGES = ("encoder", "variance", "lenreg", "decoder", "vocoder", "spkemb")
 ZVX_T_COUNT = 8
 
 EXPORTS = ("zvx_create", "zvx_destroy", "zvx_last_error", "zvx_get_int", "zvx_set_int", "zvx_spkemb", "zvx_melspec", "zvx_encode",
            "zvx_decode", "zvx_decode_features", "zvx_vocode", "zvx_vocode_mel", "zvx_synthesize", "zvx_fetch",
-           "zvx_sync", "zvx_stage_times", "zvx_kernel_stats", "zvx_reset_stats")
+           "zvx_sync", "zvx_stage_times", "zvx_kernel_stats", "zvx_tag_stats", "zvx_reset_stats",
+           "zvx_comm_unique_id", "zvx_comm_init", "zvx_comm_gather", "zvx_comm_barrier", "zvx_comm_max_f64", "zvx_comm_destroy",
+           "zvx_dev_alloc", "zvx_dev_free", "zvx_dev_from_host", "zvx_dev_to_host", "zvx_spkemb_ex")
+ZVX_COMM_ID_BYTES = 128
 
 
 class ZvxError(RuntimeError):
@@ -67,6 +70,19 @@ def load():
     lib.zvx_stage_times.argtypes = [vp, vp]
     lib.zvx_kernel_stats.argtypes = [vp, C.POINTER(KernelStat), C.c_int]
     lib.zvx_reset_stats.argtypes = [vp]
+    lib.zvx_tag_stats.argtypes = [vp, C.POINTER(KernelStat), C.c_int]
+    lib.zvx_comm_unique_id.argtypes = [vp]
+    lib.zvx_comm_init.argtypes = [vp, vp, C.c_int, C.c_int]
+    lib.zvx_comm_gather.argtypes = [vp, vp, C.c_size_t, vp, C.c_int, C.c_int]
+    lib.zvx_comm_barrier.argtypes = [vp]
+    lib.zvx_comm_max_f64.argtypes = [vp, C.POINTER(C.c_double)]
+    lib.zvx_comm_destroy.argtypes = [vp]
+    lib.zvx_comm_destroy.restype = None
+    lib.zvx_dev_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
+    lib.zvx_dev_free.argtypes = [vp, vp]
+    lib.zvx_dev_to_host.argtypes = [vp, vp, vp, C.c_size_t]
+    lib.zvx_dev_from_host.argtypes = [vp, vp, vp, C.c_size_t]
+    lib.zvx_spkemb_ex.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp, C.c_int]
     _lib = lib
     return lib
 
@@ -250,5 +266,70 @@ class Context:
         return [dict(name=arr[i].name.decode(), launches=int(arr[i].launches), ms=float(arr[i].ms),
                      flops=float(arr[i].flops), bytes=float(arr[i].bytes)) for i in range(n)]
 
+    def tag_stats(self):
+        """per pipeline stage: launches, ms, algorithmic FLOPs and bytes (profile 2, profile_only -1)"""
+        arr = (KernelStat * 64)()
+        n = self._lib.zvx_tag_stats(self._h, arr, 64)
+        return [dict(name=arr[i].name.decode(), launches=int(arr[i].launches), ms=float(arr[i].ms),
+                     flops=float(arr[i].flops), bytes=float(arr[i].bytes)) for i in range(n)]
+
     def reset_stats(self):
         self._chk(self._lib.zvx_reset_stats(self._h))
+
+    # ---- device buffers + the multi-GPU waveform gather (RCCL inside libzvx; no torch) ----------------------------
+    def dev_alloc(self, nbytes: int) -> int:
+        p = C.c_void_p()
+        self._chk(self._lib.zvx_dev_alloc(self._h, int(nbytes), C.byref(p)))
+        return int(p.value)
+
+    def dev_free(self, ptr: int):
+        self._chk(self._lib.zvx_dev_free(self._h, C.c_void_p(int(ptr))))
+
+    def dev_from_host(self, ptr: int, arr):
+        arr = np.ascontiguousarray(arr)
+        self._chk(self._lib.zvx_dev_from_host(self._h, C.c_void_p(int(ptr)), _ptr(arr), arr.nbytes))
+
+    def spkemb_device(self, mels_ptr: int, lens, B: int, Tmax: int, out_ptr: int, no_sync=False):
+        """speaker encoder on device-resident mels [B][Tmax][n_mels] -> device embeddings [B][hidden]"""
+        lens = _i32(lens, (B,))
+        self._chk(self._lib.zvx_spkemb_ex(self._h, C.c_void_p(int(mels_ptr)), _ptr(lens), B, Tmax, C.c_void_p(int(out_ptr)),
+                                          ZVX_DEVICE_IN | ZVX_DEVICE_OUT | (ZVX_NO_SYNC if no_sync else 0)))
+
+    def vocode_mel_device(self, mel_ptr: int, P, Pmax: int, wav_ptr: int, wav_stride: int, no_sync=False, pcm16=False):
+        """stand-alone vocoder on a device-resident mel [B][Pmax][n_mels] -> device waveform rows"""
+        P = _i32(P)
+        self._chk(self._lib.zvx_vocode_mel(self._h, C.c_void_p(int(mel_ptr)), _ptr(P), len(P), int(Pmax), C.c_void_p(int(wav_ptr)), int(wav_stride),
+                                           ZVX_DEVICE_IN | ZVX_DEVICE_OUT | (ZVX_NO_SYNC if no_sync else 0) | (ZVX_PCM16 if pcm16 else 0)))
+
+    def dev_to_host(self, ptr: int, shape, dtype):
+        out = np.empty(shape, dtype)
+        self._chk(self._lib.zvx_dev_to_host(self._h, _ptr(out), C.c_void_p(int(ptr)), out.nbytes))
+        return out
+
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        """rank 0: a fresh RCCL communicator id (128 bytes) to hand to every rank's comm_init."""
+        lib = load()
+        buf = C.create_string_buffer(ZVX_COMM_ID_BYTES)
+        rc = lib.zvx_comm_unique_id(buf)
+        if rc != ZVX_OK:
+            raise ZvxError(rc, lib.zvx_last_error(None).decode())
+        return buf.raw
+
+    def comm_init(self, comm_id, rank: int, world: int):
+        buf = C.create_string_buffer(bytes(comm_id), ZVX_COMM_ID_BYTES) if comm_id is not None else None
+        self._chk(self._lib.zvx_comm_init(self._h, buf, int(rank), int(world)))
+        self.rank, self.world = int(rank), int(world)
+
+    def comm_gather(self, local_ptr: int, nbytes: int, recv_ptr, root: int = 0, no_sync: bool = False):
+        self._chk(self._lib.zvx_comm_gather(self._h, C.c_void_p(int(local_ptr)), int(nbytes),
+                                            C.c_void_p(int(recv_ptr)) if recv_ptr else None, int(root),
+                                            ZVX_NO_SYNC if no_sync else 0))
+
+    def comm_barrier(self):
+        self._chk(self._lib.zvx_comm_barrier(self._h))
+
+    def comm_max(self, value: float) -> float:
+        v = C.c_double(float(value))
+        self._chk(self._lib.zvx_comm_max_f64(self._h, C.byref(v)))
+        return float(v.value)

@@ -6,7 +6,9 @@
 #include "../../include/zvx.h"
 #include "zvx_kernels.h"
 
+#include <dlfcn.h>
 #include <math.h>
+#include <rccl/rccl.h>          // types and prototypes only: the library is dlopen'ed by zvx_comm_* (single-GPU use never loads it)
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
@@ -47,13 +49,19 @@ struct Tensor {
 
 struct DevBuf { void* p = nullptr; void* base = nullptr; size_t cap = 0; };
 
-struct GemmEvent { hipEvent_t a, b; int variant; double flops, bytes; long rows; int N, K, taps, res, fused; };
+struct GemmEvent { hipEvent_t a, b; int variant; double flops, bytes; long rows; int N, K, taps, res, fused; std::string tag; };
 
 }  // namespace
 
 struct zvx_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    // multi-GPU (zvx_comm_*): communicator, its own stream, and per-buffer "the gather has read this" events
+    hipStream_t comm_stream = nullptr;
+    ncclComm_t comm = nullptr;
+    int rank = 0, world = 1;
+    hipEvent_t ev_compute = nullptr;
+    std::map<const void*, hipEvent_t> gather_fence;
     std::string err;
     std::map<std::string, std::string> cfg;
     std::map<std::string, Tensor> tensors;
@@ -84,6 +92,8 @@ struct zvx_ctx {
     float stage_ms[ZVX_T_COUNT];
     std::vector<GemmEvent> pending;
     std::vector<zvx_kernel_stat> stats;
+    std::string tag = "other";             // stage label of the launches being issued (per-stage roofline accounting, profile 2)
+    std::map<std::string, zvx_kernel_stat> tagstats;
     std::vector<hipEvent_t> event_pool;
 
     // ------------------------------------------------------------------ helpers
@@ -149,8 +159,12 @@ struct zvx_ctx {
         if (prof) {
             ev.variant = id; ev.flops = a.flops; ev.rows = (long)a.M * a.nbatch * a.nheads; ev.N = a.N; ev.K = a.K; ev.taps = a.ntaps; ev.res = a.res_mode; ev.fused = a.fused;
             const double esz = dtype_size(a.dtype);
-            ev.bytes = ((double)a.M * a.nbatch * a.nheads) * ((double)a.K * esz + (double)a.N * dtype_size(a.out_dtype)) +
-                       (double)a.N * a.K * a.ntaps * esz;
+            // algorithmic bytes: input rows + weights + everything the epilogue reads and writes (output, residual, running sum)
+            const double cells = (double)a.M * a.nbatch * a.nheads * a.N;
+            ev.bytes = ((double)a.M * a.nbatch * a.nheads) * (double)a.K * esz * (a.fused ? 1 : 1) + (double)a.N * a.K * a.ntaps * esz * (a.fused ? 2 : 1) +
+                       (a.out ? cells * dtype_size(a.out_dtype) : 0.0) + ((a.res_mode && !a.fused) ? cells * dtype_size(a.res_dtype) : 0.0) +
+                       ((a.accum && (a.accum_mode & 1)) ? cells * dtype_size(a.accum_dtype) : 0.0) + ((a.accum && (a.accum_mode & 2)) ? cells * dtype_size(a.accum_dtype) : 0.0);
+            ev.tag = tag;
             pending.push_back(ev);
         }
     }
@@ -169,9 +183,19 @@ struct zvx_ctx {
             ev.variant = id2; ev.flops = 2.0 * 2.0 * a.npair * rows * a.C * a.C * a.ntaps; ev.rows = (long)rows; ev.N = a.C; ev.K = a.C; ev.taps = a.ntaps;
             ev.res = a.accum_mode; ev.fused = 10 + a.npair;
             ev.bytes = rows * a.C * 2.0 * (1 + (a.out ? 1 : 0) + ((a.accum && (a.accum_mode & 1)) ? 1 : 0) + ((a.accum && (a.accum_mode & 2)) ? 1 : 0));
+            ev.tag = tag;
             pending.push_back(ev);
         }
         return true;
+    }
+    // the HBM-bound helpers (norms, gathers, conv_post ...): event-timed as a group when every launch is being profiled
+    template <typename F>
+    void timed(double flops, double bytes, F&& f) {
+        const bool prof = profile >= 2 && profile_only < 0;
+        GemmEvent ev{};
+        if (prof) { ev.a = new_event(); ev.b = new_event(); HIPCHK(hipEventRecord(ev.a, stream)); }
+        f();
+        if (prof) { HIPCHK(hipEventRecord(ev.b, stream)); ev.variant = -1; ev.flops = flops; ev.bytes = bytes; ev.tag = tag; pending.push_back(ev); }
     }
     void resolve_events() {
         if (stats.empty()) {
@@ -181,17 +205,23 @@ struct zvx_ctx {
         for (auto& e : pending) {
             float ms = 0.f;
             HIPCHK(hipEventElapsedTime(&ms, e.a, e.b));
-            if (shape_log) fprintf(stderr, "launch %-24s rows=%-8ld N=%-4d K=%-4d taps=%-2d res=%d fused=%d  %8.3f ms %8.1f TF/s %8.1f GB/s(alg)\n",
+            if (shape_log && e.variant >= 0) fprintf(stderr, "launch %-24s rows=%-8ld N=%-4d K=%-4d taps=%-2d res=%d fused=%d  %8.3f ms %8.1f TF/s %8.1f GB/s(alg)\n",
                                    gemm_variant_name(e.variant), e.rows, e.N, e.K, e.taps, e.res, e.fused, ms, e.flops / ms / 1e9, e.bytes / ms / 1e6);
-            auto& s = stats[e.variant];
-            s.launches++; s.ms += ms; s.flops += e.flops; s.bytes += e.bytes;
+            if (e.variant >= 0) { auto& s = stats[e.variant]; s.launches++; s.ms += ms; s.flops += e.flops; s.bytes += e.bytes; }
+            auto& ts = tagstats[e.tag];
+            if (!ts.name[0]) snprintf(ts.name, 64, "%s", e.tag.c_str());
+            ts.launches++; ts.ms += ms; ts.flops += e.flops; ts.bytes += e.bytes;
             event_pool.push_back(e.a); event_pool.push_back(e.b);
         }
         pending.clear();
         for (int s = 0; s < ZVX_T_COUNT; s++)
             if (stage_used[s]) { float ms = 0.f; HIPCHK(hipEventElapsedTime(&ms, stage_ev[s][0], stage_ev[s][1])); stage_ms[s] = ms; stage_used[s] = false; }
     }
-    void sync() { HIPCHK(hipStreamSynchronize(stream)); if (profile) resolve_events(); }
+    void sync() {
+        HIPCHK(hipStreamSynchronize(stream));
+        if (comm_stream) HIPCHK(hipStreamSynchronize(comm_stream));
+        if (profile) resolve_events();
+    }
 };
 
 namespace {
@@ -362,7 +392,7 @@ void fft_block(zvx_ctx* c, void* x, int dt, int B, int Lmax, const int* len_dev,
         a.flops = 2.0 * B * nheads * (double)Lmax * Lmax * d;
         c->gemm(a);
     }
-    launch_softmax_rows(sc, Lp, P, dt, Lp, B, nheads, Lmax, len_dev, c->stream);      // fs2.py:52-55
+    c->timed(0, (double)B * nheads * Lmax * Lp * (4.0 + es), [&] { launch_softmax_rows(sc, Lp, P, dt, Lp, B, nheads, Lmax, len_dev, c->stream); });      // fs2.py:52-55
     {   // O = P V                                                      fs2.py:56
         GemmArgs a = gemm_base(dt);
         a.X = P; a.x_bs = (long)nheads * Lmax * Lp; a.x_hs = (long)Lmax * Lp; a.ldx = Lp;
@@ -381,8 +411,11 @@ void fft_block(zvx_ctx* c, void* x, int dt, int B, int Lmax, const int* len_dev,
         a.out = y; a.out_dtype = DT_F32; a.o_bs = (long)Lmax * H; a.ldo = H;
         c->gemm(a);
     }
-    if (w.scln) launch_layernorm(y, DT_F32, H, x, dt, H, B, Lmax, len_dev, H, 1, 1e-8f, nullptr, nullptr, w.bg, w.bg_bs, nullptr, c->stream);
-    else launch_layernorm(y, DT_F32, H, x, dt, H, B, Lmax, len_dev, H, 0, 1e-5f, c->pf(w.p + ".ln1_g"), c->pf(w.p + ".ln1_b"), nullptr, 0, nullptr, c->stream);
+    const double ln_bytes = (double)B * Lmax * H * (4.0 + es);
+    c->timed(0, ln_bytes, [&] {
+        if (w.scln) launch_layernorm(y, DT_F32, H, x, dt, H, B, Lmax, len_dev, H, 1, 1e-8f, nullptr, nullptr, w.bg, w.bg_bs, nullptr, c->stream);
+        else launch_layernorm(y, DT_F32, H, x, dt, H, B, Lmax, len_dev, H, 0, 1e-5f, c->pf(w.p + ".ln1_g"), c->pf(w.p + ".ln1_b"), nullptr, 0, nullptr, c->stream);
+    });
     {   // h = relu(conv_k9(x))                                         fs2.py:198-200
         GemmArgs a = gemm_base(dt);
         a.X = x; a.x_bs = (long)Lmax * H; a.ldx = H; a.W = c->t(w.p + ".w1").dev; a.ldw = H; a.w_ts = (long)F * H;
@@ -402,8 +435,10 @@ void fft_block(zvx_ctx* c, void* x, int dt, int B, int Lmax, const int* len_dev,
         a.out = y; a.out_dtype = DT_F32; a.o_bs = (long)Lmax * H; a.ldo = H;
         c->gemm(a);
     }
-    if (w.scln) launch_layernorm(y, DT_F32, H, x, dt, H, B, Lmax, len_dev, H, 1, 1e-8f, nullptr, nullptr, w.bg + 2 * H, w.bg_bs, w.post_add, c->stream);
-    else launch_layernorm(y, DT_F32, H, x, dt, H, B, Lmax, len_dev, H, 0, 1e-5f, c->pf(w.p + ".ln2_g"), c->pf(w.p + ".ln2_b"), nullptr, 0, w.post_add, c->stream);
+    c->timed(0, ln_bytes, [&] {
+        if (w.scln) launch_layernorm(y, DT_F32, H, x, dt, H, B, Lmax, len_dev, H, 1, 1e-8f, nullptr, nullptr, w.bg + 2 * H, w.bg_bs, w.post_add, c->stream);
+        else launch_layernorm(y, DT_F32, H, x, dt, H, B, Lmax, len_dev, H, 0, 1e-5f, c->pf(w.p + ".ln2_g"), c->pf(w.p + ".ln2_b"), nullptr, 0, w.post_add, c->stream);
+    });
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -464,6 +499,7 @@ void run_encode(zvx_ctx* c, const int32_t* phoneme, const int32_t* puncts, const
     HIPCHK(hipMemcpyAsync(spk_d, spk, (size_t)B * H * 4, hipMemcpyHostToDevice, c->stream));
 
     c->stage_begin(ZVX_T_ENCODER);
+    c->tag = "encoder";
     // positional table: stored rows cover max_txt_len; longer inputs recompute it (fs2.py:383-388)
     const float* pe = c->pf("enc.pe");
     if (Tmax > c->t("enc.pe").dim(0)) {
@@ -487,6 +523,7 @@ void run_encode(zvx_ctx* c, const int32_t* phoneme, const int32_t* puncts, const
     c->stage_end(ZVX_T_ENCODER);
 
     c->stage_begin(ZVX_T_VARIANCE);
+    c->tag = "variance";
     HIPCHK(hipMemcpyAsync(c->fbuf("enc.out", nid * H), x, nid * H * 4, hipMemcpyDeviceToDevice, c->stream));
     float* logd = c->fbuf("va.logd", nid); float* pitch = c->fbuf("va.pitch", nid); float* energy = c->fbuf("va.energy", nid);
     HIPCHK(hipMemsetAsync(logd, 0, nid * 4, c->stream)); HIPCHK(hipMemsetAsync(pitch, 0, nid * 4, c->stream)); HIPCHK(hipMemsetAsync(energy, 0, nid * 4, c->stream));
@@ -500,6 +537,7 @@ void run_encode(zvx_ctx* c, const int32_t* phoneme, const int32_t* puncts, const
     c->stage_end(ZVX_T_VARIANCE);
 
     c->stage_begin(ZVX_T_LENREG);
+    c->tag = "lenreg";
     int* dur = c->ibuf("va.dur", nid); int* cum = c->ibuf("va.cum", nid); int* ml = c->ibuf("va.mel_len", B);
     HIPCHK(hipMemsetAsync(dur, 0, nid * 4, c->stream));
     launch_durations(dur_in, logd, dur, cum, ml, B, Tmax, T_d, c->stream);
@@ -514,7 +552,8 @@ void run_encode(zvx_ctx* c, const int32_t* phoneme, const int32_t* puncts, const
     c->Lmax = Lmax;
     if (Lmax > 0) {
         float* feats = c->fbuf("features", (size_t)B * Lmax * H);
-        launch_length_regulate(x, H, cum, T_d, ml, feats, B, Tmax, Lmax, H, c->stream);
+        double rows_out = 0; for (int b = 0; b < B; b++) rows_out += c->mel_len_host[b];
+        c->timed(0, (rows_out + (double)B * Tmax) * H * 4.0, [&] { launch_length_regulate(x, H, cum, T_d, ml, feats, B, Tmax, Lmax, H, c->stream); });   // fs2.py:447-455: pure copy
     }
     c->stage_end(ZVX_T_LENREG);
     c->have_features = true;
@@ -580,9 +619,14 @@ void sty_conv(const StyCtx& s, const std::string& wname, const void* x, int ldx,
 // y = lrelu_0.2(affine(IN(x)))  (InstanceNorm over each utterance's true length only)
 void sty_norm(const StyCtx& s, const void* x, int ldx, int C, void* y, int ldy, const float* gamma, const float* beta,
               long g_bs, int one_plus, int act) {
-    launch_instnorm_stats(x, s.c->dt, ldx, s.B, s.Lmax, s.L_d, C, 1e-5f, s.mean, s.rstd, s.c->stream);
-    launch_norm_affine_act(x, s.c->dt, ldx, y, s.c->dt, ldy, s.B, s.Lmax, s.L_d, C, s.mean, s.rstd, gamma, beta, g_bs, one_plus,
-                           act, 0.2f, s.c->stream);
+    const std::string keep = s.c->tag;
+    s.c->tag = "decoder.norm";
+    s.c->timed(0, (double)s.B * s.Lmax * C * s.c->es() * 3.0, [&] {          // statistics pass (read) + normalise pass (read + write)
+        launch_instnorm_stats(x, s.c->dt, ldx, s.B, s.Lmax, s.L_d, C, 1e-5f, s.mean, s.rstd, s.c->stream);
+        launch_norm_affine_act(x, s.c->dt, ldx, y, s.c->dt, ldy, s.B, s.Lmax, s.L_d, C, s.mean, s.rstd, gamma, beta, g_bs, one_plus,
+                               act, 0.2f, s.c->stream);
+    });
+    s.c->tag = keep;
 }
 
 void decoder_styletts(zvx_ctx* c, const float* feats, const float* spk_d, const int* L_d, int B, int Lmax, float* mel) {
@@ -657,6 +701,7 @@ void decoder_styletts(zvx_ctx* c, const float* feats, const float* spk_d, const 
 
 void run_decode(zvx_ctx* c, const float* feats, const float* spk_d, const int* L_d, int B, int Lmax) {
     c->stage_begin(ZVX_T_DECODER);
+    c->tag = "decoder";
     float* mel = c->fbuf("mel", (size_t)B * std::max(Lmax, 1) * c->n_mels);
     if (Lmax > 0) {
         if (c->dec_kind == 0) decoder_fs2(c, feats, spk_d, L_d, B, Lmax, mel);
@@ -697,6 +742,7 @@ void run_vocoder(zvx_ctx* c, const float* mel, int ldm, int Lmel_max, const int*
     void* PP[2] = {c->buf("voc.PP0", maxel * es), c->buf("voc.PP1", maxel * es)};
     void* XS = c->buf("voc.XS", maxel * es);     // running sum over the resblocks of a stage, in the activation dtype
 
+    c->tag = "voc.pre";
     launch_mel_pad(mel, DT_F32, ldm, Lmel_max, mel_len_d, vin, dt, nm, Pmax, P_d, B, nm, c->stream);     // model.py:331-335
     {   // conv_pre, stored as leaky_relu(x, 0.1) (its only consumer, hifigan.py:115-117)
         GemmArgs a = gemm_base(dt);
@@ -712,6 +758,7 @@ void run_vocoder(zvx_ctx* c, const float* mel, int ldm, int Lmel_max, const int*
         const int u = c->voc_rates[i], ku = c->voc_ksizes[i], Cout = Cin / 2;
         const int rows_in = Pmax * mul, rows = rows_in * u;
         const int* len_in = lens_d + (size_t)(i + 1) * B; const int* len = lens_d + (size_t)(i + 2) * B;
+        c->tag = "voc.up" + std::to_string(i + 1);
         {   // ConvTranspose1d as a polyphase GEMM: out[t][ph*Cout+co]                  hifigan.py:118
             const std::string up = "voc.up" + std::to_string(i);
             GemmArgs a = gemm_base(dt);
@@ -739,6 +786,7 @@ void run_vocoder(zvx_ctx* c, const float* mel, int ldm, int Lmel_max, const int*
             }
         }
         const float next_slope = (i == ns - 1) ? 0.01f : 0.1f;          // hifigan.py:126 uses the default slope 0.01
+        c->tag = "voc.res" + std::to_string(i + 1);
         for (int j = 0; j < nk; j++) {
             const int k = c->voc_rb_k[j];
             const std::vector<int>& dil = c->voc_rb_d[j];
@@ -865,20 +913,29 @@ void run_vocoder(zvx_ctx* c, const float* mel, int ldm, int Lmel_max, const int*
         Cin = Cout; mul *= u;
     }
     // conv_post + tanh on the first mel_len*hop samples            hifigan.py:127-128, model.py:347
-    launch_conv_post_tanh(A, dt, Cin, (long)Pmax * mul * Cin, c->pf("voc.post_w"), c->t("voc.post_b").host[0], c->t("voc.post_w").dim(0),
-                          Cin, wav_dev, wav_stride, pcm16, B, Lmel_max * c->hop, P_d, c->hop, mel_len_d, c->hop, c->stream);
+    c->tag = "voc.post";
+    {
+        double nout = 0; for (int b = 0; b < B; b++) nout += (double)mel_len_host[b] * c->hop;
+        const int kp = c->t("voc.post_w").dim(0);
+        c->timed(2.0 * nout * Cin * kp, nout * (Cin * es + (pcm16 ? 2.0 : 4.0)), [&] {
+            launch_conv_post_tanh(A, dt, Cin, (long)Pmax * mul * Cin, c->pf("voc.post_w"), c->t("voc.post_b").host[0], kp,
+                                  Cin, wav_dev, wav_stride, pcm16, B, Lmel_max * c->hop, P_d, c->hop, mel_len_d, c->hop, c->stream);
+        });
+    }
+    c->tag = "other";
 }
 
 // ------------------------------------------------------------------------------------------------
 // speaker encoder (ResNetSE34V2.py:176-212)
 // ------------------------------------------------------------------------------------------------
-void run_spkemb(zvx_ctx* c, const float* ref_mels, const int32_t* lens, int B, int Tmax, float* out_host) {
+void run_spkemb(zvx_ctx* c, const float* ref_mels, const int32_t* lens, int B, int Tmax, float* out, int flags) {
     const int dt = c->dt, F0 = c->n_mels, H = c->H;
     const size_t es = c->es();
     for (int b = 0; b < B; b++) if (lens[b] < 2 || lens[b] > Tmax) fail(ZVX_E_INVALID, "ref mel length %d out of range (2..%d)", lens[b], Tmax);
     c->stage_begin(ZVX_T_SPKEMB);
+    c->tag = "spkemb";
     float* mels_d = c->fbuf("spk.mels", (size_t)B * Tmax * F0);
-    HIPCHK(hipMemcpyAsync(mels_d, ref_mels, (size_t)B * Tmax * F0 * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(mels_d, ref_mels, (size_t)B * Tmax * F0 * 4, (flags & ZVX_DEVICE_IN) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
     // widths per resolution level: w0 = T, w_{l+1} = (w_l - 1)/2 + 1  (3x3 stride-2 pad-1 conv)
     std::vector<int> W(4 * (size_t)B);
     int Wmax[4] = {Tmax, 0, 0, 0};
@@ -972,8 +1029,8 @@ void run_spkemb(zvx_ctx* c, const float* ref_mels, const int32_t* lens, int B, i
     launch_fc_rows(pooled, 2 * D, (const float*)c->t("spk.fc_w").dev, 2 * D, c->pf("spk.fc_b"), emb, H, B, H, 2 * D, c->stream);
     launch_l2norm_rows(emb, B, H, c->stream);                                  // F.normalize   :209-210
     c->stage_end(ZVX_T_SPKEMB);
-    HIPCHK(hipMemcpyAsync(out_host, emb, (size_t)B * H * 4, hipMemcpyDeviceToHost, c->stream));
-    c->sync();
+    HIPCHK(hipMemcpyAsync(out, emb, (size_t)B * H * 4, (flags & ZVX_DEVICE_OUT) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, c->stream));
+    if (!((flags & ZVX_DEVICE_OUT) && (flags & ZVX_NO_SYNC))) c->sync();
 }
 
 // copy device rows [B][rows_max][C] (f32 contiguous) to a caller buffer with row stride
@@ -1053,7 +1110,11 @@ void do_vocode(zvx_ctx* c, const int32_t* pad_to, void* wav, int64_t wav_stride,
     const bool dev_out = flags & ZVX_DEVICE_OUT;
     const int pcm16 = (flags & ZVX_PCM16) ? 1 : 0;
     const size_t ss = pcm16 ? 2 : 4;
-    if (dev_out) { wdev = wav; wstride = wav_stride; }
+    if (dev_out) {
+        wdev = wav; wstride = wav_stride;
+        auto f = c->gather_fence.find(wav);                 // a gather still reading this buffer: the vocoder's writes queue behind it
+        if (f != c->gather_fence.end()) HIPCHK(hipStreamWaitEvent(c->stream, f->second, 0));
+    }
     else { wstride = (std::max(need, 1) + 7) & ~7; wdev = c->buf("wav", (size_t)B * wstride * ss); }
     run_vocoder(c, c->fbuf("mel", 0), c->n_mels, c->Lmax, c->mel_len_host.data(), P.data(), B, wdev, wstride, pcm16);
     c->stage_end(ZVX_T_VOCODER);
@@ -1118,6 +1179,7 @@ void zvx_destroy(zvx_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    zvx_comm_destroy(c);
     for (auto& kv : c->bufs) if (kv.second.base) (void)hipFree(kv.second.base);
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
     if (c->stream) {
@@ -1163,7 +1225,14 @@ zvx_status zvx_set_int(zvx_ctx* c, const char* key, int64_t value) {
 zvx_status zvx_spkemb(zvx_ctx* c, const float* ref_mels, const int32_t* lens, int B, int Tmax, float* out) {
     return guarded(c, [&] {
         if (!ref_mels || !lens || !out || B <= 0 || Tmax <= 0) fail(ZVX_E_INVALID, "zvx_spkemb: bad arguments");
-        run_spkemb(c, ref_mels, lens, B, Tmax, out);
+        run_spkemb(c, ref_mels, lens, B, Tmax, out, 0);
+    });
+}
+
+zvx_status zvx_spkemb_ex(zvx_ctx* c, const float* ref_mels, const int32_t* lens, int B, int Tmax, float* out, int flags) {
+    return guarded(c, [&] {
+        if (!ref_mels || !lens || !out || B <= 0 || Tmax <= 0) fail(ZVX_E_INVALID, "zvx_spkemb_ex: bad arguments");
+        run_spkemb(c, ref_mels, lens, B, Tmax, out, flags);
     });
 }
 
@@ -1231,7 +1300,7 @@ zvx_status zvx_vocode_mel(zvx_ctx* c, const float* mel, const int32_t* P, int B,
         c->B = B; c->Lmax = Pmax; c->Tmax = 0; c->mel_len_host.assign(P, P + B);
         c->have_features = false; c->have_mel = false;             // the context's batch geometry changes: earlier intermediates are void
         float* m = c->fbuf("mel", (size_t)B * Pmax * c->n_mels);
-        HIPCHK(hipMemcpyAsync(m, mel, (size_t)B * Pmax * c->n_mels * 4, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipMemcpyAsync(m, mel, (size_t)B * Pmax * c->n_mels * 4, (flags & ZVX_DEVICE_IN) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
         c->have_mel = true;
         do_vocode(c, nullptr, wav, wav_stride, flags);
     });
@@ -1290,6 +1359,159 @@ zvx_status zvx_fetch(zvx_ctx* c, const char* what, float* out, size_t out_floats
 
 zvx_status zvx_sync(zvx_ctx* c) { return guarded(c, [&] { c->sync(); }); }
 
+// ---- RCCL, resolved at run time ----------------------------------------------------------------------------------
+namespace {
+struct Rccl {
+    void* h = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+};
+Rccl& rccl() {
+    static Rccl r;
+    if (r.h) return r;
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) { r.h = dlopen(name, RTLD_NOW | RTLD_GLOBAL); if (r.h) break; }
+    if (!r.h) fail(ZVX_E_HIP, "cannot load librccl.so (%s): multi-GPU needs RCCL", dlerror());
+#define ZVX_SYM(f) do { r.f = (decltype(r.f))dlsym(r.h, "nccl" #f); if (!r.f) fail(ZVX_E_HIP, "librccl.so lacks nccl" #f); } while (0)
+    ZVX_SYM(GetUniqueId); ZVX_SYM(CommInitRank); ZVX_SYM(CommDestroy); ZVX_SYM(Send); ZVX_SYM(Recv); ZVX_SYM(GroupStart); ZVX_SYM(GroupEnd);
+    ZVX_SYM(AllReduce); ZVX_SYM(GetErrorString);
+#undef ZVX_SYM
+    return r;
+}
+#define NCCLCHK(x) do { ncclResult_t r_ = (x); if (r_ != ncclSuccess) fail(ZVX_E_HIP, "%s failed: %s (%s:%d)", #x, rccl().GetErrorString(r_), __FILE__, __LINE__); } while (0)
+}  // namespace
+
+zvx_status zvx_comm_unique_id(void* id_out) {
+    static_assert(sizeof(ncclUniqueId) == ZVX_COMM_ID_BYTES, "ncclUniqueId size");
+    if (!id_out) return ZVX_E_INVALID;
+    try {
+        ncclUniqueId id;
+        NCCLCHK(rccl().GetUniqueId(&id));
+        memcpy(id_out, &id, sizeof id);
+        return ZVX_OK;
+    } catch (const ZvxError& e) { g_create_error = e.what(); return e.code; }
+}
+
+zvx_status zvx_comm_init(zvx_ctx* c, const void* id, int rank, int world) {
+    return guarded(c, [&] {
+        if (world < 1 || rank < 0 || rank >= world) fail(ZVX_E_INVALID, "zvx_comm_init: rank %d of %d", rank, world);
+        if (c->comm || c->comm_stream) fail(ZVX_E_STATE, "zvx_comm_init: communicator already initialised");
+        HIPCHK(hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&c->ev_compute, hipEventDisableTiming));
+        c->rank = rank; c->world = world;
+        if (world > 1 || id) {                              // world == 1 with an id: a real one-rank communicator (self-test of the RCCL path)
+            if (!id) fail(ZVX_E_INVALID, "zvx_comm_init: id is NULL");
+            ncclUniqueId uid;
+            memcpy(&uid, id, sizeof uid);
+            NCCLCHK(rccl().CommInitRank(&c->comm, world, uid, rank));
+        }
+    });
+}
+
+zvx_status zvx_comm_gather(zvx_ctx* c, const void* local, size_t bytes, void* recv, int root, int flags) {
+    return guarded(c, [&] {
+        if (!c->comm_stream) fail(ZVX_E_STATE, "zvx_comm_gather: call zvx_comm_init first");
+        if (!local || root < 0 || root >= c->world || (c->rank == root && !recv)) fail(ZVX_E_INVALID, "zvx_comm_gather: bad arguments");
+        // the communication stream picks up after everything issued so far on the compute stream
+        HIPCHK(hipEventRecord(c->ev_compute, c->stream));
+        HIPCHK(hipStreamWaitEvent(c->comm_stream, c->ev_compute, 0));
+        if (c->comm && c->world == 1) {                     // one-rank communicator: the root's row travels through RCCL too
+            Rccl& r = rccl();
+            NCCLCHK(r.GroupStart());
+            NCCLCHK(r.Send(local, bytes, ncclInt8, 0, c->comm, c->comm_stream));
+            NCCLCHK(r.Recv(recv, bytes, ncclInt8, 0, c->comm, c->comm_stream));
+            NCCLCHK(r.GroupEnd());
+        } else if (c->rank == root)
+            HIPCHK(hipMemcpyAsync((char*)recv + (size_t)root * bytes, local, bytes, hipMemcpyDeviceToDevice, c->comm_stream));
+        if (c->world > 1) {
+            Rccl& r = rccl();
+            NCCLCHK(r.GroupStart());
+            if (c->rank == root) {
+                for (int p = 0; p < c->world; p++)
+                    if (p != root) NCCLCHK(r.Recv((char*)recv + (size_t)p * bytes, bytes, ncclInt8, p, c->comm, c->comm_stream));
+            } else {
+                NCCLCHK(r.Send(local, bytes, ncclInt8, root, c->comm, c->comm_stream));
+            }
+            NCCLCHK(r.GroupEnd());
+        }
+        // later writers of `local` (the vocoder of a coming call) queue behind this event on the device
+        hipEvent_t& ev = c->gather_fence[local];
+        if (!ev) HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        HIPCHK(hipEventRecord(ev, c->comm_stream));
+        if (!(flags & ZVX_NO_SYNC)) c->sync();
+    });
+}
+
+zvx_status zvx_comm_max_f64(zvx_ctx* c, double* value) {
+    return guarded(c, [&] {
+        if (!c->comm_stream || !value) fail(ZVX_E_STATE, "zvx_comm_max_f64: call zvx_comm_init first");
+        c->sync();
+        if (!c->comm) return;
+        double* d = (double*)c->buf("comm.scalar", 64);
+        HIPCHK(hipMemcpyAsync(d, value, sizeof(double), hipMemcpyHostToDevice, c->comm_stream));
+        NCCLCHK(rccl().AllReduce(d, d, 1, ncclFloat64, ncclMax, c->comm, c->comm_stream));
+        HIPCHK(hipMemcpyAsync(value, d, sizeof(double), hipMemcpyDeviceToHost, c->comm_stream));
+        HIPCHK(hipStreamSynchronize(c->comm_stream));
+    });
+}
+
+zvx_status zvx_comm_barrier(zvx_ctx* c) {
+    double one = 1.0;
+    return zvx_comm_max_f64(c, &one);
+}
+
+void zvx_comm_destroy(zvx_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->comm_stream) (void)hipStreamSynchronize(c->comm_stream);
+    if (c->comm) { (void)rccl().CommDestroy(c->comm); c->comm = nullptr; }
+    for (auto& kv : c->gather_fence) if (kv.second) (void)hipEventDestroy(kv.second);
+    c->gather_fence.clear();
+    if (c->ev_compute) { (void)hipEventDestroy(c->ev_compute); c->ev_compute = nullptr; }
+    if (c->comm_stream) { (void)hipStreamDestroy(c->comm_stream); c->comm_stream = nullptr; }
+    c->world = 1; c->rank = 0;
+}
+
+zvx_status zvx_dev_alloc(zvx_ctx* c, size_t bytes, void** out) {
+    return guarded(c, [&] {
+        if (!out || !bytes) fail(ZVX_E_INVALID, "zvx_dev_alloc: bad arguments");
+        HIPCHK(hipMalloc(out, bytes));
+        HIPCHK(hipMemsetAsync(*out, 0, bytes, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+    });
+}
+
+zvx_status zvx_dev_free(zvx_ctx* c, void* p) {
+    return guarded(c, [&] {
+        c->sync();
+        auto f = c->gather_fence.find(p);
+        if (f != c->gather_fence.end()) { if (f->second) (void)hipEventDestroy(f->second); c->gather_fence.erase(f); }
+        if (p) HIPCHK(hipFree(p));
+    });
+}
+
+zvx_status zvx_dev_from_host(zvx_ctx* c, void* dst, const void* src, size_t bytes) {
+    return guarded(c, [&] {
+        if (!dst || !src) fail(ZVX_E_INVALID, "zvx_dev_from_host: NULL pointer");
+        HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+    });
+}
+
+zvx_status zvx_dev_to_host(zvx_ctx* c, void* dst, const void* src, size_t bytes) {
+    return guarded(c, [&] {
+        if (!dst || !src) fail(ZVX_E_INVALID, "zvx_dev_to_host: NULL pointer");
+        c->sync();
+        HIPCHK(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+    });
+}
+
 zvx_status zvx_stage_times(zvx_ctx* c, float ms[ZVX_T_COUNT]) {
     return guarded(c, [&] { c->sync(); for (int s = 0; s < ZVX_T_COUNT; s++) ms[s] = c->stage_ms[s]; });
 }
@@ -1304,8 +1526,18 @@ int zvx_kernel_stats(zvx_ctx* c, zvx_kernel_stat* out, int max_out) {
     return n;
 }
 
+int zvx_tag_stats(zvx_ctx* c, zvx_kernel_stat* out, int max_out) {
+    if (!c) return 0;
+    int n = 0;
+    guarded(c, [&] {
+        c->sync();
+        for (auto& kv : c->tagstats) if (kv.second.launches > 0 && n < max_out) out[n++] = kv.second;
+    });
+    return n;
+}
+
 zvx_status zvx_reset_stats(zvx_ctx* c) {
-    return guarded(c, [&] { c->sync(); for (auto& s : c->stats) { s.launches = 0; s.ms = s.flops = s.bytes = 0; } });
+    return guarded(c, [&] { c->sync(); for (auto& s : c->stats) { s.launches = 0; s.ms = s.flops = s.bytes = 0; } c->tagstats.clear(); });
 }
 
 }  // extern "C"
