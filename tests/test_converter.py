@@ -22,7 +22,9 @@ def test_convert_roundtrip(tmp_path):
     state = {k: torch.from_numpy(np.array(v)) for k, v in sd.items()}
     state.update({"_meldec." + k: torch.from_numpy(np.array(v)) for k, v in hsd.items()})    # vocoder baked in
     ck = tmp_path / "checkpoint.pkl"
-    torch.save({"state_dict": state, "hyper_parameters": {"lr": 1e-4}}, ck)
+    cc._install_symbols_stub()                                            # a real checkpoint pickles a zerovox.tts.symbols.Symbols instance
+    sym = sys.modules["zerovox.tts.symbols"].Symbols(zcfg.PHONES, zcfg.PUNCTS)
+    torch.save({"state_dict": state, "hyper_parameters": {"lr": 1e-4, "symbols": sym}}, ck)
     mc = tmp_path / "modelcfg.yaml"
     yaml.safe_dump(cfg, open(mc, "w"))
     n_tts, n_voc = cc.convert_tts(str(ck), str(mc), str(tmp_path / "out"))

@@ -378,10 +378,10 @@ def test_stage_times_and_kernel_stats_are_reported():
     assert ks and all(k["launches"] > 0 and k["ms"] > 0 and k["flops"] > 0 for k in ks)
 
 
-def test_mel_frontend_matches_host_restatement():
-    """zvx_melspec (reflect pad + DFT GEMM + mel GEMM + log-clip on the device) against the NumPy restatement of
-    get_mel_from_wav (zerovox_amd/mels.py; parity of BOTH against librosa is unpinned, see that file) on a ragged batch."""
-    from zerovox_amd.mels import get_mel_from_wav
+def test_mel_frontend_matches_oracle():
+    """zvx_melspec (reflect pad + DFT GEMM + mel GEMM + log-clip on the device) against the independent CPU oracle of
+    get_mel_from_wav (oracle/mel_oracle.py, pinned to librosa's documented values in tests/test_mel_oracle.py) on a ragged batch."""
+    from oracle.mel_oracle import get_mel_from_wav
     ctx = ctx_for("styletts", "tiny", "bf16")
     rng = np.random.default_rng(3)
     sr = 22050
@@ -389,6 +389,7 @@ def test_mel_frontend_matches_host_restatement():
     for n in (22050, 9000, 513, 40000):
         t = np.arange(n) / sr
         wavs.append((0.3 * np.sin(2 * np.pi * 220 * t) + 0.1 * np.sin(2 * np.pi * 3100 * t) + 0.05 * rng.standard_normal(n)).astype(np.float32))
+    ctx.melspec([np.ones(60000, np.float32)])                             # a longer call first: the rows handed back below must not carry it
     mel, frames = ctx.melspec(wavs)
     for b, w in enumerate(wavs):
         ref, _ = get_mel_from_wav(w, sr, 1024, 256, 1024, 80, 0, 8000)
@@ -397,6 +398,29 @@ def test_mel_frontend_matches_host_restatement():
         assert not mel[b, frames[b]:].any()
     with pytest.raises(_lib.ZvxError):
         ctx.melspec([np.zeros(100, np.float32)])                          # shorter than the reflect padding
+
+
+@pytest.mark.parametrize("prec", ["f32", "bf16"])
+def test_speaker_embed_end_to_end_from_raw_audio(prec):
+    """ZeroVoxTTS.speaker_embed (synthesize.py:123-143): trim -> log-mel -> ResNetSE34V2, raw waveform in, [1,1,528] out,
+    against the oracle chain (mel_oracle.trim / get_mel_from_wav + zvx_oracle.resnet_se34v2)."""
+    from oracle import mel_oracle as MO
+    from zerovox_amd.synthesize import ZeroVoxTTS
+    _, synth = ZeroVoxTTS.load_model("synthetic:styletts", "synthetic:tiny", infer_device="cuda:0", precision=prec)
+    cfg, sd = tts_sd("styletts")
+    rng = np.random.default_rng(17)
+    n = 22050 * 2
+    t = np.arange(n) / 22050.0
+    voiced = (0.25 * np.sin(2 * np.pi * 140 * t) * (1 + 0.5 * np.sin(2 * np.pi * 3 * t)) + 0.02 * rng.standard_normal(n)).astype(np.float32)
+    wav = np.concatenate([np.zeros(6000, np.float32), voiced, 1e-4 * rng.standard_normal(9000).astype(np.float32)])
+    e = synth.speaker_embed(wav)
+    assert e.shape == (1, 1, 528) and abs(np.linalg.norm(e) - 1.0) < 1e-4
+    trimmed = MO.trim(wav, top_db=40)
+    assert 0 < len(trimmed) < len(wav)
+    mel, _ = MO.get_mel_from_wav(trimmed, 22050, 1024, 256, 1024, 80, 0, 8000)
+    ref = O.resnet_se34v2(mel.T, sd, cfg)
+    mx, _, _, bm = stats(e[0, 0], ref)
+    assert mx <= (5e-5 if prec == "f32" else 0.05 * bm), f"speaker_embed err {mx:.3e} (ref max {bm:.3g})"
 
 
 @pytest.mark.parametrize("prec", ["f32", "bf16"])
@@ -560,3 +584,117 @@ def test_rccl_gather_path_on_a_one_rank_communicator():
         ctx.dev_free(wav_d); ctx.dev_free(recv_d)
     finally:
         ctx.close()
+
+
+# ------------------------------------------------------------------------------------------------
+# BASELINE.json configs at their full sizes
+# ------------------------------------------------------------------------------------------------
+def test_config4_hifigan_v1_alone_1024_frames():
+    """configs[3]: HiFi-GAN V1 alone on a [80, 1024] N(0,1) mel (seed 7): B = 1 against the oracle (f32 exact-class and bf16),
+    B = 32 through size-independent properties (every row of a batch of identical mels equals the B = 1 waveform bit for bit;
+    distinct rows stay finite, bounded and different)."""
+    h, hsd = voc_sd("v1")
+    mel = np.random.default_rng(7).standard_normal((1024, 80)).astype(np.float32)
+    ref = O.hifigan_generator(mel.T, hsd, h)
+    assert ref.shape == (262144,)
+    for prec in ("f32", "bf16"):
+        ctx = ctx_for("styletts", "v1", prec)
+        wav = ctx.vocode_mel(mel[None], np.array([1024], np.int32))
+        check_wav(wav[0], ref, prec, f"config4 B=1 {prec}", e2e=False)
+    ctx = ctx_for("styletts", "v1", "bf16")
+    one = ctx.vocode_mel(mel[None], np.array([1024], np.int32))[0]
+    rng = np.random.default_rng(70)
+    batch = rng.standard_normal((32, 1024, 80)).astype(np.float32)
+    batch[5] = mel; batch[31] = mel
+    out = ctx.vocode_mel(batch, np.full(32, 1024, np.int32))
+    assert out.shape == (32, 262144) and np.isfinite(out).all() and np.abs(out).max() <= 1.0
+    assert np.array_equal(out[5], one) and np.array_equal(out[31], one)
+    assert out[0].std() > 1e-3 and not np.array_equal(out[0], out[1])
+
+
+def test_config5_speaker_encoder_1000_clips():
+    """configs[4]: 1000 x [258, 80] N(0,1) reference mels in batches of 50: unit norm everywhere, 8 sampled clips against the
+    oracle, and batch invariance (clip i in its batch == clip i alone, to f32 round-off)."""
+    ctx = ctx_for("styletts", "tiny", "bf16")
+    cfg, sd = tts_sd("styletts")
+    rng = np.random.default_rng(8)
+    mels = rng.standard_normal((1000, 258, 80)).astype(np.float32)
+    lens = np.full(50, 258, np.int32)
+    emb = np.concatenate([ctx.spkemb(mels[i:i + 50], lens) for i in range(0, 1000, 50)])
+    assert emb.shape == (1000, 528) and np.isfinite(emb).all()
+    assert np.abs(np.linalg.norm(emb, axis=1) - 1.0).max() < 1e-4
+    for i in (0, 49, 50, 333, 512, 777, 950, 999):
+        ref = O.resnet_se34v2(mels[i], sd, cfg)
+        mx, _, _, bm = stats(emb[i], ref)
+        assert mx <= 0.05 * bm, f"clip {i}: embed err {mx:.3e} (ref max {bm:.3g})"
+    solo = ctx.spkemb(mels[333:334], np.array([258], np.int32))
+    assert np.abs(solo[0] - emb[333]).max() < 1e-6                      # tile shapes follow the batch size: equal to f32 round-off, not bit for bit
+
+
+def test_config3_workload_on_one_gpu_256_utterances_equal_eight_shards():
+    """configs[2] shards 256 utterances as 8 x 32 over the GPUs of a node.  On one GPU: the 256-utterance batch in ONE call
+    is bit-identical to the eight 32-utterance shard calls (what each rank computes) -- utterances never interact, so the
+    gathered result of the 8-GPU job is exactly this tensor."""
+    ctx = ctx_for("styletts", "v1", "bf16")
+    ph, pu, T, spk, dur = synthetic.batch(256, 128, 0, "const7")
+    pad_to = np.full(256, 896, np.int32)
+    whole = ctx.synthesize(ph, pu, T, spk, dur, pad_to, want_mel=False)["wav"]
+    assert whole.shape == (256, 229376) and np.isfinite(whole).all()
+    for r in range(8):
+        sl = slice(32 * r, 32 * r + 32)
+        shard = ctx.synthesize(ph[sl], pu[sl], T[sl], spk[sl], dur[sl], pad_to[sl], want_mel=False)["wav"]
+        assert np.array_equal(shard, whole[sl]), f"shard {r}"
+
+
+def test_converted_checkpoint_runs_and_baked_in_vocoder_wins(tmp_path):
+    """SURVEY 8 f-2 end to end: a Lightning-style checkpoint (state_dict + pickled hyper_parameters holding a `Symbols`
+    object, a vocoder baked in under `_meldec.`) -> tools/convert_checkpoint.py -> ZeroVoxTTS.load_model(directory) ->
+    synthesis on the GPU equals the synthetic-weights path; the baked-in generator overrides the external one."""
+    import json
+    import sys
+    import types
+    import torch
+    import yaml
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import convert_checkpoint as cc
+    from zerovox_amd.synthesize import ZeroVoxTTS
+    cfg, sd = tts_sd("styletts")
+    h, hsd = voc_sd("tiny")
+    hsd_other = zw.hifigan_state_dict(h, 5)                                   # the EXTERNAL vocoder carries different weights
+    cc._install_symbols_stub()
+    sym = sys.modules["zerovox.tts.symbols"].Symbols(zcfg.PHONES, zcfg.PUNCTS)
+    state = {k: torch.from_numpy(np.array(v)) for k, v in sd.items()}
+    state.update({"_meldec." + k: torch.from_numpy(np.array(v)) for k, v in hsd.items()})
+    ck = tmp_path / "checkpoint.pkl"
+    torch.save({"state_dict": state, "hyper_parameters": {"symbols": sym, "lr": 1e-4}}, ck)
+    mc = tmp_path / "modelcfg.yaml"
+    yaml.safe_dump(cfg, open(mc, "w"))
+    assert cc.convert_tts(str(ck), str(mc), str(tmp_path / "tts")) == (len(sd), len(hsd))
+    gk = tmp_path / "generator.ckpt"
+    torch.save({"generator": {k: torch.from_numpy(np.array(v)) for k, v in hsd_other.items()}}, gk)
+    cj = tmp_path / "config.json"
+    json.dump(h, open(cj, "w"))
+    cc.convert_vocoder(str(gk), str(cj), str(tmp_path / "voc"))
+    _, synth = ZeroVoxTTS.load_model(str(tmp_path / "tts"), str(tmp_path / "voc"), infer_device="cuda:0", precision="f32")
+    _, ref_synth = ZeroVoxTTS.load_model("synthetic:styletts", "synthetic:tiny", infer_device="cuda:0", precision="f32")
+    spk = synthetic.utterance(4, 3)[2][None, None]
+    a = synth.tts_ex("converted checkpoint", spk, duration=[4] * 19)
+    b = ref_synth.tts_ex("converted checkpoint", spk, duration=[4] * 19)
+    assert a[2] == b[2] == 76 and np.array_equal(a[0], b[0]) and np.array_equal(a[3], b[3])
+
+
+def test_demo_cli_prints_the_reference_rtf_lines(capsys, monkeypatch, tmp_path):
+    """zerovox_amd.demo mirrors demo.py --iter (demo.py:99-138): per-iteration line, warm-up of 10 discarded, mean RTF."""
+    import re
+    import sys
+    import wave
+    from zerovox_amd import demo
+    out_wav = tmp_path / "demo.wav"
+    monkeypatch.setattr(sys, "argv", ["demo", "--model", "synthetic:styletts", "--meldec-model", "synthetic:tiny", "--precision", "bf16",
+                                      "--iter", "13", "--wav-filename", str(out_wav), "hello world, this is a test."])
+    demo.main()
+    lines = capsys.readouterr().out.splitlines()
+    its = [l for l in lines if re.match(r"^\[\d+/13\] Synth time: \d+\.\d\d sec, voice length: \d+\.\d\d sec, rtf: \d+\.\d\d$", l)]
+    assert len(its) == 13 and lines[0] == "computing speaker embedding..." and re.match(r"^Average RTF: \d+\.\d\d$", lines[-1])
+    with wave.open(str(out_wav), "rb") as w:
+        assert w.getframerate() == 22050 and w.getnchannels() == 1 and w.getsampwidth() == 2 and w.getnframes() > 0

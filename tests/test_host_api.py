@@ -150,7 +150,7 @@ def test_stft_basis_matches_torch_stft():
 def test_library_exports_every_declared_symbol():
     hdr = open(os.path.join(ROOT, "include", "zvx.h")).read()
     code = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)                  # strip comments
-    declared = set(re.findall(r"\b(zvx_[a-z_]+)\s*\(", code))
+    declared = set(re.findall(r"\b(zvx_[a-z0-9_]+)\s*\(", code))
     assert declared == set(_lib.EXPORTS), declared ^ set(_lib.EXPORTS)
     lib = _lib.load()
     for name in declared:
@@ -196,3 +196,37 @@ def test_committed_bench_line_follows_the_contract():
     c = d["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
     assert abs(d["value"] - d["config"]["global_batch"] * d["config"]["samples_per_utt"] / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
+
+
+def test_write_wav_to_file_is_int16_pcm_x32760(tmp_path):
+    """demo.py:29-35 / model.py:44-63: (wav * 32760).astype(int16), cut to length * hop, 16-bit mono."""
+    import wave
+    from zerovox_amd.synthesize import write_wav_to_file
+    rng = np.random.default_rng(1)
+    wav = np.clip(rng.standard_normal(5000) * 0.4, -1, 1).astype(np.float32)
+    f = tmp_path / "t.wav"
+    write_wav_to_file(wav, length=7, filename=f, sample_rate=22050, hop_length=256)
+    with wave.open(str(f), "rb") as w:
+        assert (w.getframerate(), w.getnchannels(), w.getsampwidth(), w.getnframes()) == (22050, 1, 2, 7 * 256)
+        pcm = np.frombuffer(w.readframes(w.getnframes()), np.int16)
+    assert np.array_equal(pcm, (wav * 32760).astype("int16")[: 7 * 256])
+
+
+def test_get_speakerref_resamples_to_the_model_rate(tmp_path):
+    """synthesize.py:112-121 loads the reference voice at the model's sampling rate (librosa.load(sr=...)): a 16 kHz file comes
+    back at 22.05 kHz with its pitch preserved; a file already at the model rate comes back sample-exact."""
+    import wave
+    n = 16000
+    tone = (0.5 * np.sin(2 * np.pi * 440 * np.arange(n) / 16000.0)).astype(np.float32)
+    f = tmp_path / "ref16k.wav"
+    with wave.open(str(f), "wb") as w:
+        w.setnchannels(1); w.setsampwidth(2); w.setframerate(16000); w.writeframes((tone * 32767).astype(np.int16).tobytes())
+    a = ZeroVoxTTS.get_speakerref(f, 22050)
+    assert abs(len(a) - 22050) <= 1 and a.dtype == np.float32
+    spec = np.abs(np.fft.rfft(a * np.hanning(len(a))))
+    assert abs(np.argmax(spec) * 22050.0 / len(a) - 440.0) < 2.0
+    g = tmp_path / "ref22k.wav"
+    pcm = (np.random.default_rng(0).standard_normal(3000) * 3000).astype(np.int16)
+    with wave.open(str(g), "wb") as w:
+        w.setnchannels(1); w.setsampwidth(2); w.setframerate(22050); w.writeframes(pcm.tobytes())
+    assert np.array_equal(ZeroVoxTTS.get_speakerref(g, 22050), pcm.astype(np.float32) / 32768.0)

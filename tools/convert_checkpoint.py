@@ -24,16 +24,23 @@ import types
 import numpy as np
 
 
+class _SymbolsStub:
+    """Stand-in for `zerovox.tts.symbols.Symbols` instances pickled inside a checkpoint's hyper_parameters: it only has to
+    unpickle (the symbol tables themselves come from modelcfg.yaml)."""
+
+    def __init__(self, *a, **k):
+        pass
+
+
+_SymbolsStub.__module__ = "zerovox.tts.symbols"
+_SymbolsStub.__qualname__ = _SymbolsStub.__name__ = "Symbols"
+
+
 def _install_symbols_stub():
     if "zerovox.tts.symbols" in sys.modules:
         return
     pkg = types.ModuleType("zerovox"); tts = types.ModuleType("zerovox.tts"); sym = types.ModuleType("zerovox.tts.symbols")
-
-    class Symbols:                       # only needs to unpickle
-        def __init__(self, *a, **k):
-            pass
-
-    sym.Symbols = Symbols
+    sym.Symbols = _SymbolsStub
     pkg.tts = tts; tts.symbols = sym
     sys.modules.update({"zerovox": pkg, "zerovox.tts": tts, "zerovox.tts.symbols": sym})
 

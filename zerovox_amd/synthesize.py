@@ -54,17 +54,24 @@ class ZeroVoxTTS:
 
     @staticmethod
     def get_speakerref(speakerref, sampling_rate):
-        """Load a reference wav (16-bit PCM / float) as float32 mono at ``sampling_rate`` (synthesize.py:112-121;
-        the reference resamples through librosa -- here the file must already be at ``sampling_rate``)."""
+        """Load a reference wav (8/16/32-bit PCM) as float32 mono at ``sampling_rate`` (synthesize.py:112-121).  The reference
+        goes through ``librosa.load(sr=sampling_rate)``, which resamples with soxr_hq; here a file at another rate is
+        resampled with a polyphase Kaiser filter (scipy.signal.resample_poly) -- the same band-limited signal, not
+        bit-identical to soxr (parity of resampled references is unpinned: librosa/soxr are not installable here)."""
         with wave.open(str(speakerref), "rb") as w:
             sr, nch, sw = w.getframerate(), w.getnchannels(), w.getsampwidth()
             raw = w.readframes(w.getnframes())
-        if sr != sampling_rate:
-            raise ValueError(f"{speakerref}: sample rate {sr} != {sampling_rate} (resampling needs librosa)")
         dt = {1: np.uint8, 2: np.int16, 4: np.int32}[sw]
         a = np.frombuffer(raw, dtype=dt).astype(np.float32)
         a = (a - 128.0) / 128.0 if sw == 1 else a / float(2 ** (8 * sw - 1))
-        return a.reshape(-1, nch).mean(axis=1) if nch > 1 else a
+        if nch > 1:
+            a = a.reshape(-1, nch).mean(axis=1)
+        if sr != sampling_rate:
+            from math import gcd
+            from scipy.signal import resample_poly
+            g = gcd(int(sr), int(sampling_rate))
+            a = resample_poly(a.astype(np.float64), int(sampling_rate) // g, int(sr) // g).astype(np.float32)
+        return a
 
     def speaker_embed(self, wav: np.ndarray):
         """wav -> [1, 1, hidden] speaker embedding (synthesize.py:123-143)."""
