@@ -4,12 +4,17 @@
 Stated tolerances
   f32 mode  (exact-f32 MFMA everywhere): max|err| <= 2e-4 * max(1, max|ref|) on every float output
             (measured ~3e-5: fp32 summation-order noise); lengths / durations / bucket ids exact.
-  bf16 mode (bf16 activations+weights, fp32 accumulate, the benchmarked mode); encoder + variance adaptor
-            stay f32 in this mode, so log-duration / pitch / energy / features keep the f32 tolerance and
-            every discrete decision is exact.  mel: rms err <= 3 % of the reference rms and
-            max|err| <= 0.15; waveform in [-1, 1]: rms err <= 1e-2, max|err| <= 6e-2 end-to-end
-            (vocoder alone from an exact mel: rms <= 3e-3, max <= 1.5e-2).  These are ~3x the measured
-            values and match the bf16 storage-emulation floor measured on the reference.
+  bf16 mode (bf16 activations+weights, fp32 accumulate, the benchmarked mode).  The phoneme encoder + variance adaptor stay
+            f32-class in this mode: the variance predictors run on the exact-f32 MFMA, the encoder's FFT blocks as 3-plane bf16
+            split products (hi.wh + hi.wl + lo.wh, measured 5e-5 max / 9e-6 rms on the encoder output against the exact-f32
+            path), so log-duration / pitch / energy / features keep the f32 tolerance (2e-4) and every discrete decision
+            (duration, pitch / energy bucket) equals the reference's unless the reference value lies within 2e-2 bucket units
+            (5e-3 frames) of a rounding boundary (measured: 2 + 11 of 4096 bucket ids move by one against the exact-f32 path).
+            mel: rms err <= 2.5 % of the reference rms and max|err| <= 0.12; waveform in [-1, 1]: rms err <= 6e-3,
+            max|err| <= 3e-2 end-to-end (vocoder alone from an exact mel: rms <= 3e-3, max <= 1.5e-2).  About 2x the measured
+            values (tools/error_budget.py on e2e_styletts_v1_T64: decoder mel 7e-2 max / 1.5e-2 rms; vocoder alone 7e-3 /
+            1.3e-3; decoder error through an exact vocoder 1.2e-2 / 2.2e-3; end to end 1.3e-2 / 2.6e-3): the end-to-end
+            error is the decoder's bf16 activation storage, the vocoder alone meets SURVEY.md 8c's 1e-2 / 2e-3.
 """
 import os
 
@@ -67,14 +72,14 @@ def check_mel(a, b, prec, what):
     if prec == "f32":
         return check_f32(a, b, what)
     mx, rms, ref_rms, _ = stats(a, b)
-    assert rms <= 0.03 * ref_rms and mx <= 0.15, f"{what}: mel err max {mx:.3e} rms {rms:.3e} (ref rms {ref_rms:.3g})"
+    assert rms <= 0.025 * ref_rms and mx <= 0.12, f"{what}: mel err max {mx:.3e} rms {rms:.3e} (ref rms {ref_rms:.3g})"
 
 
 def check_wav(a, b, prec, what, e2e=True):
     if prec == "f32":
         return check_f32(a, b, what)
     mx, rms, _, _ = stats(a, b)
-    lim_mx, lim_rms = (6e-2, 1e-2) if e2e else (1.5e-2, 3e-3)
+    lim_mx, lim_rms = (3e-2, 6e-3) if e2e else (1.5e-2, 3e-3)
     assert mx <= lim_mx and rms <= lim_rms, f"{what}: wav err max {mx:.3e} rms {rms:.3e}"
 
 
@@ -151,11 +156,13 @@ def test_predicted_durations_and_buckets_exact(prec):
     pidx = ctx.fetch("pitch_idx", (3, 20)); eidx = ctx.fetch("energy_idx", (3, 20)); dur = ctx.fetch("duration", (3, 20))
     for b in range(3):
         ref = O.fs2_encoder(ph[b], pu[b], spk[b], sd, cfg)
-        # a rounding boundary closer than 1e-3 would make the discrete outcome legitimately ambiguous in fp32
-        safe_p = np.abs((ref["pitch"] * 255) % 1 - 0.5) > 1e-3
-        safe_e = np.abs((ref["energy"] * 255) % 1 - 0.5) > 1e-3
-        safe_d = np.abs((np.exp(ref["log_duration"]) - 1) % 1 - 0.5) > 1e-3
-        assert safe_p.mean() > 0.9
+        # a rounding boundary closer than 1e-3 would make the discrete outcome legitimately ambiguous in fp32; the bf16 mode's
+        # split-product encoder is f32-class, not f32-exact (see the header): 2e-2 bucket units / 5e-3 frames there
+        mb, md = (1e-3, 1e-3) if prec == "f32" else (2e-2, 5e-3)
+        safe_p = np.abs((ref["pitch"] * 255) % 1 - 0.5) > mb
+        safe_e = (np.abs((ref["energy"] * 255) % 1 - 0.5) > mb) & (pidx[b] == ref["pitch_idx"])     # energy sees the pitch-embedded input
+        safe_d = np.abs((np.exp(ref["log_duration"]) - 1) % 1 - 0.5) > md
+        assert safe_p.mean() >= 0.8
         assert np.array_equal(pidx[b][safe_p], ref["pitch_idx"][safe_p])
         assert np.array_equal(eidx[b][safe_e], ref["energy_idx"][safe_e])
         assert np.array_equal(dur[b][safe_d], ref["duration"][safe_d])

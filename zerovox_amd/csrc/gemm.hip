@@ -1396,6 +1396,7 @@ static const Variant kVariants[] = {
     {"resfuse_bf16_c32", DT_BF16, 256, 32},       {"resfuse_bf16_c64", DT_BF16, 128, 64},
     {"gemm_bf16_64x64", DT_BF16, 64, 64},         {"gemm_f32_64x64", DT_F32, 64, 64},
     {"resstream_bf16_c32", DT_BF16, 64, 32},      {"resstream_bf16_c64", DT_BF16, 32, 64},
+    {"convslab_bf16_128x128", DT_BF16, 128, 128},
 };
 const char* gemm_variant_name(int id) { return kVariants[id].name; }
 int gemm_num_variants() { return (int)(sizeof(kVariants) / sizeof(kVariants[0])); }
@@ -1439,6 +1440,22 @@ static int launch_convslab(GemmArgs a, hipStream_t stream) {
         if (best_cost < 0 || cost < best_cost - 1e-9) { best_cost = cost; best = i; }
     }
     static const int bms[4] = {128, 256, 256, 256};
+    // short utterances (the phoneme encoder: M <= 128 rows each): 256-row tiles would be half empty.  128-row tiles, 128 or 256
+    // channels wide, whichever puts more workgroups on the chip while it is not yet full
+    if (a.M <= 128 && a.N >= 128) {
+        static int ncu = 0;
+        if (!ncu) { int dev = 0; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) ncu = 256; }
+        const int wide = ((a.N + 255) / 256) * a.nbatch;
+        const bool narrow = wide < 2 * ncu;
+        const int bn = narrow ? 128 : 256;
+        dim3 grid((a.N + bn - 1) / bn, a.nbatch);
+        size_t lds = ((size_t)(128 + hl + hr) * SLAB_PITCH + 1023) & ~(size_t)1023;
+        const size_t stage = (size_t)4 * 32 * (2 * 128 + 16);
+        if (lds < stage) lds = stage;
+        if (narrow) { launch_slab_variant<128, 128, 2, 2, 2, 0>(a, grid, lds, stream); return 22; }
+        launch_slab_variant<128, 256, 1, 4, 2, 0>(a, grid, lds, stream);
+        return 6;
+    }
     // 1x1 convs (StyleTTS decoder) have no tap reuse of the slab: the wider channel tile halves the re-reads of the input
     // rows, and 128-row tiles divide the decoder's 896 frames exactly
     if (a.ntaps == 1 && a.N >= 512) best = 0;

@@ -46,6 +46,46 @@ void launch_cast(const void* in, int in_dt, void* out, int out_dt, size_t n, hip
 }
 void launch_f32_to_bf16(const float* in, bf16_t* out, size_t n, hipStream_t s) { launch_cast(in, DT_F32, out, DT_BF16, n, s); }
 
+// ---------------------------------------------------------------- bf16 split planes of an f32 tensor
+// f32-class GEMMs on the bf16 MFMA: x = hi + lo (+ 2^-17 x), w = wh + wl likewise, and
+//     x.w ~= hi.wh + hi.wl + lo.wh     (the dropped lo.wl term is 2^-18 relative)
+// is ONE bf16 GEMM over a K axis of three planes: activations [hi | hi | lo] against weights [wh | wl | wh], accumulated in
+// f32 by the MFMA.  k_split3 writes the activation planes (rows past an utterance's length as zeros), k_split3_w the weights.
+__device__ __forceinline__ void split2(float v, unsigned short& hi, unsigned short& lo) {
+    hi = tobf(v);
+    lo = tobf(v - __uint_as_float(((unsigned)hi) << 16));
+}
+__global__ __launch_bounds__(256) void k_split3(const float* x, int ldx, unsigned short* out, int rows_max, const int* rows, int C) {
+    const int b = blockIdx.y, r = blockIdx.x;
+    const bool live = r < (rows ? rows[b] : rows_max);
+    const float* xr = x + ((long)b * rows_max + r) * ldx;
+    unsigned short* o = out + ((long)b * rows_max + r) * 3 * C;
+    for (int c = threadIdx.x * 4; c < C; c += blockDim.x * 4) {                 // C % 4 == 0
+        unsigned short h[4], l[4];
+        if (live) { const float4 v = *(const float4*)(xr + c); split2(v.x, h[0], l[0]); split2(v.y, h[1], l[1]); split2(v.z, h[2], l[2]); split2(v.w, h[3], l[3]); }
+        else { for (int e = 0; e < 4; e++) h[e] = l[e] = 0; }
+        const uint2 hv = make_uint2(h[0] | ((unsigned)h[1] << 16), h[2] | ((unsigned)h[3] << 16));
+        const uint2 lv = make_uint2(l[0] | ((unsigned)l[1] << 16), l[2] | ((unsigned)l[3] << 16));
+        *(uint2*)(o + c) = hv; *(uint2*)(o + C + c) = hv; *(uint2*)(o + 2 * C + c) = lv;
+    }
+}
+void launch_split3(const float* x, int ldx, void* out, int B, int rows_max, const int* rows, int C, hipStream_t s) {
+    if (rows_max <= 0) return;
+    hipLaunchKernelGGL(k_split3, dim3(rows_max, B), dim3(C >= 1024 ? 256 : 128), 0, s, x, ldx, (unsigned short*)out, rows_max, rows, C);
+}
+__global__ void k_split3_w(const float* w, unsigned short* out, long nrows, int K) {
+    const long r = blockIdx.x;
+    if (r >= nrows) return;
+    for (int k = threadIdx.x; k < K; k += blockDim.x) {
+        unsigned short h, l;
+        split2(w[r * K + k], h, l);
+        out[r * 3 * K + k] = h; out[r * 3 * K + K + k] = l; out[r * 3 * K + 2 * K + k] = h;
+    }
+}
+void launch_split3_weights(const float* w, void* out, long nrows, int K, hipStream_t s) {
+    hipLaunchKernelGGL(k_split3_w, dim3((unsigned)nrows), dim3(256), 0, s, w, (unsigned short*)out, nrows, K);
+}
+
 // ---------------------------------------------------------------- embedding + positional encoding
 __global__ void k_embed(const int* ph, const int* pu, const float* emb, int ed, const float* pemb, int pd,
                         const float* pe, float* out, int Tmax, const int* T) {

@@ -84,6 +84,8 @@ struct zvx_ctx {
     int profile = 0;
     int profile_only = -1;                 // >= 0: per-launch events only for this kernel variant (keeps the timed region lean)
     int rs_prof = 0;                       // zvx_set_int("rs_prof", 1): per-wave cycle counters of the streaming kernels (library built with -DRS_PROFILE)
+    int enc_split = 0;                     // bf16 mode: the f32 GEMMs of the phoneme encoder / variance adaptor run as 3-plane bf16 GEMMs
+    int voc_chunk = 0;                     // utterances per vocoder ResBlock sub-batch (0 = whole batch)
     int use_resstream = 1;                 // zvx_set_int("resstream", 0): ResBlocks of the narrow stages as per-pair launches (A/B, bit-equal)
     int shape_log = 0;                     // zvx_set_int("shape_log", 1): one stderr line per timed launch (profile 2)
     int max_frames = 1 << 18;              // hard cap on a predicted mel length (guards the allocation, fs2.py:678-681 has none)
@@ -309,6 +311,35 @@ void upload_weights(zvx_ctx* c) {
             }
         }
     }
+    // phoneme encoder (kept in f32 because it feeds discrete decisions): in bf16 mode its static-weight
+    // GEMMs run on the bf16 MFMA as 3-plane split products (ops.hip: k_split3), f32-class accuracy at ~5x the f32 MFMA rate.
+    // Weights [taps][N][K] -> bf16 [taps][N][wh | wl | wh], fragment-packed like every other slab-kernel weight.
+    if (c->enc_split) {
+        std::vector<std::pair<std::string, Tensor>> add;
+        size_t stotal = 0;
+        for (auto& kv : c->tensors) {
+            const Tensor& t = kv.second;
+            const bool mine = kv.first.rfind("enc.", 0) == 0;      // the variance predictors stay on the exact-f32 MFMA: N = 256 gives the
+                                                                     // slab tiling too few workgroups to win, and their outputs are the decisions
+            if (!mine || t.kind != 'f' || t.dims.size() != 3 || (3 * t.dim(2)) % 16 || t.dim(1) % 8) continue;
+            Tensor s3 = t;
+            s3.kind = 's'; s3.dtype = DT_BF16; s3.dims = {t.dim(0), t.dim(1), 3 * t.dim(2)}; s3.numel = t.numel * 3; s3.host = nullptr;
+            stotal += ((s3.numel * 2 + 255) & ~(size_t)255) + ((packed_weight_elems(s3.dim(0), s3.dim(1), s3.dim(2)) * 2 + 255) & ~(size_t)255);
+            add.emplace_back(kv.first + ".s3", s3);
+        }
+        char* sarena = stotal ? (char*)c->buf("weights_split", stotal) : nullptr;
+        size_t soff = 0;
+        for (auto& kv : add) {
+            Tensor& s3 = kv.second;
+            const Tensor& src = c->tensors[kv.first.substr(0, kv.first.size() - 3)];
+            s3.dev = sarena + soff; soff += (s3.numel * 2 + 255) & ~(size_t)255;
+            launch_split3_weights((const float*)src.dev, s3.dev, (long)src.dim(0) * src.dim(1), src.dim(2), c->stream);
+            void* pk = sarena + soff; soff += (packed_weight_elems(s3.dim(0), s3.dim(1), s3.dim(2)) * 2 + 255) & ~(size_t)255;
+            launch_pack_weights(s3.dev, s3.dim(0), s3.dim(1), s3.dim(2), pk, c->stream);
+            c->packed[s3.dev] = pk;
+            c->tensors[kv.first] = s3;
+        }
+    }
     HIPCHK(hipStreamSynchronize(c->stream));
     DevBuf& st = c->bufs["weights_staging"];
     HIPCHK(hipFree(st.base)); st.base = nullptr; st.p = nullptr; st.cap = 0;
@@ -319,6 +350,7 @@ void read_config(zvx_ctx* c) {
     if (it == c->cfg.end()) fail(ZVX_E_MANIFEST, "manifest: missing cfg 'precision'");
     if (it->second == "bf16") c->dt = DT_BF16; else if (it->second == "f32") c->dt = DT_F32;
     else fail(ZVX_E_MANIFEST, "manifest: unknown precision '%s'", it->second.c_str());
+    c->enc_split = c->dt == DT_BF16 ? (c->cfg.count("enc_split") ? c->cfg_int("enc_split") : 1) : 0;
     c->H = c->cfg_int("hidden"); c->emb_dim = c->cfg_int("emb_dim"); c->punct_dim = c->cfg_int("punct_dim");
     c->n_phone_rows = c->cfg_int("n_phone_rows"); c->n_punct_rows = c->cfg_int("n_punct_rows");
     c->max_txt_len = c->cfg_int("max_txt_len"); c->max_mel_len = c->cfg_int("max_mel_len");
@@ -364,10 +396,23 @@ void fft_block(zvx_ctx* c, void* x, int dt, int B, int Lmax, const int* len_dev,
     float* y = c->fbuf("fft.y", (size_t)B * Lmax * H);
     void* hbuf = c->buf("fft.h", (size_t)B * Lmax * F * es);
 
+    // f32 blocks (phoneme encoder) in bf16 mode: the static-weight GEMMs take bf16 split planes [hi | hi | lo] of their f32 input
+    // against [wh | wl | wh] weights (K = 3 x the logical K): f32-class results from the bf16 MFMA
+    const bool split = dt == DT_F32 && c->enc_split && c->has(w.p + ".wqk.s3");
+    void* xs = split ? c->buf("fft.xs", (size_t)B * Lmax * 3 * H * 2) : nullptr;
+    auto split_of = [&](const float* src, int C, void* dst) { launch_split3(src, C, dst, B, Lmax, len_dev, C, c->stream); };
+    auto as_split = [&](GemmArgs& a, const void* planes, int C, const std::string& wname) {      // operand swap: same GEMM, 3-plane K axis
+        const Tensor& ws = c->t(wname + ".s3");
+        a.dtype = DT_BF16; a.X = planes; a.x_bs = (long)Lmax * 3 * C; a.ldx = 3 * C; a.K = 3 * C;
+        a.W = ws.dev; a.ldw = 3 * C; a.w_ts = (long)ws.dim(1) * 3 * C;
+        a.flops = 2.0 * (double)a.M * a.nbatch * a.N * C * a.ntaps;                                 // algorithmic (f32) work, not the 3x issued
+    };
+    if (split) split_of((const float*)x, H, xs);
     {   // [Q | K] = x Wqk^T + b                                       fs2.py:143-144
         GemmArgs a = gemm_base(dt);
         a.X = x; a.x_bs = (long)Lmax * H; a.ldx = H; a.W = c->t(w.p + ".wqk").dev; a.ldw = H;
         a.M = Lmax; a.N = 2 * H; a.K = H; a.nbatch = B; a.in_len = len_dev; a.out_len = len_dev;
+        if (split) { as_split(a, xs, H, w.p + ".wqk"); a.out_dtype = DT_F32; }
         a.bias = c->pf(w.p + ".bqk"); a.bias_mode = 1;
         a.out = qk; a.o_bs = (long)Lmax * 2 * H; a.ldo = 2 * H;
         c->gemm(a);
@@ -409,6 +454,7 @@ void fft_block(zvx_ctx* c, void* x, int dt, int B, int Lmax, const int* len_dev,
         a.bias = c->pf(w.p + ".bo"); a.bias_mode = 1;
         a.res = x; a.r_bs = (long)Lmax * H; a.ldr = H; a.res_mode = 1; a.res_dtype = dt;
         a.out = y; a.out_dtype = DT_F32; a.o_bs = (long)Lmax * H; a.ldo = H;
+        if (split) { split_of((const float*)o, H, xs); as_split(a, xs, H, w.p + ".wo"); }
         c->gemm(a);
     }
     const double ln_bytes = (double)B * Lmax * H * (4.0 + es);
@@ -423,6 +469,7 @@ void fft_block(zvx_ctx* c, void* x, int dt, int B, int Lmax, const int* len_dev,
         set_taps_1d(a, c->ffn_k0, 1);
         a.bias = c->pf(w.p + ".b1"); a.bias_mode = 1; a.act = ACT_RELU;
         a.out = hbuf; a.o_bs = (long)Lmax * F; a.ldo = F;
+        if (split) { split_of((const float*)x, H, xs); as_split(a, xs, H, w.p + ".w1"); a.out_dtype = DT_F32; }
         c->gemm(a);
     }
     {   // y = conv_k1(h) + residual                                    fs2.py:201-207
@@ -433,6 +480,7 @@ void fft_block(zvx_ctx* c, void* x, int dt, int B, int Lmax, const int* len_dev,
         a.bias = c->pf(w.p + ".b2"); a.bias_mode = 1;
         a.res = x; a.r_bs = (long)Lmax * H; a.ldr = H; a.res_mode = 1; a.res_dtype = dt;
         a.out = y; a.out_dtype = DT_F32; a.o_bs = (long)Lmax * H; a.ldo = H;
+        if (split) { void* hs = c->buf("fft.hs", (size_t)B * Lmax * 3 * F * 2); split_of((const float*)hbuf, F, hs); as_split(a, hs, F, w.p + ".w2"); }
         c->gemm(a);
     }
     c->timed(0, ln_bytes, [&] {
@@ -787,127 +835,141 @@ void run_vocoder(zvx_ctx* c, const float* mel, int ldm, int Lmel_max, const int*
         }
         const float next_slope = (i == ns - 1) ? 0.01f : 0.1f;          // hifigan.py:126 uses the default slope 0.01
         c->tag = "voc.res" + std::to_string(i + 1);
-        for (int j = 0; j < nk; j++) {
-            const int k = c->voc_rb_k[j];
-            const std::vector<int>& dil = c->voc_rb_d[j];
-            const int nd = (int)dil.size();
-            const std::string rb = "voc.rb" + std::to_string(i * nk + j);
-            const void* cur = X0;
-            int pp = 0;
-            int t_first = 0;
-            if (c->voc_resblock == 1 && dt == DT_BF16 && c->use_resstream && nd >= 1 && nd <= 3) {
-                // whole ResBlock (or its first two pairs + the last one) as streaming launches: the stage tensor crosses HBM once
-                bool packed_ok = true;
-                for (int t = 0; t < nd; t++)
-                    packed_ok = packed_ok && c->packed.count(c->t(rb + ".c1_" + std::to_string(t) + "_w").dev) && c->packed.count(c->t(rb + ".c2_" + std::to_string(t) + "_w").dev);
-                auto chain = [&](int t0, int np, const void* in, bool closes) {
-                    StreamArgs sa;
-                    memset(&sa, 0, sizeof sa);
-                    sa.X = in; sa.x_bs = (long)rows * Cout; sa.ldx = Cout; sa.C = Cout; sa.ntaps = k; sa.npair = np;
-                    for (int q = 0; q < np; q++) {
-                        const std::string ts = std::to_string(t0 + q);
-                        sa.W1[q] = c->packed[c->t(rb + ".c1_" + ts + "_w").dev]; sa.W2[q] = c->packed[c->t(rb + ".c2_" + ts + "_w").dev];
-                        sa.b1[q] = c->pf(rb + ".c1_" + ts + "_b"); sa.b2[q] = c->pf(rb + ".c2_" + ts + "_b");
-                        sa.dil[q] = dil[t0 + q];
-                    }
-                    if (c->rs_prof) sa.prof = (long long*)c->buf("rs.prof." + rb + "." + std::to_string(t0), 16 * 8 * 8);   // RS_PROFILE builds only
-                    sa.slope1 = 0.1f; sa.res_inv_slope = 10.0f; sa.out_scale = 1.f; sa.slope = 0.1f;
-                    sa.len = len; sa.M = rows; sa.nbatch = B; sa.o_bs = (long)rows * Cout; sa.ldo = Cout; sa.a_bs = (long)rows * Cout; sa.lda = Cout;
-                    if (!closes) { sa.out = PP[pp]; }
-                    else if (nk == 1) { sa.out = A; sa.slope = next_slope; }
-                    else {
-                        sa.accum = XS; sa.accum_mode = j == 0 ? 2 : (j < nk - 1 ? 3 : 1);
-                        if (j == nk - 1) { sa.out = A; sa.out_scale = 1.0f / nk; sa.slope = next_slope; }
-                    }
-                    return sa;
-                };
-                if (packed_ok) {
-                    StreamArgs whole = chain(0, nd, X0, true);
-                    if (c->run_stream(whole)) t_first = nd;
-                    else if (nd == 3) {
-                        StreamArgs head = chain(0, 2, X0, false);
-                        StreamArgs probe = chain(2, 1, PP[pp], true);
-                        if (launch_resstream(head, c->stream, true) >= 0 && launch_resstream(probe, c->stream, true) >= 0) {
-                            c->run_stream(head);
-                            cur = PP[pp]; pp ^= 1;
-                            StreamArgs tail = chain(2, 1, cur, true);
-                            c->run_stream(tail);
-                            t_first = nd;
+        // The stage's ResBlocks can run on sub-batches of utterances (zvx_set_int("voc_chunk", n)) so that the tensors one
+        // sub-batch touches stay in the 256 MB Infinity Cache between launches.  Measured on B = 32 x 896 frames: no gain at
+        // any size (stage 2: 7.70 ms whole batch, 7.70 / 7.74 / 8.40 ms at 16 / 8 / 4 utterances) -- these stages are bound by
+        // MFMA issue, not by HBM -- so the default is the whole batch.  Results are bit-identical for any sub-batch size.
+        const size_t utt_bytes = (size_t)rows * Cout * es;
+        const int CH = (c->voc_chunk > 0 && c->voc_chunk < B) ? c->voc_chunk : B;
+        for (int b0 = 0; b0 < B; b0 += CH) {
+            const int Bs = std::min(CH, B - b0);
+            const size_t boff = (size_t)b0 * utt_bytes;
+            const void* X0s = (const char*)X0 + boff;
+            void* T1s = (char*)T1 + boff; void* XSs = (char*)XS + boff; void* As = (char*)A + boff;
+            void* PPs[2] = {(char*)PP[0] + boff, (char*)PP[1] + boff};
+            const int* lens = len + b0;
+            for (int j = 0; j < nk; j++) {
+                const int k = c->voc_rb_k[j];
+                const std::vector<int>& dil = c->voc_rb_d[j];
+                const int nd = (int)dil.size();
+                const std::string rb = "voc.rb" + std::to_string(i * nk + j);
+                const void* cur = X0s;
+                int pp = 0;
+                int t_first = 0;
+                if (c->voc_resblock == 1 && dt == DT_BF16 && c->use_resstream && nd >= 1 && nd <= 3) {
+                    // whole ResBlock (or its first two pairs + the last one) as streaming launches: the stage tensor crosses HBM once
+                    bool packed_ok = true;
+                    for (int t = 0; t < nd; t++)
+                        packed_ok = packed_ok && c->packed.count(c->t(rb + ".c1_" + std::to_string(t) + "_w").dev) && c->packed.count(c->t(rb + ".c2_" + std::to_string(t) + "_w").dev);
+                    auto chain = [&](int t0, int np, const void* in, bool closes) {
+                        StreamArgs sa;
+                        memset(&sa, 0, sizeof sa);
+                        sa.X = in; sa.x_bs = (long)rows * Cout; sa.ldx = Cout; sa.C = Cout; sa.ntaps = k; sa.npair = np;
+                        for (int q = 0; q < np; q++) {
+                            const std::string ts = std::to_string(t0 + q);
+                            sa.W1[q] = c->packed[c->t(rb + ".c1_" + ts + "_w").dev]; sa.W2[q] = c->packed[c->t(rb + ".c2_" + ts + "_w").dev];
+                            sa.b1[q] = c->pf(rb + ".c1_" + ts + "_b"); sa.b2[q] = c->pf(rb + ".c2_" + ts + "_b");
+                            sa.dil[q] = dil[t0 + q];
+                        }
+                        if (c->rs_prof) sa.prof = (long long*)c->buf("rs.prof." + rb + "." + std::to_string(t0), 16 * 8 * 8);   // RS_PROFILE builds only
+                        sa.slope1 = 0.1f; sa.res_inv_slope = 10.0f; sa.out_scale = 1.f; sa.slope = 0.1f;
+                        sa.len = lens; sa.M = rows; sa.nbatch = Bs; sa.o_bs = (long)rows * Cout; sa.ldo = Cout; sa.a_bs = (long)rows * Cout; sa.lda = Cout;
+                        if (!closes) { sa.out = PPs[pp]; }
+                        else if (nk == 1) { sa.out = As; sa.slope = next_slope; }
+                        else {
+                            sa.accum = XSs; sa.accum_mode = j == 0 ? 2 : (j < nk - 1 ? 3 : 1);
+                            if (j == nk - 1) { sa.out = As; sa.out_scale = 1.0f / nk; sa.slope = next_slope; }
+                        }
+                        return sa;
+                    };
+                    if (packed_ok) {
+                        StreamArgs whole = chain(0, nd, X0s, true);
+                        if (c->run_stream(whole)) t_first = nd;
+                        else if (nd == 3) {
+                            StreamArgs head = chain(0, 2, X0s, false);
+                            StreamArgs probe = chain(2, 1, PPs[pp], true);
+                            if (launch_resstream(head, c->stream, true) >= 0 && launch_resstream(probe, c->stream, true) >= 0) {
+                                c->run_stream(head);
+                                cur = PPs[pp]; pp ^= 1;
+                                StreamArgs tail = chain(2, 1, cur, true);
+                                c->run_stream(tail);
+                                t_first = nd;
+                            }
                         }
                     }
                 }
-            }
-            for (int t = t_first; t < nd; t++) {
-                const bool last = (t == nd - 1);
-                const void* cin_buf = cur;
-                auto rb_base = [&] {
-                    GemmArgs a = gemm_base(dt);
-                    a.M = rows; a.N = Cout; a.K = Cout; a.nbatch = B; a.in_len = len; a.out_len = len; a.ldw = Cout; a.w_ts = (long)Cout * Cout;
-                    a.x_bs = (long)rows * Cout; a.ldx = Cout; a.o_bs = (long)rows * Cout; a.ldo = Cout;
-                    return a;
-                };
-                // what the LAST conv of the iteration does with its result: + bias + x (raw residual recovered from the activated
-                // input), then either the next iteration's input (activated) or the stage's running sum / mean
-                int pp_next = pp;
-                auto rb_tail = [&](GemmArgs& a) {
-                    a.bias_mode = 1;
-                    a.res = cin_buf; a.r_bs = (long)rows * Cout; a.ldr = Cout; a.res_mode = 2; a.res_inv_slope = 10.0f; a.res_dtype = dt;
-                    if (!last) {
-                        a.act = ACT_LRELU; a.slope = 0.1f; a.out = PP[pp];
-                        pp_next = pp ^ 1;
+                for (int t = t_first; t < nd; t++) {
+                    const bool last = (t == nd - 1);
+                    const void* cin_buf = cur;
+                    auto rb_base = [&] {
+                        GemmArgs a = gemm_base(dt);
+                        a.M = rows; a.N = Cout; a.K = Cout; a.nbatch = Bs; a.in_len = lens; a.out_len = lens; a.ldw = Cout; a.w_ts = (long)Cout * Cout;
+                        a.x_bs = (long)rows * Cout; a.ldx = Cout; a.o_bs = (long)rows * Cout; a.ldo = Cout;
+                        return a;
+                    };
+                    // what the LAST conv of the iteration does with its result: + bias + x (raw residual recovered from the activated
+                    // input), then either the next iteration's input (activated) or the stage's running sum / mean
+                    int pp_next = pp;
+                    auto rb_tail = [&](GemmArgs& a) {
+                        a.bias_mode = 1;
+                        a.res = cin_buf; a.r_bs = (long)rows * Cout; a.ldr = Cout; a.res_mode = 2; a.res_inv_slope = 10.0f; a.res_dtype = dt;
+                        if (!last) {
+                            a.act = ACT_LRELU; a.slope = 0.1f; a.out = PPs[pp];
+                            pp_next = pp ^ 1;
+                        } else {
+                            // xs (+)= resblock output; last kernel size: x = xs / num_kernels, stored activated for the next stage
+                            a.accum = XSs; a.accum_dtype = dt; a.a_bs = (long)rows * Cout; a.lda = Cout;
+                            if (nk == 1) { a.accum_mode = 0; a.accum = nullptr; }
+                            else if (j == 0) a.accum_mode = 2;
+                            else if (j < nk - 1) a.accum_mode = 3;
+                            else a.accum_mode = 1;
+                            if (j == nk - 1) { a.out = As; a.out_scale = 1.0f / nk; a.act = ACT_LRELU; a.slope = next_slope; }
+                            else a.out = nullptr;
+                        }
+                    };
+                    GemmArgs a = rb_base();
+                    if (c->voc_resblock == 1) {
+                        const std::string ts = std::to_string(t);
+                        const Tensor& w1 = c->t(rb + ".c1_" + ts + "_w");
+                        const Tensor& w2 = c->t(rb + ".c2_" + ts + "_w");
+                        bool fuse = dt == DT_BF16 && c->packed.count(w1.dev) && c->packed.count(w2.dev);
+                        if (fuse) {
+                            // one launch: xt = lrelu(c1(x_act)+b1) stays in LDS; x' = c2(xt) + b2 + x      hifigan.py:51-55
+                            a.X = cur; a.W = w2.dev; a.Wp = c->packed[w2.dev]; a.Wp2 = c->packed[w1.dev];
+                            a.bias1 = c->pf(rb + ".c1_" + ts + "_b"); a.slope1 = 0.1f; a.fused = 1;
+                            set_taps_1d(a, k, 1);
+                            for (int q = 0; q < k; q++) a.dv1[q] = (q - (k - 1) / 2) * dil[t];
+                            a.bias = c->pf(rb + ".c2_" + ts + "_b");
+                            a.flops = 2.0 * 2.0 * Bs * (double)rows * Cout * Cout * k;
+                            rb_tail(a);
+                            // the fused kernels cover a subset of (C, k, dilation, LDS footprint): ask the launcher (dry run) first
+                            fuse = gemm_variant_of(a) >= 0;
+                        }
+                        if (!fuse) {
+                            // xt = c1(lrelu(x)); stored as lrelu(xt)                       hifigan.py:51-53
+                            a = rb_base();
+                            a.X = cur; a.W = w1.dev;
+                            set_taps_1d(a, k, dil[t]);
+                            a.bias = c->pf(rb + ".c1_" + ts + "_b"); a.bias_mode = 1; a.act = ACT_LRELU; a.slope = 0.1f;
+                            a.out = T1s;
+                            c->gemm(a);
+                            // x = c2(.) + x                                                hifigan.py:54-55
+                            a = rb_base();
+                            a.X = T1s; a.W = w2.dev;
+                            set_taps_1d(a, k, 1);
+                            a.bias = c->pf(rb + ".c2_" + ts + "_b");
+                            rb_tail(a);
+                        }
                     } else {
-                        // xs (+)= resblock output; last kernel size: x = xs / num_kernels, stored activated for the next stage
-                        a.accum = XS; a.accum_dtype = dt; a.a_bs = (long)rows * Cout; a.lda = Cout;
-                        if (nk == 1) { a.accum_mode = 0; a.accum = nullptr; }
-                        else if (j == 0) a.accum_mode = 2;
-                        else if (j < nk - 1) a.accum_mode = 3;
-                        else a.accum_mode = 1;
-                        if (j == nk - 1) { a.out = A; a.out_scale = 1.0f / nk; a.act = ACT_LRELU; a.slope = next_slope; }
-                        else a.out = nullptr;
-                    }
-                };
-                GemmArgs a = rb_base();
-                if (c->voc_resblock == 1) {
-                    const std::string ts = std::to_string(t);
-                    const Tensor& w1 = c->t(rb + ".c1_" + ts + "_w");
-                    const Tensor& w2 = c->t(rb + ".c2_" + ts + "_w");
-                    bool fuse = dt == DT_BF16 && c->packed.count(w1.dev) && c->packed.count(w2.dev);
-                    if (fuse) {
-                        // one launch: xt = lrelu(c1(x_act)+b1) stays in LDS; x' = c2(xt) + b2 + x      hifigan.py:51-55
-                        a.X = cur; a.W = w2.dev; a.Wp = c->packed[w2.dev]; a.Wp2 = c->packed[w1.dev];
-                        a.bias1 = c->pf(rb + ".c1_" + ts + "_b"); a.slope1 = 0.1f; a.fused = 1;
-                        set_taps_1d(a, k, 1);
-                        for (int q = 0; q < k; q++) a.dv1[q] = (q - (k - 1) / 2) * dil[t];
-                        a.bias = c->pf(rb + ".c2_" + ts + "_b");
-                        a.flops = 2.0 * 2.0 * B * (double)rows * Cout * Cout * k;
-                        rb_tail(a);
-                        // the fused kernels cover a subset of (C, k, dilation, LDS footprint): ask the launcher (dry run) first
-                        fuse = gemm_variant_of(a) >= 0;
-                    }
-                    if (!fuse) {
-                        // xt = c1(lrelu(x)); stored as lrelu(xt)                       hifigan.py:51-53
-                        a = rb_base();
-                        a.X = cur; a.W = w1.dev;
+                        // x = c(lrelu(x)) + x                                          hifigan.py:78-81
+                        a.X = cur; a.W = c->t(rb + ".c_" + std::to_string(t) + "_w").dev;
                         set_taps_1d(a, k, dil[t]);
-                        a.bias = c->pf(rb + ".c1_" + ts + "_b"); a.bias_mode = 1; a.act = ACT_LRELU; a.slope = 0.1f;
-                        a.out = T1;
-                        c->gemm(a);
-                        // x = c2(.) + x                                                hifigan.py:54-55
-                        a = rb_base();
-                        a.X = T1; a.W = w2.dev;
-                        set_taps_1d(a, k, 1);
-                        a.bias = c->pf(rb + ".c2_" + ts + "_b");
+                        a.bias = c->pf(rb + ".c_" + std::to_string(t) + "_b");
                         rb_tail(a);
                     }
-                } else {
-                    // x = c(lrelu(x)) + x                                          hifigan.py:78-81
-                    a.X = cur; a.W = c->t(rb + ".c_" + std::to_string(t) + "_w").dev;
-                    set_taps_1d(a, k, dil[t]);
-                    a.bias = c->pf(rb + ".c_" + std::to_string(t) + "_b");
-                    rb_tail(a);
+                    c->gemm(a);
+                    if (!last) { cur = PPs[pp]; pp = pp_next; }
                 }
-                c->gemm(a);
-                if (!last) { cur = PP[pp]; pp = pp_next; }
             }
         }
         Cin = Cout; mul *= u;
@@ -1216,6 +1278,8 @@ zvx_status zvx_set_int(zvx_ctx* c, const char* key, int64_t value) {
         else if (std::string(key) == "profile_only") { c->sync(); c->profile_only = (int)value; }
         else if (std::string(key) == "shape_log") c->shape_log = (int)value;
         else if (std::string(key) == "resstream") c->use_resstream = (int)value;
+        else if (std::string(key) == "voc_chunk") c->voc_chunk = (int)value;
+        else if (std::string(key) == "enc_split") c->enc_split = (c->dt == DT_BF16 && value && c->has("enc.0.wqk.s3")) ? 1 : 0;
         else if (std::string(key) == "rs_prof") c->rs_prof = (int)value;
         else if (std::string(key) == "max_frames") { if (value < 1 || value > (1 << 24)) fail(ZVX_E_INVALID, "max_frames out of range"); c->max_frames = (int)value; }
         else fail(ZVX_E_INVALID, "unknown option '%s'", key);

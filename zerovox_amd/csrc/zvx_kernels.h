@@ -107,6 +107,11 @@ void resstream_profile_events(hipEvent_t start, hipEvent_t stop);     // like ge
 void launch_f32_to_bf16(const float* in, bf16_t* out, size_t n, hipStream_t s);
 void launch_cast(const void* in, int in_dt, void* out, int out_dt, size_t n, hipStream_t s);
 
+// f32 -> three bf16 planes [hi | hi | lo] per row (out [b][rows_max][3C]; rows >= rows[b] -> zeros) and weights
+// [nrows][K] -> [nrows][hi | lo | hi]: an f32-class GEMM as one bf16 GEMM over 3K (see ops.hip)
+void launch_split3(const float* x, int ldx, void* out, int B, int rows_max, const int* rows, int C, hipStream_t s);
+void launch_split3_weights(const float* w, void* out, long nrows, int K, hipStream_t s);
+
 // encoder front: out[b][t][:] = cat(emb[ph], pemb[pu]) + pe[t]      (fs2.py:372-392)
 void launch_embed(const int* phoneme, const int* puncts, const float* emb, int emb_dim, const float* pemb,
                   int pemb_dim, const float* pe, float* out, int B, int Tmax, const int* T, hipStream_t s);
