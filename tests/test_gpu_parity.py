@@ -705,3 +705,28 @@ def test_demo_cli_prints_the_reference_rtf_lines(capsys, monkeypatch, tmp_path):
     assert len(its) == 13 and lines[0] == "computing speaker embedding..." and re.match(r"^Average RTF: \d+\.\d\d$", lines[-1])
     with wave.open(str(out_wav), "rb") as w:
         assert w.getframerate() == 22050 and w.getnchannels() == 1 and w.getsampwidth() == 2 and w.getnframes() > 0
+
+
+def test_fused_attention_of_the_fs2_decoder():
+    """attention.hip (softmax(Q K^T / sqrt(d)) V in one launch, online softmax, no [L][L] tensor) against the score-GEMM +
+    softmax + PV-GEMM path it replaces (both bf16: equal to bf16 rounding) and against the oracle; ragged lengths down to 2 frames,
+    lengths that are not multiples of the 32-key tile or the 128-query tile, and more than one query tile."""
+    ctx = ctx_for("fastspeech2", "tiny", "bf16")
+    cfg, sd = tts_sd("fastspeech2")
+    rng = np.random.default_rng(41)
+    L = np.array([50, 2, 130, 33, 257], np.int32)
+    feats = np.zeros((5, 257, 528), np.float32)
+    spk = rng.standard_normal((5, 528)).astype(np.float32); spk /= np.linalg.norm(spk, axis=1, keepdims=True)
+    for b in range(5):
+        feats[b, :L[b]] = rng.standard_normal((L[b], 528)).astype(np.float32)
+    try:
+        ctx.set_int("flash", 0); unfused = ctx.decode_features(feats, L, spk)
+        ctx.set_int("flash", 1); fused = ctx.decode_features(feats, L, spk)
+    finally:
+        ctx.set_int("flash", 1)
+    for b in range(5):
+        ref = O.fs2_decoder(feats[b, :L[b]], spk[b], sd, cfg)
+        check_mel(fused[b, :L[b]], ref, "bf16", f"fused attention utt {b}")
+        check_mel(unfused[b, :L[b]], ref, "bf16", f"unfused attention utt {b}")
+        assert np.abs(fused[b, :L[b]] - unfused[b, :L[b]]).max() < 0.08
+        assert not fused[b, L[b]:].any()

@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libzvx.so")
-SOURCES = ["gemm.hip", "resstream.hip", "ops.hip", "zvx.hip"]
+SOURCES = ["gemm.hip", "resstream.hip", "attention.hip", "ops.hip", "zvx.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-inline-asm"]
 # gemm.hip: no NaN is ever a legitimate operand of its epilogue min/max (leaky-relu and its inverse); without this flag every
 # fminf/fmaxf input coming from a bit operation (bf16 unpack) gets a canonicalising `v_max x, x, x` in front (IEEE mode)

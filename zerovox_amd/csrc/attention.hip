@@ -1,0 +1,213 @@
+// attention.hip -- fused scaled-dot-product attention for the FS2 / SCLN mel decoder (fs2.py:47-58, 133-164), bf16 in, f32 state.
+//
+//     out[q][:] = softmax_k( Q[q].K[k] / sqrt(d)  masked to k < len ) . V[k][:]
+//
+// One workgroup = one (utterance, head, 128-query tile); its four waves own 32 queries each.  Keys / values stream through
+// LDS in 32-key tiles (double-buffered, global loads of tile t+1 in flight while tile t is computed); the [L][L] score
+// matrix never exists in HBM (the unfused path moved 2 x 205 MB of f32 scores + 2 x 103 MB of bf16 probabilities per layer
+// at B = 32, L = 896).  Online softmax keeps (running max, running sum) per query in registers.
+//
+// MFMA layout trick: scores are computed TRANSPOSED, S^T = K.Q^T (A = K rows from LDS, B = Q fragments held in registers),
+// so a lane owns ONE query and 16 keys per 32-key block -- the row max / row sum are in-register reductions plus one
+// exchange between lanes l and l+32 -- and P^T is already the B operand of O^T = V^T.P^T after one v_permlane32_swap per
+// 8 keys (no LDS round trip for P).  V arrives transposed from its projection GEMM ([d][key], key-contiguous), so the A
+// operand of the second product is a plain ds_read_b128 as well.  d = 264 is padded to 272 (17 k16 steps) for Q.K and to
+// 288 (9 row tiles) for the output; one wave per SIMD with the full 512-register file (9 x 16 output accumulators, 17 Q
+// fragments, 2 x 16 score accumulators).
+#include "mfma_util.h"
+#include "zvx_kernels.h"
+
+#include <hip/hip_ext.h>
+
+namespace zvx {
+
+static thread_local hipEvent_t g_fa_ev_start = nullptr, g_fa_ev_stop = nullptr;
+void flash_profile_events(hipEvent_t start, hipEvent_t stop) { g_fa_ev_start = start; g_fa_ev_stop = stop; }
+
+#define FA_BQ 128
+#define FA_BK 32
+#define FA_NKB (FA_BK / 32)      // 32-key blocks per tile
+
+template <int D>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void flash_attn_kernel(const FlashArgs a) {
+    constexpr int KS = (D + 15) / 16, DP = KS * 16;             // k16 steps / padded depth of Q.K
+    constexpr int NDB = (D + 31) / 32, DO = NDB * 32;           // 32-row output tiles / padded depth of the output
+    constexpr int KP = DP * 2 + 16;                             // LDS pitch of a K row (bytes): odd number of 16-byte slots
+    constexpr int VP = FA_BK * 2 + 16;                          // LDS pitch of a V^T row
+    constexpr int KCH = DP / 8, VCH = FA_BK / 8;                // 16-byte chunks per row
+    constexpr int KIT = (FA_BK * KCH + 255) / 256, VIT = (DO * VCH + 255) / 256;
+    constexpr int KBYTES = FA_BK * KP, VBYTES = DO * VP;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // [2][K tile | V^T tile]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l32 = lane & 31, hi = lane >> 5;
+    const int b = blockIdx.y / a.nheads, h = blockIdx.y - b * a.nheads;
+    const int len = a.len ? a.len[b] : a.L;
+    const int q0 = blockIdx.x * FA_BQ;
+    if (q0 >= len) return;
+    const unsigned short* const Qg = (const unsigned short*)a.qk + (long)b * a.qk_bs + (long)h * D;
+    const unsigned short* const Kg = Qg + a.k_off;
+    const unsigned short* const Vg = (const unsigned short*)a.vt + (long)b * a.vt_bs + (long)h * D * a.ldv;
+    const int q = q0 + wave * 32 + l32;
+
+    // ---- Q fragments (B operand of S^T = K.Q^T): 8 consecutive depth elements of this lane's query per k16 step ----
+    uint4 qf[KS];
+#pragma unroll
+    for (int s = 0; s < KS; s++) {
+        const int d0 = 16 * s + 8 * hi;
+        qf[s] = make_uint4(0, 0, 0, 0);
+        if (q < len && d0 < D) qf[s] = *(const uint4*)(Qg + (long)q * a.ldq + d0);       // D % 8 == 0: a chunk is all inside or all padding
+    }
+
+    // ---- staging of one K / V^T tile: global -> registers (issued a tile ahead) -> LDS ----
+    uint4 kreg[KIT], vreg[VIT];
+    auto load_tile = [&](int k0) {
+#pragma unroll
+        for (int it = 0; it < KIT; it++) {
+            const int c = tid + it * 256, row = c / KCH, ch = c - row * KCH;
+            kreg[it] = make_uint4(0, 0, 0, 0);
+            if (c < FA_BK * KCH && k0 + row < len && ch * 8 < D) kreg[it] = *(const uint4*)(Kg + (long)(k0 + row) * a.ldq + ch * 8);
+        }
+#pragma unroll
+        for (int it = 0; it < VIT; it++) {
+            const int c = tid + it * 256, row = c / VCH, ch = c - row * VCH;
+            vreg[it] = make_uint4(0, 0, 0, 0);
+            if (c < DO * VCH && row < D && k0 + ch * 8 < len) vreg[it] = *(const uint4*)(Vg + (long)row * a.ldv + k0 + ch * 8);
+        }
+    };
+    auto store_tile = [&](int buf) {
+        unsigned char* const kb = lds + buf * (KBYTES + VBYTES);
+        unsigned char* const vb = kb + KBYTES;
+#pragma unroll
+        for (int it = 0; it < KIT; it++) {
+            const int c = tid + it * 256, row = c / KCH, ch = c - row * KCH;
+            if (c < FA_BK * KCH) *(uint4*)(kb + row * KP + ch * 16) = kreg[it];
+        }
+#pragma unroll
+        for (int it = 0; it < VIT; it++) {
+            const int c = tid + it * 256, row = c / VCH, ch = c - row * VCH;
+            if (c < DO * VCH) *(uint4*)(vb + row * VP + ch * 16) = vreg[it];
+        }
+    };
+
+    f32x16 o[NDB];
+#pragma unroll
+    for (int i = 0; i < NDB; i++)
+#pragma unroll
+        for (int e = 0; e < 16; e++) o[i][e] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;                       // running max (shared by the lane pair) and this lane's partial row sum
+    const float sc = a.scale * 1.4426950408889634f;             // exp(x) = exp2(x log2 e)
+
+    const int ntiles = (len + FA_BK - 1) / FA_BK;
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+    for (int t = 0; t < ntiles; t++) {
+        const int k0 = t * FA_BK;
+        if (t + 1 < ntiles) load_tile(k0 + FA_BK);              // in flight while this tile is computed
+        const unsigned char* const kb = lds + (t & 1) * (KBYTES + VBYTES);
+        const unsigned char* const vb = kb + KBYTES;
+
+        // ---- S^T = K.Q^T: two 32-key blocks x 32 queries ----
+        f32x16 s[FA_NKB];
+#pragma unroll
+        for (int kbk = 0; kbk < FA_NKB; kbk++) {
+#pragma unroll
+            for (int e = 0; e < 16; e++) s[kbk][e] = 0.f;
+            const unsigned char* const rowp = kb + (kbk * 32 + l32) * KP + hi * 16;
+#pragma unroll
+            for (int st = 0; st < KS; st++) {
+                const uint4 kf = *(const uint4*)(rowp + st * 32);
+                s[kbk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf), __builtin_bit_cast(bf16x8, qf[st]), s[kbk], 0, 0, 0);
+            }
+        }
+        // ---- online softmax over this lane's 32 keys (+ the partner lane's 32): key of element (kbk, g, e) = 32 kbk + 8 g + 4 hi + e ----
+        float mt = -INFINITY;
+#pragma unroll
+        for (int kbk = 0; kbk < FA_NKB; kbk++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                const int key = k0 + kbk * 32 + 8 * (e >> 2) + 4 * hi + (e & 3);
+                const float v = key < len ? s[kbk][e] * sc : -INFINITY;
+                s[kbk][e] = v;
+                mt = fmaxf(mt, v);
+            }
+        mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+        const float m_new = fmaxf(m_run, mt);                   // finite: every tile has at least one valid key
+        const float alpha = exp2f(m_run - m_new);               // first tile: exp2(-inf) = 0
+        m_run = m_new;
+        float rs = 0.f;
+        unsigned pk[FA_NKB][8];                                      // probabilities as bf16 pairs: pk[kbk][2 g + (0: e 0,1 | 1: e 2,3)]
+#pragma unroll
+        for (int kbk = 0; kbk < FA_NKB; kbk++)
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const float p0 = exp2f(s[kbk][4 * g] - m_new), p1 = exp2f(s[kbk][4 * g + 1] - m_new);
+                const float p2 = exp2f(s[kbk][4 * g + 2] - m_new), p3 = exp2f(s[kbk][4 * g + 3] - m_new);
+                rs += (p0 + p1) + (p2 + p3);
+                pk[kbk][2 * g] = pack_bf16x2(p0, p1); pk[kbk][2 * g + 1] = pack_bf16x2(p2, p3);
+            }
+        l_run = l_run * alpha + rs;
+#pragma unroll
+        for (int i = 0; i < NDB; i++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) o[i][e] *= alpha;
+        // ---- P^T as B operand of O^T += V^T.P^T: lanes l / l+32 swap the halves of every 8-key group (v_permlane32_swap) ----
+        uint4 pf[2 * FA_NKB];                                            // key steps of 16: step 2 kbk + t covers keys 32 kbk + 16 t .. + 15
+#pragma unroll
+        for (int kbk = 0; kbk < FA_NKB; kbk++)
+#pragma unroll
+            for (int tt = 0; tt < 2; tt++) {
+                unsigned a0 = pk[kbk][2 * (2 * tt)], a1 = pk[kbk][2 * (2 * tt) + 1];          // group g = 2 tt
+                unsigned b0 = pk[kbk][2 * (2 * tt + 1)], b1 = pk[kbk][2 * (2 * tt + 1) + 1];  // group g = 2 tt + 1
+                asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(a0), "+v"(b0));             // a[32:63] <-> b[0:31]
+                asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(a1), "+v"(b1));
+                pf[2 * kbk + tt] = make_uint4(a0, a1, b0, b1);
+            }
+        // ---- O^T += V^T.P^T ----
+#pragma unroll
+        for (int i = 0; i < NDB; i++) {
+            const unsigned char* const rowp = vb + (i * 32 + l32) * VP + hi * 16;
+#pragma unroll
+            for (int st = 0; st < 2 * FA_NKB; st++) {
+                const uint4 vf = *(const uint4*)(rowp + st * 32);
+                o[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf), __builtin_bit_cast(bf16x8, pf[st]), o[i], 0, 0, 0);
+            }
+        }
+        if (t + 1 < ntiles) store_tile((t + 1) & 1);            // the other buffer: last read in tile t-1, behind the barrier below
+        __syncthreads();
+    }
+    // ---- out[q][h D + d] = O[d][q] / l ----
+    const float inv = 1.0f / (l_run + __shfl_xor(l_run, 32, 64));
+    if (q < len) {
+        unsigned short* const op = (unsigned short*)a.out + (long)b * a.o_bs + (long)q * a.ldo + (long)h * D;
+#pragma unroll
+        for (int i = 0; i < NDB; i++)
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const int d = i * 32 + 8 * g + 4 * hi;
+                if (d < D) {                                    // D % 4 == 0
+                    uint2 w;
+                    w.x = pack_bf16x2(o[i][4 * g] * inv, o[i][4 * g + 1] * inv);
+                    w.y = pack_bf16x2(o[i][4 * g + 2] * inv, o[i][4 * g + 3] * inv);
+                    *(uint2*)(op + d) = w;
+                }
+            }
+    }
+}
+
+// returns true when the shape is covered (head depth 264, bf16, 16-byte aligned rows)
+bool launch_flash_attention(const FlashArgs& a, hipStream_t stream, bool dry_run) {
+    if (a.D != 264 || a.L <= 0 || a.ldq % 8 || a.ldv % 8 || a.ldo % 4 || a.k_off % 8) return false;
+    if (dry_run) return true;
+    constexpr int D = 264, KS = (D + 15) / 16, DP = KS * 16, DO = (D + 31) / 32 * 32;
+    const size_t lds = 2 * ((size_t)FA_BK * (DP * 2 + 16) + (size_t)DO * (FA_BK * 2 + 16));
+    auto kfn = flash_attn_kernel<264>;
+    static bool attr_done = false;
+    if (!attr_done) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_done = true; }
+    const dim3 grid((a.L + FA_BQ - 1) / FA_BQ, a.nbatch * a.nheads), block(256);
+    if (g_fa_ev_start) hipExtLaunchKernelGGL(kfn, grid, block, lds, stream, g_fa_ev_start, g_fa_ev_stop, 0, a);
+    else hipLaunchKernelGGL(kfn, grid, block, lds, stream, a);
+    return true;
+}
+
+}  // namespace zvx

@@ -85,6 +85,7 @@ struct zvx_ctx {
     int profile_only = -1;                 // >= 0: per-launch events only for this kernel variant (keeps the timed region lean)
     int rs_prof = 0;                       // zvx_set_int("rs_prof", 1): per-wave cycle counters of the streaming kernels (library built with -DRS_PROFILE)
     int enc_split = 0;                     // bf16 mode: the f32 GEMMs of the phoneme encoder / variance adaptor run as 3-plane bf16 GEMMs
+    int use_flash = 1;                     // zvx_set_int("flash", 0): the decoder's attention as score GEMM + softmax + PV GEMM (A/B)
     int voc_chunk = 0;                     // utterances per vocoder ResBlock sub-batch (0 = whole batch)
     int use_resstream = 1;                 // zvx_set_int("resstream", 0): ResBlocks of the narrow stages as per-pair launches (A/B, bit-equal)
     int shape_log = 0;                     // zvx_set_int("shape_log", 1): one stderr line per timed launch (profile 2)
@@ -427,6 +428,16 @@ void fft_block(zvx_ctx* c, void* x, int dt, int B, int Lmax, const int* len_dev,
         // only ever receive finite values); P is exactly zero there, so they never contribute
         c->gemm(a);
     }
+    FlashArgs fa;
+    memset(&fa, 0, sizeof fa);
+    fa.qk = qk; fa.qk_bs = (long)Lmax * 2 * H; fa.ldq = 2 * H; fa.k_off = H; fa.vt = vt; fa.vt_bs = (long)H * Lp; fa.ldv = Lp;
+    fa.out = o; fa.o_bs = (long)Lmax * H; fa.ldo = H; fa.len = len_dev; fa.L = Lmax; fa.D = d; fa.nheads = nheads; fa.nbatch = B;
+    fa.scale = (float)(1.0 / pow((double)d, 0.5));
+    const bool flash = dt == DT_BF16 && c->use_flash && launch_flash_attention(fa, c->stream, true);
+    if (flash) {
+        // softmax(Q K^T / sqrt(d)) V in one launch, scores and probabilities stay on chip            fs2.py:47-58
+        c->timed(4.0 * B * nheads * (double)Lmax * Lmax * d, (double)B * Lmax * (3.0 * H + H) * es, [&] { launch_flash_attention(fa, c->stream, false); });
+    } else {
     {   // scores = Q K^T / sqrt(d)                                    fs2.py:49-50
         GemmArgs a = gemm_base(dt);
         a.X = qk; a.x_bs = (long)Lmax * 2 * H; a.x_hs = d; a.ldx = 2 * H;
@@ -446,6 +457,7 @@ void fft_block(zvx_ctx* c, void* x, int dt, int B, int Lmax, const int* len_dev,
         a.out = o; a.o_bs = (long)Lmax * H; a.o_hs = d; a.ldo = H;
         a.flops = 2.0 * B * nheads * (double)Lmax * Lmax * d;
         c->gemm(a);
+    }
     }
     {   // y = fc(O) + residual                                         fs2.py:158-162
         GemmArgs a = gemm_base(dt);
@@ -1279,6 +1291,7 @@ zvx_status zvx_set_int(zvx_ctx* c, const char* key, int64_t value) {
         else if (std::string(key) == "shape_log") c->shape_log = (int)value;
         else if (std::string(key) == "resstream") c->use_resstream = (int)value;
         else if (std::string(key) == "voc_chunk") c->voc_chunk = (int)value;
+        else if (std::string(key) == "flash") c->use_flash = (int)value;
         else if (std::string(key) == "enc_split") c->enc_split = (c->dt == DT_BF16 && value && c->has("enc.0.wqk.s3")) ? 1 : 0;
         else if (std::string(key) == "rs_prof") c->rs_prof = (int)value;
         else if (std::string(key) == "max_frames") { if (value < 1 || value > (1 << 24)) fail(ZVX_E_INVALID, "max_frames out of range"); c->max_frames = (int)value; }

@@ -102,6 +102,21 @@ int launch_resstream(StreamArgs a, hipStream_t stream, bool dry_run);
 void resstream_profile_events(hipEvent_t start, hipEvent_t stop);     // like gemm_profile_events, for the next launch_resstream
 
 // ------------------------------------------------------------------------------------------------
+// Fused attention of the FS2 / SCLN decoder (attention.hip): out = softmax(Q K^T * scale, keys < len) V per (utterance, head),
+// bf16 operands, no [L][L] tensor in HBM.  Q and K live in one projection buffer (K at element offset k_off of a row), V
+// arrives TRANSPOSED ([head*D + j][key], key-contiguous) from its projection GEMM.
+// ------------------------------------------------------------------------------------------------
+struct FlashArgs {
+    const void* qk; long qk_bs; int ldq; int k_off;     // [b][L][ldq] bf16: Q at column h*D, K at column k_off + h*D
+    const void* vt; long vt_bs; int ldv;                 // [b][nheads*D][ldv] bf16 (ldv >= L rounded up to 8)
+    void* out; long o_bs; int ldo;                       // [b][L][ldo] bf16, head h at column h*D
+    const int* len; int L, D, nheads, nbatch;
+    float scale;                                         // 1 / sqrt(D)   (fs2.py:49-50)
+};
+bool launch_flash_attention(const FlashArgs& a, hipStream_t stream, bool dry_run);
+void flash_profile_events(hipEvent_t start, hipEvent_t stop);
+
+// ------------------------------------------------------------------------------------------------
 // Small kernels (ops.hip).  T-typed pointers are void* + dtype.
 // ------------------------------------------------------------------------------------------------
 void launch_f32_to_bf16(const float* in, bf16_t* out, size_t n, hipStream_t s);
