@@ -6,6 +6,7 @@ import json, re, sqlite3, sys
 
 NAMES = {  # rocprof kernel name pattern -> bench variant name
     r"convslab_kernel<256, 128,": "convslab_bf16_256x128", r"convslab_kernel<128, 256,": "convslab_bf16_128x256",
+    r"convslab_kernel<128, 128,": "convslab_bf16_128x128", r"flash_attn_kernel<": "flash_attn_bf16",
     r"convslab_kernel<256, 64,": "convslab_bf16_256x64", r"convslab_kernel<256, 32,": "convslab_bf16_256x32",
     r"resfuse_kernel<64,": "resfuse_bf16_c64", r"resfuse_kernel<32,": "resfuse_bf16_c32",
     r"resfuse_persist_kernel<64,": "resfuse_bf16_c64", r"resfuse_persist_kernel<32,": "resfuse_bf16_c32",
