@@ -39,3 +39,27 @@ def test_convert_roundtrip(tmp_path):
     assert cc.convert_vocoder(str(gk), str(cj), str(tmp_path / "voc")) == len(hsd)
     h2, hsd2 = load_meldec_weights(str(tmp_path / "voc"))
     assert h2 == h and all(np.array_equal(hsd2[k], hsd[k]) for k in hsd)
+
+
+def test_reference_model_directories_load_without_conversion(tmp_path):
+    """synthesize.py:295-326 / model.py:90-111: a model directory as the reference downloads it (modelcfg.yaml +
+    checkpoints/*.ckpt, the newest wins; config.json + generator.ckpt) is read directly."""
+    import time
+    cfg = zcfg.medium_modelcfg("fastspeech2")
+    h = zcfg.hifigan_config("tiny2")
+    sd, hsd = zw.tts_state_dict(cfg, 1), zw.hifigan_state_dict(h, 1)
+    mdir = tmp_path / "tts_en"
+    (mdir / "checkpoints").mkdir(parents=True)
+    yaml.safe_dump(cfg, open(mdir / "modelcfg.yaml", "w"))
+    old = {k: torch.zeros_like(torch.from_numpy(np.array(v))) for k, v in sd.items()}
+    torch.save({"state_dict": old}, mdir / "checkpoints" / "epoch=1.ckpt")
+    time.sleep(0.05)
+    torch.save({"state_dict": {k: torch.from_numpy(np.array(v)) for k, v in sd.items()}}, mdir / "checkpoints" / "epoch=2.ckpt")
+    cfg2, sd2 = load_tts_weights(str(mdir))
+    assert cfg2["model"]["decoder"]["kind"] == "fastspeech2" and all(np.array_equal(sd2[k], sd[k]) for k in sd)
+    vdir = tmp_path / "hifigan"
+    vdir.mkdir()
+    json.dump(h, open(vdir / "config.json", "w"))
+    torch.save({"generator": {k: torch.from_numpy(np.array(v)) for k, v in hsd.items()}}, vdir / "generator.ckpt")
+    h2, hsd2 = load_meldec_weights(str(vdir), tts_modelpath=str(mdir))
+    assert h2 == h and all(np.array_equal(hsd2[k], hsd[k]) for k in hsd)

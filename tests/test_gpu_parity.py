@@ -730,3 +730,23 @@ def test_fused_attention_of_the_fs2_decoder():
         check_mel(unfused[b, :L[b]], ref, "bf16", f"unfused attention utt {b}")
         assert np.abs(fused[b, :L[b]] - unfused[b, :L[b]]).max() < 0.08
         assert not fused[b, L[b]:].any()
+
+
+def test_speaker_encoder_sap_pooling():
+    """encoder_type 'SAP' (ResNetSE34V2.py:135-143, 199-200: attention-weighted mean only, fc over 2560 inputs)."""
+    import copy
+    cfg = copy.deepcopy(zcfg.medium_modelcfg("styletts"))
+    cfg["model"]["resnet"]["encoder_type"] = "SAP"
+    sd = zw.tts_state_dict(cfg, 0)
+    h, hsd = voc_sd("tiny")
+    man, blob = pack.pack_model(cfg, sd, h, hsd, "f32")
+    ctx = _lib.Context(man, blob, 0)
+    try:
+        r = np.random.default_rng(13)
+        lens = np.array([40, 23], np.int32)
+        mels = r.standard_normal((2, 40, 80)).astype(np.float32)
+        e = ctx.spkemb(mels, lens)
+        for b in range(2):
+            check_f32(e[b], O.resnet_se34v2(mels[b, :lens[b]], sd, cfg), f"SAP embed[{b}]", 5e-5)
+    finally:
+        ctx.close()

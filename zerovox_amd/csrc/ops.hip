@@ -633,7 +633,7 @@ void launch_se_apply(const void* x, const void* res, void* y, int dt, const floa
 }
 
 // attentive statistics pooling: softmax over time per feature column, weighted mean / std
-__global__ void k_asp_pool(const void* x, int xdt, const float* logits, int F, int Wmax, const int* W, int C, float* out) {
+__global__ void k_asp_pool(const void* x, int xdt, const float* logits, int F, int Wmax, const int* W, int C, float* out, int with_std) {
     const int b = blockIdx.y, j = blockIdx.x * blockDim.x + threadIdx.x;
     const int D = F * C;
     if (j >= D) return;
@@ -648,12 +648,12 @@ __global__ void k_asp_pool(const void* x, int xdt, const float* logits, int F, i
     }
     const float mu = sx / s;
     const float sg = sqrtf(fmaxf(sxx / s - mu * mu, 1e-5f));      // ResNetSE34V2.py:204 clamp(min=1e-5)
-    out[(long)b * 2 * D + j] = mu;
-    out[(long)b * 2 * D + D + j] = sg;
+    if (with_std) { out[(long)b * 2 * D + j] = mu; out[(long)b * 2 * D + D + j] = sg; }      // ASP: [mu | sg]
+    else out[(long)b * D + j] = mu;                                                              // SAP: the weighted mean only
 }
 void launch_asp_pool(const void* x, int x_dt, const float* logits, int B, int F, int Wmax, const int* W, int C,
-                     float* out, hipStream_t s) {
-    hipLaunchKernelGGL(k_asp_pool, dim3((F * C + 255) / 256, B), dim3(256), 0, s, x, x_dt, logits, F, Wmax, W, C, out);
+                     float* out, int with_std, hipStream_t s) {
+    hipLaunchKernelGGL(k_asp_pool, dim3((F * C + 255) / 256, B), dim3(256), 0, s, x, x_dt, logits, F, Wmax, W, C, out, with_std);
 }
 
 __global__ void k_l2norm_rows(float* x, int C) {

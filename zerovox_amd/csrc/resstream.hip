@@ -382,14 +382,15 @@ static bool launch_rs(StreamArgs& a, hipStream_t stream, bool dry_run) {
     // segments: about one per CU, never shorter than 2048 rows (pipeline fill and halo are paid per segment)
     long total = 0; (void)total;
     const long rows_all = (long)a.M * a.nbatch;
-    int S = (int)((rows_all + ncu() - 1) / ncu());
+    const int nwg = ncu();                                                          // one persistent workgroup per CU
+    int S = (int)((rows_all + nwg - 1) / nwg);
     if (S < 2048) S = 2048;
     S = (S + R - 1) / R * R;
     a.S = S; a.nseg = (a.M + S - 1) / S;
     const int nsegs = a.nseg * a.nbatch;
     a.flops = 2.0 * 2.0 * NPAIR * (double)rows_all * C * C * NT;
     if (dry_run) return true;
-    const dim3 grid(nsegs < ncu() ? nsegs : ncu()), block(64 * NR * WPR);
+    const dim3 grid(nsegs < nwg ? nsegs : nwg), block(64 * NR * WPR);
     const int am = a.accum ? a.accum_mode : 0;
 #define RS_GO(AM_, HO_) do { auto kfn = resstream_kernel<C, NT, NPAIR, RSPLIT, AM_, HO_>; \
         static bool attr_done = false; \

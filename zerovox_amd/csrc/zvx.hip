@@ -1095,12 +1095,13 @@ void run_spkemb(zvx_ctx* c, const float* ref_mels, const int32_t* lens, int B, i
         a.out = logits; a.out_dtype = DT_F32; a.o_bs = (long)Wp * D; a.ldo = D;
         c->gemm(a);
     }
-    if (!c->rn_asp) fail(ZVX_E_UNSUPPORTED, "SAP pooling is not built (the shipped configs use ASP)");
-    float* pooled = c->fbuf("spk.pooled", (size_t)B * 2 * D);
-    launch_asp_pool(x, dt, logits, B, Fp, Wp, w3_d, C4, pooled, c->stream);
+    const int PD = c->rn_asp ? 2 * D : D;                 // ASP: [mu | sg], SAP: mu     ResNetSE34V2.py:135-143, 199-205
+    if (c->t("spk.fc_w").dim(2) != PD) fail(ZVX_E_MANIFEST, "spk.fc_w has %d inputs, the %s pooling produces %d", c->t("spk.fc_w").dim(2), c->rn_asp ? "ASP" : "SAP", PD);
+    float* pooled = c->fbuf("spk.pooled", (size_t)B * PD);
+    launch_asp_pool(x, dt, logits, B, Fp, Wp, w3_d, C4, pooled, c->rn_asp, c->stream);
     float* emb = c->fbuf("spk.emb", (size_t)B * H);
-    // Linear(2*D -> hidden): a few rows against a 5120-long K -- one wave per output column      ResNetSE34V2.py:207
-    launch_fc_rows(pooled, 2 * D, (const float*)c->t("spk.fc_w").dev, 2 * D, c->pf("spk.fc_b"), emb, H, B, H, 2 * D, c->stream);
+    // Linear(PD -> hidden): a few rows against a 5120-long K -- one wave per output column      ResNetSE34V2.py:207
+    launch_fc_rows(pooled, PD, (const float*)c->t("spk.fc_w").dev, PD, c->pf("spk.fc_b"), emb, H, B, H, PD, c->stream);
     launch_l2norm_rows(emb, B, H, c->stream);                                  // F.normalize   :209-210
     c->stage_end(ZVX_T_SPKEMB);
     HIPCHK(hipMemcpyAsync(out, emb, (size_t)B * H * 4, (flags & ZVX_DEVICE_OUT) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, c->stream));

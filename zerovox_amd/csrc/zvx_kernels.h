@@ -204,8 +204,9 @@ void launch_se_apply(const void* x, const void* res, void* y, int dt, const floa
                      const int* W, int C, hipStream_t s);
 // ASP pooling (ResNetSE34V2.py:197-205): x map [b][F][Wmax][C] viewed as [t][f*C+c]; logits [b][Wmax][F*C] f32
 // out [b][2*F*C] = [mu | sg] in (f*C+c) order
+// with_std = 0: self-attentive pooling (SAP, ResNetSE34V2.py:199-200): out [b][F*C] = mu only
 void launch_asp_pool(const void* x, int x_dt, const float* logits, int B, int F, int Wmax, const int* W, int C,
-                     float* out, hipStream_t s);
+                     float* out, int with_std, hipStream_t s);
 void launch_l2norm_rows(float* x, int B, int C, hipStream_t s);
 
 // ---- log-mel front end (mels.py:357-395) ----

@@ -30,8 +30,9 @@ def parse_device(infer_device) -> int:
 
 
 def load_tts_weights(modelpath):
-    """-> (modelcfg, state_dict).  ``synthetic:<styletts|fastspeech2>[:seed]`` or a directory holding
-    ``modelcfg.yaml`` (synthesize.py:295-311) + ``weights.npz`` (tools/convert_checkpoint.py output)."""
+    """-> (modelcfg, state_dict).  ``synthetic:<styletts|fastspeech2>[:seed]``, or a directory holding ``modelcfg.yaml``
+    (synthesize.py:310-326) and either ``weights.npz`` (tools/convert_checkpoint.py output, torch-free) or the reference's
+    own ``checkpoints/*.ckpt`` / ``checkpoint.pkl`` (synthesize.py:295-304; read with torch through zerovox_amd.convert)."""
     spec = str(modelpath)
     if spec.startswith("synthetic:"):
         parts = spec.split(":")
@@ -39,13 +40,16 @@ def load_tts_weights(modelpath):
         return cfg, zw.tts_state_dict(cfg, int(parts[2]) if len(parts) > 2 else 0)
     with open(os.path.join(spec, "modelcfg.yaml")) as f:
         cfg = yaml.load(f, Loader=yaml.FullLoader)
-    sd = dict(np.load(os.path.join(spec, "weights.npz")))
+    if os.path.exists(os.path.join(spec, "weights.npz")):
+        return cfg, dict(np.load(os.path.join(spec, "weights.npz")))
+    from .convert import read_tts_checkpoint          # a reference model directory as downloaded: needs torch to unpickle
+    sd, _ = read_tts_checkpoint(spec)
     return cfg, sd
 
 
 def load_meldec_weights(modelspec, tts_modelpath=None):
     """-> (hifigan_cfg, state_dict).  ``synthetic:<v1|v2|v3|tiny|tiny2>[:seed]`` or a directory with
-    ``config.json`` (model.py:90-105) + ``generator.npz``.
+    ``config.json`` (model.py:90-105) + ``generator.npz`` (converted) or the reference's ``generator.ckpt``.
 
     A vocoder BAKED INTO the TTS checkpoint (``_meldec.*`` keys, utils/edit_meldec_in_checkpoint.py:77-90; split off
     by tools/convert_checkpoint.py into ``<tts_modelpath>/generator.npz``) overrides the external weights, exactly as
@@ -60,10 +64,22 @@ def load_meldec_weights(modelspec, tts_modelpath=None):
     else:
         with open(os.path.join(spec, "config.json")) as f:
             h = json.load(f)
-        hsd = dict(np.load(os.path.join(spec, "generator.npz")))
-    baked = None if tts_modelpath is None or str(tts_modelpath).startswith("synthetic:") else os.path.join(str(tts_modelpath), "generator.npz")
-    if baked and os.path.exists(baked):
-        bsd = dict(np.load(baked))
+        if os.path.exists(os.path.join(spec, "generator.npz")):
+            hsd = dict(np.load(os.path.join(spec, "generator.npz")))
+        else:                                           # the reference's own layout: generator.ckpt next to config.json (model.py:90-111)
+            from .convert import read_generator_checkpoint
+            hsd = read_generator_checkpoint(os.path.join(spec, "generator.ckpt"))
+    bsd = None
+    if tts_modelpath is not None and not str(tts_modelpath).startswith("synthetic:"):
+        baked = os.path.join(str(tts_modelpath), "generator.npz")
+        if os.path.exists(baked):
+            bsd = dict(np.load(baked))
+        elif not os.path.exists(os.path.join(str(tts_modelpath), "weights.npz")):
+            from .convert import find_tts_checkpoint, read_tts_checkpoint
+            if find_tts_checkpoint(str(tts_modelpath)):
+                bsd = read_tts_checkpoint(str(tts_modelpath))[1] or None
+                baked = find_tts_checkpoint(str(tts_modelpath))
+    if bsd:
         bad = sorted(k for k in set(bsd) | set(hsd) if k not in bsd or k not in hsd or bsd[k].shape != hsd[k].shape)
         if bad:
             raise ValueError(f"{baked}: baked-in vocoder does not match {spec}/config.json (first mismatching keys: {bad[:4]})")
