@@ -99,8 +99,10 @@ class StubContext:
         assert world == 1 or cid == bytes(range(128)), "every rank must receive rank 0's id"
         self.rank, self.world = rank, world
         if world > 1:
+            # under torchrun the elastic agent hosts the store (env://); spawned by hand, rank 0 hosts one next to bench.py's
+            agent = os.environ.get("TORCHELASTIC_USE_AGENT_STORE", "") == "True"
             dist.init_process_group("gloo", rank=rank, world_size=world,
-                                    init_method=f"tcp://127.0.0.1:{int(os.environ['MASTER_PORT']) + 1}")
+                                    init_method="env://" if agent else f"tcp://127.0.0.1:{int(os.environ['MASTER_PORT']) + 1}")
 
     def comm_gather(self, local_ptr, nbytes, recv_ptr, root=0, no_sync=False):
         local = torch.from_numpy(self._bufs[local_ptr][:nbytes])
@@ -176,3 +178,19 @@ def test_bench_control_flow_world2_with_stub_context():
     total = 2 * 4 * r["config"]["samples_per_utt"] * 3
     assert abs(r["value"] * r["ms_per_step"] * 1e-3 * 3 - total) < 1e-6 * total
     assert r["higher_is_better"] is True and r["vs_baseline"] is None
+
+
+def test_bench_under_torchrun_with_stub_context():
+    """The driver's own launch line (python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N ...): env parsing, the TCPStore rendezvous against the elastic agent's store, one JSON line."""
+    import subprocess
+    port = 29700 + (os.getpid() % 200)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "tests", "_bench_stub_main.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--batch", "3", "--phonemes", "8", "--profile", "0", "--no-cpu-baseline"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["steps"] == 2 and r["config"]["global_batch"] == 6 and r["output_ok"] is True
