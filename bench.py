@@ -14,8 +14,8 @@
 --config 5 (configs[4]): ResNetSE34V2 speaker encoder on 1000 device-resident 3 s mels; a step = one batch of 50 clips.
 
 Timing: W untimed steps, then exactly K steps bracketed by a barrier + full device drain on both sides; MAX over ranks.
-Rank 0 prints ONE JSON line.  No GPU runtime other than libzvx is loaded (no torch on the hot path; for N > 1 the 128-byte
-RCCL id travels through torch.distributed's TCPStore, nothing else).
+Rank 0 prints ONE JSON line.  No GPU runtime other than libzvx (and, for N > 1, the system librccl it dlopens) is loaded and
+torch is never imported; for N > 1 the 128-byte RCCL id travels over a plain TCP socket from rank 0.
 """
 import argparse
 import hashlib
@@ -46,22 +46,44 @@ def src_sha16():
 
 
 def exchange_comm_id(rank, world, make_id):
-    """rank 0's RCCL id -> every rank, through the TCPStore at MASTER_ADDR:MASTER_PORT (under torchrun that store is hosted
-    by the elastic agent; stand-alone, rank 0 hosts it).  Rendezvous plumbing only."""
-    from torch.distributed import TCPStore
-    addr, port = os.environ.get("MASTER_ADDR", "127.0.0.1"), int(os.environ.get("MASTER_PORT", "29500"))
-    agent = os.environ.get("TORCHELASTIC_USE_AGENT_STORE", "") == "True"
-    store = TCPStore(addr, port, world, is_master=(rank == 0 and not agent), wait_for_workers=False)
-    key = "zvx_comm_id/" + os.environ.get("TORCHELASTIC_RESTART_COUNT", "0")
+    """rank 0's 128-byte RCCL id -> every rank over a plain TCP socket on MASTER_ADDR : (ZVX_RDZV_PORT or MASTER_PORT + 37).
+    Deliberately NOT torch.distributed: importing torch after libzvx.so loads torch's bundled copies of librccl / libhsa-runtime
+    next to the system HIP runtime libzvx is linked against, and RCCL then initialises against an HSA instance the process never
+    opened (`pfn_hsa_system_get_info failed`, "no ROCm-capable device").  The bench process loads no GPU runtime but libzvx's."""
+    import socket
+    addr = os.environ.get("MASTER_ADDR", "127.0.0.1")
+    port = int(os.environ.get("ZVX_RDZV_PORT", int(os.environ.get("MASTER_PORT", "29500")) + 37))
     if rank == 0:
-        store.set(key, make_id())
-    cid = bytes(store.get(key))
-    store.add(key + "/got", 1)
-    if rank == 0:                                  # keep a self-hosted store alive until everyone has read the id
-        t0 = time.time()
-        while int(store.add(key + "/got", 0)) < world and time.time() - t0 < 120:
-            time.sleep(0.01)
-    return cid, store
+        cid = bytes(make_id())
+        srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+        srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+        srv.bind(("" if addr not in ("127.0.0.1", "localhost") else "127.0.0.1", port))
+        srv.listen(world)
+        srv.settimeout(600)
+        served = 0
+        while served < world - 1:
+            conn, _ = srv.accept()
+            with conn:
+                conn.sendall(cid)
+            served += 1
+        srv.close()
+        return cid
+    t0, last = time.time(), None
+    while time.time() - t0 < 600:                  # rank 0 may still be packing weights: retry until it listens
+        try:
+            with socket.create_connection((addr, port), timeout=30) as c:
+                buf = b""
+                while len(buf) < 128:
+                    chunk = c.recv(128 - len(buf))
+                    if not chunk:
+                        break
+                    buf += chunk
+                if len(buf) == 128:
+                    return buf
+        except OSError as e:
+            last = e
+        time.sleep(0.2)
+    raise SystemExit(f"rank {rank}: no RCCL id from rank 0 at {addr}:{port} ({last})")
 
 
 def default_ctx_factory(args, local_rank):
@@ -131,10 +153,8 @@ def main(argv=None, ctx_factory=default_ctx_factory):
     ctx, model = ctx_factory(args, local_rank)       # raises when libzvx.so / a GPU is missing: there is no CPU fallback
     cfg = model[0]
     hop, sr = cfg["audio"]["hop_size"], cfg["audio"]["sampling_rate"]
-    store = None
     if world > 1:
-        cid, store = exchange_comm_id(rank, world, ctx.comm_unique_id)
-        ctx.comm_init(cid, rank, world)
+        ctx.comm_init(exchange_comm_id(rank, world, ctx.comm_unique_id), rank, world)
     else:
         ctx.comm_init(None, 0, 1)
 

@@ -126,7 +126,9 @@ zvx_status zvx_fetch(zvx_ctx* ctx, const char* what, float* out, size_t out_floa
 /* ---- multi-GPU: utterances shard across ranks with no data-path exchange; the ONE collective is the gather of the
  * finished waveform rows to one rank, issued here directly on RCCL (grouped ncclSend / ncclRecv: every peer -> root
  * transfer rides its own xGMI link).  The reference has no distributed layer; one process per GPU,
- * one context per process.  librccl.so is dlopen'ed by zvx_comm_unique_id / zvx_comm_init only. ---- */
+ * one context per process.  librccl.so.1 is dlopen'ed by zvx_comm_unique_id / zvx_comm_init only; it must belong to the
+ * same ROCm runtime as the HIP library already in the process (do not import a framework that bundles its own ROCm AFTER
+ * this library has been loaded). ---- */
 #define ZVX_COMM_ID_BYTES 128
 /* rank 0 creates the communicator id (ncclGetUniqueId) and ships the 128 bytes to the other ranks out of band */
 zvx_status zvx_comm_unique_id(void* id_out);

@@ -750,3 +750,13 @@ def test_speaker_encoder_sap_pooling():
             check_f32(e[b], O.resnet_se34v2(mels[b, :lens[b]], sd, cfg), f"SAP embed[{b}]", 5e-5)
     finally:
         ctx.close()
+
+
+def test_rccl_gather_path_in_a_torch_free_process():
+    """bench.py's configuration: no torch in the process, the SYSTEM librccl + HIP runtime (the pytest process itself runs on
+    torch's bundled ROCm copies).  tools/rccl_selftest.py: one-rank communicator, send/recv to self, barrier, result check."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "tools", "rccl_selftest.py")], capture_output=True, text=True, timeout=600, cwd=root)
+    assert p.returncode == 0 and "torch-free RCCL self-test: OK" in p.stdout, (p.stdout[-500:], p.stderr[-1500:])
