@@ -52,38 +52,50 @@ def exchange_comm_id(rank, world, make_id):
     opened (`pfn_hsa_system_get_info failed`, "no ROCm-capable device").  The bench process loads no GPU runtime but libzvx's."""
     import socket
     addr = os.environ.get("MASTER_ADDR", "127.0.0.1")
-    port = int(os.environ.get("ZVX_RDZV_PORT", int(os.environ.get("MASTER_PORT", "29500")) + 37))
+    base = int(os.environ.get("ZVX_RDZV_PORT", int(os.environ.get("MASTER_PORT", "29500")) + 37))
+    ports = [base + 100 * i for i in range(4)]       # rank 0 binds the first free one; the others probe them in turn
+    magic = b"ZVXID1"
     if rank == 0:
         cid = bytes(make_id())
-        srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
-        srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
-        srv.bind(("" if addr not in ("127.0.0.1", "localhost") else "127.0.0.1", port))
+        srv = None
+        for port in ports:
+            try:
+                srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+                srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+                srv.bind(("127.0.0.1" if addr in ("127.0.0.1", "localhost") else "", port))
+                break
+            except OSError:
+                srv.close(); srv = None
+        if srv is None:
+            raise SystemExit(f"rank 0: none of the rendezvous ports {ports} is free")
         srv.listen(world)
         srv.settimeout(600)
         served = 0
         while served < world - 1:
             conn, _ = srv.accept()
             with conn:
-                conn.sendall(cid)
+                conn.sendall(magic + cid)
             served += 1
         srv.close()
         return cid
-    t0, last = time.time(), None
+    t0, last, need = time.time(), None, len(magic) + 128
     while time.time() - t0 < 600:                  # rank 0 may still be packing weights: retry until it listens
-        try:
-            with socket.create_connection((addr, port), timeout=30) as c:
-                buf = b""
-                while len(buf) < 128:
-                    chunk = c.recv(128 - len(buf))
-                    if not chunk:
-                        break
-                    buf += chunk
-                if len(buf) == 128:
-                    return buf
-        except OSError as e:
-            last = e
+        for port in ports:
+            try:
+                with socket.create_connection((addr, port), timeout=30) as c:
+                    c.settimeout(30)
+                    buf = b""
+                    while len(buf) < need:
+                        chunk = c.recv(need - len(buf))
+                        if not chunk:
+                            break
+                        buf += chunk
+                    if len(buf) == need and buf.startswith(magic):
+                        return buf[len(magic):]
+            except OSError as e:
+                last = e
         time.sleep(0.2)
-    raise SystemExit(f"rank {rank}: no RCCL id from rank 0 at {addr}:{port} ({last})")
+    raise SystemExit(f"rank {rank}: no RCCL id from rank 0 at {addr}:{ports} ({last})")
 
 
 def default_ctx_factory(args, local_rank):
