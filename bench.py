@@ -98,6 +98,11 @@ def exchange_comm_id(rank, world, make_id):
     raise SystemExit(f"rank {rank}: no RCCL id from rank 0 at {addr}:{ports} ({last})")
 
 
+def flush_c_stdio():
+    import ctypes
+    ctypes.CDLL(None).fflush(None)
+
+
 def default_ctx_factory(args, local_rank):
     from zerovox_amd import _lib, config as zcfg, pack, weights as zw
     cfg = zcfg.medium_modelcfg(args.decoder)
@@ -167,6 +172,7 @@ def main(argv=None, ctx_factory=default_ctx_factory):
     hop, sr = cfg["audio"]["hop_size"], cfg["audio"]["sampling_rate"]
     if world > 1:
         ctx.comm_init(exchange_comm_id(rank, world, ctx.comm_unique_id), rank, world)
+        flush_c_stdio()                              # RCCL's version banner (C stdio, block-buffered on a pipe) goes out now, not after the JSON line
     else:
         ctx.comm_init(None, 0, 1)
 
@@ -292,10 +298,12 @@ def main(argv=None, ctx_factory=default_ctx_factory):
             f32_dom = dom["name"].startswith("gemm_f32")
             peak = MFMA_PEAK["f32" if (args.precision == "f32" or f32_dom) else "bf16"]
             traffic = traffic_note = None
+            pmc = {}
             try:    # per-launch HBM bytes of this kernel from the rocprofv3 PMC passes of the SAME sources (tools/refresh_profiles.sh)
                 tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
                 if tj.get("src_sha16") == res["src_sha16"] and tj.get("config", 2) == args.config:
-                    traffic = tj.get(dom["name"], {}).get("hbm_bytes_per_launch")
+                    pmc = tj.get(dom["name"], {})
+                    traffic = pmc.get("hbm_bytes_per_launch")
                 else:
                     traffic_note = "profiles/traffic.json was collected on different sources/config: not quoted"
             except Exception:
@@ -308,6 +316,11 @@ def main(argv=None, ctx_factory=default_ctx_factory):
                                "alg_GBps": dom["bytes"] / (dom["ms"] * 1e-3) / 1e9}
             if traffic_note:
                 res["roofline"]["traffic_note"] = traffic_note
+            if pmc.get("eff_clock_GHz"):
+                # the same profile's GRBM_GUI_ACTIVE / kernel time and MFMA busy cycles: `peak` above is the 2.4 GHz figure, the
+                # chip sustains less under this load (power budget), and `mfma_busy_frac` is the share of THOSE cycles the pipe works
+                res["roofline"]["profiled_clock_GHz"] = round(pmc["eff_clock_GHz"], 3)
+                res["roofline"]["profiled_mfma_busy_frac"] = round(pmc.get("mfma_busy_frac", 0.0), 3)
             # per-variant and per-stage split of ONE (untimed, fully instrumented) step
             res["kernels_one_step"] = [{"name": k["name"], "launches": k["launches"], "ms": round(k["ms"], 3),
                                         "TFLOPs": round(k["flops"] / (k["ms"] * 1e-3) / 1e12, 2) if k["ms"] > 0 else None}
@@ -326,6 +339,7 @@ def main(argv=None, ctx_factory=default_ctx_factory):
             res["roofline_per_stage"] = per_stage
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(args.config, model, T, 896 if args.config == 2 else 0)
+        flush_c_stdio()
         print(json.dumps(res), flush=True)
     fence()
     ctx.close()

@@ -27,12 +27,33 @@ def per_kernel(db, counter):
     return out
 
 
+def clocks(db):
+    """Effective shader clock and MFMA-pipe duty per variant from the SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE pass:
+    GRBM_GUI_ACTIVE is summed over the 8 XCDs (clock = sum / 8 / kernel time), MFMA busy cycles over the 1024 SIMDs."""
+    cur = sqlite3.connect(db).cursor()
+    busy = per_kernel(db, "SQ_VALU_MFMA_BUSY_CYCLES")
+    gui = {}
+    for kn, sm, ns in cur.execute("select kernel_name, sum(value), sum(duration) from counters_collection where counter_name='GRBM_GUI_ACTIVE' group by kernel_name"):
+        for pat, name in NAMES.items():
+            if pat in kn:
+                a = gui.setdefault(name, [0.0, 0.0]); a[0] += sm; a[1] += ns
+    out = {}
+    for name, (g, ns) in gui.items():
+        if g and ns:
+            out[name] = {"eff_clock_GHz": g / 8.0 / ns, "mfma_busy_frac": busy.get(name, [0, 0.0])[1] / 1024.0 / (g / 8.0)}
+    return out
+
+
 fetch, write = per_kernel(sys.argv[1], "FETCH_SIZE"), per_kernel(sys.argv[2], "WRITE_SIZE")
 res = {}
 for name in fetch:
     n, f = fetch[name]; w = write.get(name, [n, 0.0])[1]
     res[name] = {"launches": n, "fetch_KiB_per_launch_raw": f / n, "write_KiB_per_launch": w / n,
                  "hbm_bytes_per_launch": (2 * f + w) * 1024 / n}
+if len(sys.argv) > 5:
+    for name, c in clocks(sys.argv[5]).items():
+        if name in res:
+            res[name].update(c)
 sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from bench import src_sha16
 json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on `python bench.py --steps 3 --warmup 1 --no-cpu-baseline`",

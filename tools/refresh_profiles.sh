@@ -24,9 +24,9 @@ for C in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pm_$C; timeout 600 rocprofv3 --pmc $C -d /tmp/pm_$C -o pm -- $CMD > /dev/null 2>&1
   python $ROOT/tools/rocpd_summary.py $(find /tmp/pm_$C -name "*.db" | head -1) --pmc > $OUT/pmc_${C}_bench_n1.txt
 done
-python $ROOT/tools/make_traffic_json.py $(find /tmp/pm_FETCH_SIZE -name "*.db" | head -1) $(find /tmp/pm_WRITE_SIZE -name "*.db" | head -1) $OUT/traffic.json 2 > /dev/null
 rm -rf /tmp/pm_m; timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES -d /tmp/pm_m -o pm -- $CMD > /dev/null 2>&1
 python $ROOT/tools/rocpd_summary.py $(find /tmp/pm_m -name "*.db" | head -1) --pmc > $OUT/pmc_mfma_bench_n1.txt
+python $ROOT/tools/make_traffic_json.py $(find /tmp/pm_FETCH_SIZE -name "*.db" | head -1) $(find /tmp/pm_WRITE_SIZE -name "*.db" | head -1) $OUT/traffic.json 2 $(find /tmp/pm_m -name "*.db" | head -1) > $OUT/traffic_json.log 2>&1
 # the bench line again, now WITH the matching traffic.json in place (bench.py quotes it only when src_sha16 agrees)
 cp $OUT/traffic.json $ROOT/profiles/traffic.json
 python $ROOT/bench.py > $OUT/bench_n1.json 2> $OUT/bench_n1.err

@@ -159,8 +159,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             for (int tt = 0; tt < 2; tt++) {
                 unsigned a0 = pk[kbk][2 * (2 * tt)], a1 = pk[kbk][2 * (2 * tt) + 1];          // group g = 2 tt
                 unsigned b0 = pk[kbk][2 * (2 * tt + 1)], b1 = pk[kbk][2 * (2 * tt + 1) + 1];  // group g = 2 tt + 1
-                asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(a0), "+v"(b0));             // a[32:63] <-> b[0:31]
-                asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(a1), "+v"(b1));
+                // inline asm gets none of hipcc's VALU wait states: the s_nops keep a VALU result from being consumed by the swap,
+                // and the swap's result from being consumed by a VALU op, in the next two slots (stale lanes otherwise)
+                asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\tv_permlane32_swap_b32 %2, %3\n\ts_nop 1"
+                             : "+v"(a0), "+v"(b0), "+v"(a1), "+v"(b1));                          // a[32:63] <-> b[0:31]
                 pf[2 * kbk + tt] = make_uint4(a0, a1, b0, b1);
             }
         // ---- O^T += V^T.P^T ----

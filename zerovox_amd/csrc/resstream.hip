@@ -363,8 +363,6 @@ template <int C, int NT, int NPAIR, int RSPLIT>
 static bool launch_rs(StreamArgs& a, hipStream_t stream, bool dry_run) {
     constexpr int NTL = C / 32, WPR = NTL * RSPLIT, R = 32 * RSPLIT, P = 2 * C + 16, H2 = (NT - 1) / 2, NR = 2 * NPAIR;
     // ring sizes (rows): see the header comment; X0 also covers the DMA lead and holds whole 64-row DMA blocks
-    int hsum = 0;
-    for (int p = 0; p < NPAIR; p++) hsum += (a.dil[p] + 1) * H2;
     const int h0 = a.dil[0] * H2;
     if (2 * h0 + R > 4 * RS_RD) return false;                                       // DMA lead assumed <= 4 blocks in flight
     for (int p = 0; p < NPAIR; p++) if (a.dil[p] * H2 + H2 > R) return false;       // the residual rows of a block lie within the producer's last two blocks

@@ -1438,6 +1438,7 @@ zvx_status zvx_fetch(zvx_ctx* c, const char* what, float* out, size_t out_floats
 zvx_status zvx_sync(zvx_ctx* c) { return guarded(c, [&] { c->sync(); }); }
 
 // ---- RCCL, resolved at run time ----------------------------------------------------------------------------------
+extern "C++" {
 namespace {
 struct Rccl {
     void* h = nullptr;
@@ -1464,6 +1465,7 @@ Rccl& rccl() {
 }
 #define NCCLCHK(x) do { ncclResult_t r_ = (x); if (r_ != ncclSuccess) fail(ZVX_E_HIP, "%s failed: %s (%s:%d)", #x, rccl().GetErrorString(r_), __FILE__, __LINE__); } while (0)
 }  // namespace
+}  // extern "C++"
 
 zvx_status zvx_comm_unique_id(void* id_out) {
     static_assert(sizeof(ncclUniqueId) == ZVX_COMM_ID_BYTES, "ncclUniqueId size");
