@@ -82,8 +82,8 @@ def exchange_comm_id(rank, world, make_id):
     while time.time() - t0 < 600:                  # rank 0 may still be packing weights: retry until it listens
         for port in ports:
             try:
-                with socket.create_connection((addr, port), timeout=30) as c:
-                    c.settimeout(30)
+                with socket.create_connection((addr, port), timeout=5) as c:
+                    c.settimeout(3)                 # rank 0 answers at once; anything slower is not rank 0
                     buf = b""
                     while len(buf) < need:
                         chunk = c.recv(need - len(buf))

@@ -194,3 +194,35 @@ def test_bench_under_torchrun_with_stub_context():
     assert len(lines) == 1, p.stdout
     r = json.loads(lines[0])
     assert r["n_gpus"] == 2 and r["steps"] == 2 and r["config"]["global_batch"] == 6 and r["output_ok"] is True
+
+
+def test_comm_id_rendezvous_world8_over_plain_sockets(monkeypatch):
+    """bench.py's RCCL-id exchange (no torch, no store): rank 0 serves the 128-byte id to 7 late / early clients, also when
+    the first rendezvous port is already taken by something else."""
+    import socket, threading, time
+    import bench
+    blocker = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+    blocker.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+    blocker.bind(("127.0.0.1", 0))
+    base = blocker.getsockname()[1]                       # the first candidate port is occupied (and never answers with an id)
+    blocker.listen(16)
+    monkeypatch.setenv("MASTER_ADDR", "127.0.0.1")
+    monkeypatch.setenv("ZVX_RDZV_PORT", str(base))
+    cid = bytes(range(128))
+    got = {}
+
+    def client(r, delay):
+        time.sleep(delay)
+        got[r] = bench.exchange_comm_id(r, 8, lambda: b"")
+    ths = [threading.Thread(target=client, args=(r, 0.05 * (r % 3))) for r in range(1, 8)]
+    for t in ths[:3]:
+        t.start()                                          # three clients are up before rank 0 listens
+    time.sleep(0.3)
+    srv = threading.Thread(target=lambda: got.__setitem__(0, bench.exchange_comm_id(0, 8, lambda: cid)))
+    srv.start()
+    for t in ths[3:]:
+        t.start()
+    for t in ths + [srv]:
+        t.join(60)
+    blocker.close()
+    assert sorted(got) == list(range(8)) and all(got[r] == cid for r in range(8))

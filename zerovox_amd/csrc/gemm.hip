@@ -1452,6 +1452,13 @@ static int launch_convslab(GemmArgs a, hipStream_t stream) {
         size_t lds = ((size_t)(128 + hl + hr) * SLAB_PITCH + 1023) & ~(size_t)1023;
         const size_t stage = (size_t)4 * 32 * (2 * 128 + 16);
         if (lds < stage) lds = stage;
+        // fewer than two 128 x 128 workgroups per CU: 64-row tiles double the count, and the second workgroup of a CU is what
+        // covers the first one's slab fills (these launches are latency-paced, not MFMA-paced)
+        if (narrow && a.M > 64 && ((a.N + 127) / 128) * a.nbatch < 2 * ncu) {
+            dim3 g64(((a.N + 127) / 128) * ((a.M + 63) / 64), a.nbatch);
+            launch_slab_variant<64, 128, 2, 2, 2, 0>(a, g64, lds, stream);
+            return 22;
+        }
         if (narrow) { launch_slab_variant<128, 128, 2, 2, 2, 0>(a, grid, lds, stream); return 22; }
         launch_slab_variant<128, 256, 1, 4, 2, 0>(a, grid, lds, stream);
         return 6;
