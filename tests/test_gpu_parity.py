@@ -197,6 +197,25 @@ def test_vocoder_v1_ragged_batch_equals_independent_oracle_calls(prec):
         check_wav(wav[b, :P[b] * 256], ref, prec, f"utt {b}", e2e=False)
 
 
+@pytest.mark.parametrize("prec", ["f32", "bf16"])
+def test_vocoder_v3_resblock2_ragged_batch_equals_independent_oracle_calls(prec):
+    """HiFi-GAN V3 (hifigan.py:65-99: ResBlock2 = single convolutions with a residual, k = 3 / 5 / 7, dilations up to 12,
+    256 -> 128 -> 64 -> 32 channels, three upsamplers 8 x 8 x 4) at its published width: each utterance of a ragged batch
+    against its own batch-1 oracle call."""
+    h, hsd = voc_sd("v3")
+    ctx = ctx_for("styletts", "v3", prec)
+    P = np.array([19, 7, 12], np.int32)
+    rng = np.random.default_rng(13)
+    mel = np.zeros((3, int(P.max()), 80), np.float32)
+    for b in range(3):
+        mel[b, :P[b]] = rng.standard_normal((P[b], 80)).astype(np.float32)
+    wav = ctx.vocode_mel(mel, P)
+    for b in range(3):
+        ref = O.hifigan_generator(mel[b, :P[b]].T, hsd, h)
+        check_wav(wav[b, :P[b] * 256], ref, prec, f"utt {b}", e2e=False)
+        assert not wav[b, P[b] * 256:].any()
+
+
 def test_vocoder_many_short_utterances():
     """130 utterances of 1-4 frames: more utterances than the fused kernel's LDS length table holds (scalar-load path),
     fewer tiles than CUs, row tiles entirely past an utterance's end."""
