@@ -20,6 +20,34 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def _parse_resources(text):
+    """hipcc -Rpass-analysis=kernel-resource-usage remarks -> {kernel: {vgprs, agprs, sgprs, scratch, vgpr_spill, sgpr_spill, occupancy}}."""
+    import re
+    res, cur = {}, None
+    keys = {"TotalSGPRs": "sgprs", "VGPRs": "vgprs", "AGPRs": "agprs", "ScratchSize [bytes/lane]": "scratch", "Occupancy [waves/SIMD]": "occupancy",
+            "SGPRs Spill": "sgpr_spill", "VGPRs Spill": "vgpr_spill", "LDS Size [bytes/block]": "lds"}
+    for line in text.splitlines():
+        m = re.search(r"remark:\s+Function Name: (\S+)", line)
+        if m:
+            cur = res.setdefault(m.group(1), {})
+            continue
+        m = re.search(r"remark:\s+([A-Za-z \[\]/]+): (\d+)", line)
+        if m and cur is not None and m.group(1).strip() in keys:
+            cur[keys[m.group(1).strip()]] = int(m.group(2))
+    return res
+
+
+def resources():
+    """Register / scratch usage of every kernel as reported by hipcc when the objects were compiled (csrc/*.resources.json)."""
+    import json
+    out = {}
+    for src in SOURCES:
+        f = os.path.join(CSRC, src.replace(".hip", ".resources.json"))
+        if os.path.exists(f):
+            out.update(json.load(open(f)))
+    return out
+
+
 def build(force: bool = False, verbose: bool = True) -> str:
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     headers = [os.path.join(CSRC, "zvx_kernels.h"), os.path.join(CSRC, "mfma_util.h"), os.path.join(os.path.dirname(HERE), "include", "zvx.h")]
@@ -27,11 +55,32 @@ def build(force: bool = False, verbose: bool = True) -> str:
     for src in SOURCES:
         s = os.path.join(CSRC, src)
         o = os.path.join(CSRC, src.replace(".hip", ".o"))
-        if force or _stale(o, [s] + headers):
-            cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(src, []) + ["-c", s, "-o", o]
+        rj = os.path.join(CSRC, src.replace(".hip", ".resources.json"))
+        if force or _stale(o, [s] + headers) or not os.path.exists(rj):
+            cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(src, []) + ["-Rpass-analysis=kernel-resource-usage", "-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd), flush=True)
-            subprocess.check_call(cmd)
+            p = subprocess.run(cmd, stderr=subprocess.PIPE, text=True)
+            # the remarks (one block per kernel, each followed by a two-line source excerpt) are parsed below, everything else is shown
+            lines, keep, skip = p.stderr.splitlines(), [], 0
+            for l in lines:
+                if "[-Rpass-analysis=kernel-resource-usage]" in l:
+                    skip = 2
+                elif skip and (l.lstrip().startswith("|") or (l.strip()[:1].isdigit() and " | " in l)):
+                    skip -= 1
+                elif "remarks generated" not in l:
+                    skip = 0
+                    keep.append(l)
+            if keep:
+                print("\n".join(keep), file=sys.stderr)
+            if p.returncode:
+                raise subprocess.CalledProcessError(p.returncode, cmd)
+            import json
+            res = _parse_resources(p.stderr)
+            json.dump(res, open(rj, "w"), indent=0, sort_keys=True)
+            spilled = {k: v for k, v in res.items() if v.get("vgpr_spill")}
+            if spilled and verbose:
+                print(f"note: {len(spilled)} kernels of {src} spill VGPRs: " + ", ".join(f"{k[:60]}({v['vgpr_spill']})" for k, v in list(spilled.items())[:6]), flush=True)
         objs.append(o)
     if force or _stale(LIB, objs):
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-ldl", "-o", LIB]
