@@ -672,6 +672,30 @@ def test_config3_workload_on_one_gpu_256_utterances_equal_eight_shards():
         assert np.array_equal(shard, whole[sl]), f"shard {r}"
 
 
+@pytest.mark.parametrize("kind", ["styletts", "fastspeech2"])
+def test_config2_secondary_workload_variable_lengths_full_size(kind):
+    """configs[1], secondary input of SURVEY 8(d): 32 x 128 phonemes with forced durations ~ U{3..10} (each utterance its own
+    length, 770-890 frames).  At this size the oracle is out of reach; the size-independent property is that an utterance does
+    not see its batch: sampled utterances equal their own batch-1 calls bit for bit (waveform, mel, mel_len), tails are zero."""
+    ctx = ctx_for(kind, "v1", "bf16")
+    ph, pu, T, spk, dur = synthetic.batch(32, 128, 0, "uniform")
+    L = dur.sum(1).astype(np.int32)
+    assert L.min() >= 600 and L.max() <= 1280 and len(set(L.tolist())) > 16
+    pad_to = np.maximum(689, L).astype(np.int32)                          # the fresh-model value of model.py:331-335 per utterance
+    out = ctx.synthesize(ph, pu, T, spk, dur, pad_to, want_mel=True)
+    wav, mel, ml = out["wav"], out["mel"], out["mel_len"]
+    assert np.array_equal(ml, pad_to) and np.isfinite(wav).all()
+    for b in range(32):
+        assert not wav[b, int(ml[b]) * 256:].any() and not mel[b, int(ml[b]):].any()
+        assert np.abs(wav[b, :int(L[b]) * 256]).max() > 1e-3
+    for b in (0, 7, 19, 31):
+        solo = ctx.synthesize(ph[b:b + 1], pu[b:b + 1], T[b:b + 1], spk[b:b + 1], dur[b:b + 1], pad_to[b:b + 1], want_mel=True)
+        n = int(ml[b])
+        assert int(solo["mel_len"][0]) == n
+        assert np.array_equal(solo["wav"][0, :n * 256], wav[b, :n * 256]), f"utt {b}: waveform depends on the batch"
+        assert np.array_equal(solo["mel"][0, :n], mel[b, :n]), f"utt {b}: mel depends on the batch"
+
+
 def test_converted_checkpoint_runs_and_baked_in_vocoder_wins(tmp_path):
     """SURVEY 8 f-2 end to end: a Lightning-style checkpoint (state_dict + pickled hyper_parameters holding a `Symbols`
     object, a vocoder baked in under `_meldec.`) -> tools/convert_checkpoint.py -> ZeroVoxTTS.load_model(directory) ->
