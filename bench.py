@@ -129,8 +129,8 @@ def cpu_baseline(config, model, T, pad_to):
             out = O.inference_ex(sd, hsd, cfg, hcfg, ph, pu, spk, duration=dur, pad_to=pad_to)
             n, unit, what = len(out["wav"]), "samples/s", f"1 utterance of the workload ({T} phonemes -> {out['mel_len']} frames -> {len(out['wav'])} samples)"
         elif config == 4:
-            mel = np.random.default_rng(7).standard_normal((80, 1024)).astype(np.float32)
-            n, unit, what = len(O.hifigan_generator(mel, hsd, hcfg)), "samples/s", "1 utterance of the workload (1024-frame mel -> 262144 samples)"
+            mel = np.random.default_rng(7).standard_normal((80, 1024)).astype(np.float32)[:, :512]      # half an utterance keeps the sample within ~30 s
+            n, unit, what = len(O.hifigan_generator(mel, hsd, hcfg)), "samples/s", "the first 512 frames of one utterance of the workload (-> 131072 samples)"
         else:
             mels = np.random.default_rng(8).standard_normal((4, 258, 80)).astype(np.float32)
             for m in mels:
