@@ -24,6 +24,7 @@
 #include "zvx_kernels.h"
 
 #include <hip/hip_ext.h>
+#include <cstring>
 #include <type_traits>
 
 // Per-launch timing without marker packets: when the caller has armed a pair of events (gemm_profile_events), the
@@ -1369,6 +1370,25 @@ int launch_resfuse(GemmArgs a, hipStream_t stream) {
     if (h1 > 32) return -1;
     a.halo_l = a.halo_r = h1;
     a.fused = 1;
+    if (a.N == 128 && !a.no_pairstream) {
+        // C = 128: the streaming pair kernel (pairstream.hip); its epilogue covers exactly what the vocoder asks for
+        const int h2 = (a.ntaps - 1) / 2, dil = a.dv1[1] - a.dv1[0];
+        bool ok = a.alpha == 1.f && a.bias_mode == 1 && !a.post_scale && (!a.out || a.out_dtype == DT_BF16) && a.res_mode == 2 && a.res_dtype == DT_BF16 &&
+                  a.res == a.X && a.r_bs == a.x_bs && a.ldr == a.ldx && (!a.accum || a.accum_dtype == DT_BF16) && (a.act == ACT_NONE || a.act == ACT_LRELU) &&
+                  (a.accum_mode || a.out_scale == 1.f) && a.in_len == a.out_len;
+        for (int t = 0; t < a.ntaps; t++) ok = ok && a.dv[t] == t - h2 && a.dv1[t] == (t - h2) * dil;
+        if (ok) {
+            PairArgs p;
+            memset(&p, 0, sizeof p);
+            p.X = a.X; p.x_bs = a.x_bs; p.ldx = a.ldx; p.W1 = a.Wp2; p.W2 = a.Wp; p.b1 = a.bias1; p.b2 = a.bias;
+            p.C = a.N; p.ntaps = a.ntaps; p.dil = dil;
+            p.out = a.out; p.o_bs = a.o_bs; p.ldo = a.ldo;
+            p.accum = a.accum; p.a_bs = a.a_bs; p.lda = a.lda; p.accum_mode = a.accum ? a.accum_mode : 0;
+            p.slope1 = a.slope1; p.res_inv_slope = a.res_inv_slope; p.out_scale = a.out_scale; p.slope = a.act == ACT_LRELU ? a.slope : 1.f;
+            p.len = a.out_len; p.M = a.M; p.nbatch = a.nbatch;
+            if (launch_pairstream(p, stream, g_dry_run, g_dry_run ? nullptr : g_ev_start, g_ev_stop)) return 23;
+        }
+    }
     {
         if (a.N == 32 && launch_resfuse_persist_c<32>(a, stream)) return 16;
         if (a.N == 64 && a.ntaps != 11 && launch_resfuse_persist_c<64>(a, stream)) return 17;
@@ -1397,6 +1417,7 @@ static const Variant kVariants[] = {
     {"gemm_bf16_64x64", DT_BF16, 64, 64},         {"gemm_f32_64x64", DT_F32, 64, 64},
     {"resstream_bf16_c32", DT_BF16, 64, 32},      {"resstream_bf16_c64", DT_BF16, 32, 64},
     {"convslab_bf16_128x128", DT_BF16, 128, 128},
+    {"pairstream_bf16_c128", DT_BF16, 128, 128},
 };
 const char* gemm_variant_name(int id) { return kVariants[id].name; }
 int gemm_num_variants() { return (int)(sizeof(kVariants) / sizeof(kVariants[0])); }

@@ -36,6 +36,7 @@ struct GemmArgs {
     int halo_l, halo_r;        // filled by the launcher
     // fused ResBlock1 pair (resfuse kernel): out = epilogue(conv2(lrelu(conv1(X) + bias1)) + bias + inverse_lrelu(X))
     const void* Wp2; const float* bias1; int dv1[ZVX_MAX_TAPS]; int fused; float slope1;   // conv1: Wp2/bias1/dv1 (dilated); conv2: Wp/bias/dv
+    int no_pairstream;         // fused: 1 = never the streaming pair kernel of pairstream.hip (A/B switch)
     int dtype;                 // DType of X and W (same)
     int M, N, K;               // M = max rows per z, N cols, K per tap (multiple of 8 elements bf16 / 4 f32)
     int nbatch, nheads;
@@ -100,6 +101,25 @@ struct StreamArgs {
 // variant id (index into gemm_variant_name) or -1 when the shape is not covered; dry_run: decide only, launch nothing
 int launch_resstream(StreamArgs a, hipStream_t stream, bool dry_run);
 void resstream_profile_events(hipEvent_t start, hipEvent_t stop);     // like gemm_profile_events, for the next launch_resstream
+
+// ------------------------------------------------------------------------------------------------
+// Streaming ResBlock1 PAIR for the wide stages (pairstream.hip): x' = conv2(lrelu(conv1_dilated(x_act) + b1)) + b2 + x in ONE
+// launch for C = 128 (hifigan.py:51-55).  conv1 and conv2 are two wave groups of a persistent workgroup that walk a segment
+// of one utterance in 128-row steps; T = lrelu(conv1) lives only in an LDS ring, weights stream through per-wave register rings.
+// ------------------------------------------------------------------------------------------------
+struct PairArgs {
+    const void* X; long x_bs; int ldx;             // stage input [b][M][ldx] bf16, activated domain; also the residual
+    const void* W1; const void* W2;                // fragment-packed bf16 weights: conv1 (dilated), conv2 (dilation 1)
+    const float* b1; const float* b2;
+    int C, ntaps, dil;
+    void* out; long o_bs; int ldo;                 // bf16 output activated with `slope` (NULL: running sum only)
+    void* accum; long a_bs; int lda; int accum_mode;   // bf16 running sum xs: bit0 v += xs, bit1 xs = v
+    float slope1, res_inv_slope, out_scale, slope; // slope 1 = no output activation
+    const int* len; int M, nbatch;
+    int S, nseg, DX, DT, G0;                       // filled by the launcher: segment rows, segments per utterance, ring rows
+};
+// true when the shape is covered (and, unless dry_run, launched); ev_start / ev_stop: optional dispatch-carried events
+bool launch_pairstream(PairArgs a, hipStream_t stream, bool dry_run, hipEvent_t ev_start, hipEvent_t ev_stop);
 
 // ------------------------------------------------------------------------------------------------
 // Fused attention of the FS2 / SCLN decoder (attention.hip): out = softmax(Q K^T * scale, keys < len) V per (utterance, head),
