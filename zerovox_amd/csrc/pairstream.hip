@@ -35,6 +35,27 @@ namespace zvx {
 #define PS_TP 272         // T ring row pitch (256 B + 16 B pad)
 #define PS_NDMA 8         // LDS-DMA pieces (4 rows each) per conv1 wave and step
 
+// Development switches (tools/micro/ps_bench.hip): PS_EXP cuts pieces OUT of the kernel (results are wrong by design, only the
+// timing means something): 1 no weight refills, 2 no x-fragment LDS reads, 4 no global traffic in conv2's epilogue, 8 no DMA
+// in the loop, 16 no T writes, 32 no MFMAs.  PS_PROFILE: per-wave s_memtime totals of workgroup 0 -> a.prof.
+#ifndef PS_EXP
+#define PS_EXP 0
+#endif
+#ifndef PS_PD
+#define PS_PD 2           // x fragments are requested this many MFMA steps ahead (4 register sets)
+#endif
+#ifndef PS_PRIO
+#define PS_PRIO 1         // bit 0 / bit 1: conv2's / conv1's epilogue runs at raised wave priority (it competes with the partner's MFMA stream for issue slots)
+#endif
+#ifndef PS_RPF
+#define PS_RPF 1          // conv2: residual / running-sum rows of a block are requested before its main loop (not in its epilogue)
+#endif
+#ifdef PS_PROFILE
+#define PS_STAMP(k) do { const unsigned long long t_ = __builtin_readcyclecounter(); tacc[k] += t_ - tlast; tlast = t_; } while (0)
+#else
+#define PS_STAMP(k) do {} while (0)
+#endif
+
 // ROLE 0: conv1 (dilated; X ring -> T ring, issues the X DMA).  ROLE 1: conv2 (T ring -> HBM).
 template <int ROLE, int NT, int AM, bool HAS_OUT>
 __device__ __forceinline__ void ps_role(const PairArgs& a, unsigned char* lds, const int lane, const int ct) {
@@ -62,6 +83,9 @@ __device__ __forceinline__ void ps_role(const PairArgs& a, unsigned char* lds, c
 
     const float slope1 = a.slope1, rinv = a.res_inv_slope, oscale = a.out_scale, oslope = a.slope;
     f32x16 acc[4];
+#ifdef PS_PROFILE
+    unsigned long long tacc[4] = {0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
+#endif
 
     const int nsegs = a.nseg * a.nbatch;
     for (int seg = blockIdx.x; seg < nsegs; seg += gridDim.x) {
@@ -112,78 +136,99 @@ __device__ __forceinline__ void ps_role(const PairArgs& a, unsigned char* lds, c
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 
-        auto mma4 = [&](const u32x4& w, uint4 (&xf)[4]) __attribute__((always_inline)) {
-#pragma unroll
-            for (int j = 0; j < 4; j++)
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, xf[j]), acc[j], 0, 0, 0);
-        };
         // One block: NS steps of (1 weight fragment x 4 row tiles) as NT iterations of 8.  u = K-chunk * NT + tap; every LDS read
-        // is inline asm, requested one step ahead (sets A / B) with counted lgkmcnt; the weight fragment of a step was requested
+        // is inline asm, requested PS_PD steps ahead (4 register sets) with counted lgkmcnt; the weight fragment of a step was requested
         // one iteration earlier (counted vmcnt: the WD - 1 younger fragments + the EPI DMA instructions every iteration issues).
         auto main_loop = [&](bool dma_real) __attribute__((always_inline)) {
 #pragma unroll
             for (int j = 0; j < 4; j++)
 #pragma unroll
                 for (int e = 0; e < 16; e++) acc[j][e] = 0.f;
-            unsigned bs[4], nbs[4];
-            auto bases = [&](int u, unsigned (&o)[4]) __attribute__((always_inline)) {
+            unsigned bs[4], nbs[4], pn = 0, hkn = 0;
+            // LDS byte offsets of this lane's rows for step group u (= K-chunk * NT + tap), in two parts so that the VALU work can be
+            // spread over the gaps between MFMAs: the part common to the 4 row tiles, then one tile each
+            auto bases_common = [&](int u) __attribute__((always_inline)) {
                 const int kc = u >= NT ? 1 : 0, tap = u - kc * NT;
                 if (ROLE == 0) {
-                    unsigned p = x_rd + l32 + tap * dil; p = min(p, p - (unsigned)DX);
-                    const unsigned hk4 = (((p ^ hi) & 15u) << 4) ^ ((unsigned)kc << 7);
-#pragma unroll
-                    for (int j = 0; j < 4; j++) { unsigned pj = p + 32 * j; pj = min(pj, pj - (unsigned)DX); o[j] = (pj << 8) + hk4; }
+                    pn = x_rd + l32 + tap * dil; pn = min(pn, pn - (unsigned)DX);
+                    hkn = (((pn ^ hi) & 15u) << 4) ^ ((unsigned)kc << 7);
                 } else {
-                    unsigned p = t_rd + l32 + tap; p = min(p, p - (unsigned)DT);
-#pragma unroll
-                    for (int j = 0; j < 4; j++) { unsigned pj = p + 32 * j; pj = min(pj, pj - (unsigned)DT); o[j] = tbase + pj * PS_TP + hi * 16 + kc * 128; }
+                    pn = t_rd + l32 + tap; pn = min(pn, pn - (unsigned)DT);
+                    hkn = tbase + hi * 16 + kc * 128;
                 }
             };
-            auto rd = [&](uint4 (&xf)[4], unsigned (&o)[4], int kk) __attribute__((always_inline)) {          // kk is a literal at every call site
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    if (ROLE == 0) asm volatile("ds_read_b128 %0, %1" : "=v"(xf[j]) : "v"(o[j] ^ (unsigned)(kk << 5)));
-                    else {
-                        switch (kk) {
-                            case 0: asm volatile("ds_read_b128 %0, %1" : "=v"(xf[j]) : "v"(o[j])); break;
-                            case 1: asm volatile("ds_read_b128 %0, %1 offset:32" : "=v"(xf[j]) : "v"(o[j])); break;
-                            case 2: asm volatile("ds_read_b128 %0, %1 offset:64" : "=v"(xf[j]) : "v"(o[j])); break;
-                            default: asm volatile("ds_read_b128 %0, %1 offset:96" : "=v"(xf[j]) : "v"(o[j])); break;
-                        }
+            auto bases_tile = [&](int j, unsigned (&o)[4]) __attribute__((always_inline)) {
+                unsigned pj = pn + 32 * j;
+                if (ROLE == 0) { pj = min(pj, pj - (unsigned)DX); o[j] = (pj << 8) + hkn; }
+                else { pj = min(pj, pj - (unsigned)DT); o[j] = pj * PS_TP + hkn; }
+            };
+            auto rd1 = [&](uint4& xf, unsigned o, int kk) __attribute__((always_inline)) {          // kk is a literal at every call site
+                if (PS_EXP & 2) { asm volatile("" : "=v"(xf)); return; }
+                if (PS_EXP & 64) {                                              // the read happens, the MFMAs keep consuming a never-written register
+                    uint4 dummy;
+                    if (ROLE == 0) asm volatile("ds_read_b128 %0, %1" : "=v"(dummy) : "v"(o ^ (unsigned)(kk << 5)));
+                    else asm volatile("ds_read_b128 %0, %1" : "=v"(dummy) : "v"(o + kk * 32));
+                    asm volatile("" : "=v"(xf));
+                    return;
+                }
+                if (ROLE == 0) asm volatile("ds_read_b128 %0, %1" : "=v"(xf) : "v"(o ^ (unsigned)(kk << 5)));
+                else {
+                    switch (kk) {
+                        case 0: asm volatile("ds_read_b128 %0, %1" : "=v"(xf) : "v"(o)); break;
+                        case 1: asm volatile("ds_read_b128 %0, %1 offset:32" : "=v"(xf) : "v"(o)); break;
+                        case 2: asm volatile("ds_read_b128 %0, %1 offset:64" : "=v"(xf) : "v"(o)); break;
+                        default: asm volatile("ds_read_b128 %0, %1 offset:96" : "=v"(xf) : "v"(o)); break;
                     }
                 }
             };
-            uint4 xA[4], xB[4];
+            constexpr int PD = PS_PD;
+            static_assert(PD == 1 || PD == 2, "prefetch distance");
+            uint4 xs[4][4];                                                    // fragment sets: step i uses set i & 3
             const i32x4 rsd = dma_rsrc(gx, dma_real);
-            bases(0, bs);
+            bases_common(0);
+#pragma unroll
+            for (int j = 0; j < 4; j++) bases_tile(j, bs);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                 // nothing else in the LGKM queue while waits are counted
             __builtin_amdgcn_sched_barrier(0);
-            rd(xA, bs, 0);
+#pragma unroll
+            for (int i = 0; i < PD; i++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) rd1(xs[i][j], bs[j], i);
             for (int u2 = 0; u2 < NT; u2++) {
                 const int next_off = (u2 + 1 == NT ? 0 : (u2 + 1) * (WD * 1024));
 #pragma unroll
                 for (int h = 0; h < 2; h++) {
                     const int u = 2 * u2 + h;
+                    int un = u + 1; if (un == 2 * NT) un = 0;
 #pragma unroll
                     for (int kk = 0; kk < 4; kk++) {
-                        if (kk == 3) { int un = u + 1; if (un == 2 * NT) un = 0; bases(un, nbs); }
-                        if (kk == 0) rd(xB, bs, 1);
-                        else if (kk == 1) rd(xA, bs, 2);
-                        else if (kk == 2) rd(xB, bs, 3);
-                        else rd(xA, nbs, 0);
-                        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(4)" :: "n"(WD - 1 + EPI) : "memory");
+                        const int i = h * 4 + kk;
+                        // this step's weight fragment (requested one iteration ago) and fragment set (PD steps ago) have landed
+                        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(%1)" :: "n"(WD - 1 + EPI), "n"(4 * (PD - 1)) : "memory");
                         __builtin_amdgcn_sched_barrier(0);
-                        if (kk & 1) mma4(wreg[h * 4 + kk], xB); else mma4(wreg[h * 4 + kk], xA);
-                        __builtin_amdgcn_sched_barrier(0);
-                        wload(next_off + (h * 4 + kk) * 1024, h * 4 + kk);      // the slot just consumed takes the fragment 8 steps on
-                        if (ROLE == 0) {
-                            // this iteration's DMA instructions, spread over its steps (pieces past PS_NDMA: surplus, zero-fill the scratch KiB)
+                        // the step's other instructions sit in the gaps BETWEEN its MFMAs: a wave that is alone on its SIMD (its partner
+                        // is in an epilogue) otherwise leaves the matrix pipe idle while it issues them
 #pragma unroll
-                            for (int e = 0; e < EPI; e++)
-                                if (h * 4 + kk == (8 * e + 4) / EPI) {
-                                    const int pidx = u2 * EPI + e;
-                                    dma_piece(rsd, gx, x_wr, ct * PS_NDMA + (pidx < PS_NDMA ? pidx : 0), dma_real && pidx < PS_NDMA);
+                        for (int j = 0; j < 4; j++) {
+                            if (PS_EXP & 32) asm volatile("" : "+v"(acc[j]) : "v"(wreg[i]), "v"(xs[i & 3][j]));
+                            else acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wreg[i]), __builtin_bit_cast(bf16x8, xs[i & 3][j]), acc[j], 0, 0, 0);
+                            __builtin_amdgcn_sched_barrier(0);
+                            if (kk + PD < 4) rd1(xs[(i + PD) & 3][j], bs[j], kk + PD); else rd1(xs[(i + PD) & 3][j], nbs[j], kk + PD - 4);
+                            if (kk == 0 && j == 3) bases_common(un);
+                            if (kk == 1) bases_tile(j, nbs);
+                            if (j == 3) {
+                                if (!(PS_EXP & 1)) wload(next_off + i * 1024, i);          // the slot just consumed takes the fragment 8 steps on
+                                if (ROLE == 0 && !(PS_EXP & 8)) {
+                                    // this iteration's DMA instructions, spread over its steps (pieces past PS_NDMA: surplus, zero-fill the scratch KiB)
+#pragma unroll
+                                    for (int e = 0; e < EPI; e++)
+                                        if (i == (8 * e + 4) / EPI) {
+                                            const int pidx = u2 * EPI + e;
+                                            dma_piece(rsd, gx, x_wr, ct * PS_NDMA + (pidx < PS_NDMA ? pidx : 0), dma_real && pidx < PS_NDMA);
+                                        }
                                 }
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
                         }
                     }
 #pragma unroll
@@ -215,7 +260,8 @@ __device__ __forceinline__ void ps_role(const PairArgs& a, unsigned char* lds, c
                     uint2 pk;
                     pk.x = inside ? pack_bf16x2(v01.x, v01.y) : 0u;
                     pk.y = inside ? pack_bf16x2(v23.x, v23.y) : 0u;
-                    *(uint2*)(dst + q * 16) = pk;
+                    if (!(PS_EXP & 16)) *(uint2*)(dst + q * 16) = pk;
+                    else asm volatile("" :: "v"(pk.x), "v"(pk.y), "v"(dst));
                 }
             }
         };
@@ -225,23 +271,20 @@ __device__ __forceinline__ void ps_role(const PairArgs& a, unsigned char* lds, c
         // channels per lane: 16-byte loads / stores, lanes l and l + 32 adjacent in a row.  All global accesses are raw buffer
         // operations on per-utterance descriptors: rows outside the segment get an out-of-range offset (loads return 0, stores
         // are dropped), so the whole epilogue is branch-free and every load of the block is in flight before the first use.
-        auto epilogue_out = [&](int gb) __attribute__((always_inline)) {
+        int off[4];
+        u32x4 rx[4][2], sx[4][2];
+        auto res_rsrc = [&](const void* base, long bs_) __attribute__((always_inline)) {
+            return __builtin_amdgcn_make_buffer_rsrc((void*)((unsigned short*)base + (long)b * bs_), 0, len * a.ldx * 2, 0x00020000);
+        };
+        auto epilogue_loads = [&](int gb) __attribute__((always_inline)) {
             int lv = lane;
             asm volatile("" : "+v"(lv));                                       // nothing below is hoisted out of the step loop
             const int cA = ct * 32 + 8 * (lv >> 5);
-            float4 bq[4];
-#pragma unroll
-            for (int q = 0; q < 4; q++) bq[q] = *(const float4*)(bias_l + ct * 32 + 8 * q + 4 * (lv >> 5));
-            const int nbytes = len * a.ldx * 2;
-            const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc((void*)Xb, 0, nbytes, 0x00020000);
-            const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)((unsigned short*)a.accum + (long)b * a.a_bs), 0, nbytes, 0x00020000);
-            const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc((void*)((unsigned short*)a.out + (long)b * a.o_bs), 0, nbytes, 0x00020000);
-            int off[4];
-            u32x4 rx[4][2], sx[4][2];
+            const __amdgpu_buffer_rsrc_t rsX = res_rsrc(a.X, a.x_bs), rsA = res_rsrc(a.accum, a.a_bs);
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const int g = gb + 32 * j + (lv & 31);
-                off[j] = (g >= seg0 && g < seg_end) ? (g * a.ldx + cA) * 2 : (int)0x80000000;
+                off[j] = (g >= seg0 && g < seg_end && !(PS_EXP & 4)) ? (g * a.ldx + cA) * 2 : (int)0x80000000;
                 rx[j][0] = __builtin_amdgcn_raw_buffer_load_b128(rsX, off[j], 0, 0);
                 rx[j][1] = __builtin_amdgcn_raw_buffer_load_b128(rsX, off[j] + 32, 0, 0);
             }
@@ -252,6 +295,14 @@ __device__ __forceinline__ void ps_role(const PairArgs& a, unsigned char* lds, c
                     sx[j][1] = __builtin_amdgcn_raw_buffer_load_b128(rsA, off[j] + 32, 0, 0);
                 }
             }
+        };
+        auto epilogue_out = [&]() __attribute__((always_inline)) {
+            int lv = lane;
+            asm volatile("" : "+v"(lv));
+            float4 bq[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) bq[q] = *(const float4*)(bias_l + ct * 32 + 8 * q + 4 * (lv >> 5));
+            const __amdgpu_buffer_rsrc_t rsA = res_rsrc(a.accum, a.a_bs), rsO = res_rsrc(a.out, a.o_bs);
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 float v[16];
@@ -298,25 +349,43 @@ __device__ __forceinline__ void ps_role(const PairArgs& a, unsigned char* lds, c
             if (ROLE == 0) {
                 if (s < nb) {
                     main_loop(s + 1 < nb);                                     // fetches the X rows of block s + 1 on the way
+                    PS_STAMP(0);
                     gx += R; x_wr += R; if (x_wr >= DX) x_wr -= DX;
+                    if (PS_PRIO & 2) __builtin_amdgcn_s_setprio(2);
                     epilogue_T();
+                    if (PS_PRIO & 2) __builtin_amdgcn_s_setprio(0);
+                    PS_STAMP(1);
                     x_rd += R; if (x_rd >= DX) x_rd -= DX;
                     t_wr += R; if (t_wr >= DT) t_wr -= DT;
                     g1 += R;
                 }
             } else {
-                if (s >= 2) { epilogue_out(g2); g2 += R; }
+                if (s >= 2) {
+                    if (PS_PRIO & 1) __builtin_amdgcn_s_setprio(2);
+                    if (!PS_RPF) epilogue_loads(g2);
+                    epilogue_out();
+                    if (PS_PRIO & 1) __builtin_amdgcn_s_setprio(0);
+                    g2 += R;
+                    PS_STAMP(1);
+                }
                 if (s >= 1 && s <= nb) {
+                    if (PS_RPF) epilogue_loads(g2);                            // rows of THIS block: in registers long before its epilogue (next step)
                     main_loop(false);
                     t_rd += R; if (t_rd >= DT) t_rd -= DT;
+                    PS_STAMP(0);
                 }
             }
             if (s <= nb) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            PS_STAMP(2);
         }
     }
     // the ring registers stay allocated until the last requests have landed (hipcc would otherwise re-use them)
 #pragma unroll
     for (int i = 0; i < WD; i++) asm volatile("s_waitcnt vmcnt(0)" : "+v"(wreg[i]) :: "memory");
+#ifdef PS_PROFILE
+    if (a.prof && blockIdx.x == 0 && lane == 0)
+        for (int k = 0; k < 4; k++) a.prof[(ROLE * 4 + ct) * 4 + k] = (long long)tacc[k];
+#endif
 }
 
 template <int NT, int AM, bool HAS_OUT>

@@ -117,6 +117,7 @@ struct PairArgs {
     float slope1, res_inv_slope, out_scale, slope; // slope 1 = no output activation
     const int* len; int M, nbatch;
     int S, nseg, DX, DT, G0;                       // filled by the launcher: segment rows, segments per utterance, ring rows
+    long long* prof;                               // PS_PROFILE builds: [8 waves][main, epilogue, barrier, -] cycle totals of workgroup 0
 };
 // true when the shape is covered (and, unless dry_run, launched); ev_start / ev_stop: optional dispatch-carried events
 bool launch_pairstream(PairArgs a, hipStream_t stream, bool dry_run, hipEvent_t ev_start, hipEvent_t ev_stop);
