@@ -63,3 +63,38 @@ def test_reference_model_directories_load_without_conversion(tmp_path):
     torch.save({"generator": {k: torch.from_numpy(np.array(v)) for k, v in hsd.items()}}, vdir / "generator.ckpt")
     h2, hsd2 = load_meldec_weights(str(vdir), tts_modelpath=str(mdir))
     assert h2 == h and all(np.array_equal(hsd2[k], hsd[k]) for k in hsd)
+
+
+def test_baked_in_vocoder_with_folded_weights_as_the_reference_stores_it(tmp_path):
+    """model.py:115, 247 / edit_meldec_in_checkpoint.py:77-84: the reference attaches the generator AFTER remove_weight_norm(), so
+    a Lightning checkpoint holds plain `_meldec.*.weight` tensors while generator.ckpt holds weight_g / weight_v pairs.  The
+    baked-in copy must still be accepted (and win), and pack to the same device weights as the weight-normed original."""
+    from zerovox_amd import pack
+    cfg = zcfg.medium_modelcfg("styletts")
+    h = zcfg.hifigan_config("tiny")
+    sd, hsd = zw.tts_state_dict(cfg, 5), zw.hifigan_state_dict(h, 5)
+    baked = zw.folded(hsd)
+    assert any(k.endswith(".weight_g") for k in hsd) and not any(k.endswith(".weight_g") for k in baked)
+    mdir = tmp_path / "tts_en"
+    (mdir / "checkpoints").mkdir(parents=True)
+    yaml.safe_dump(cfg, open(mdir / "modelcfg.yaml", "w"))
+    state = {k: torch.from_numpy(np.array(v)) for k, v in sd.items()}
+    state.update({"_meldec." + k: torch.from_numpy(np.array(v)) for k, v in baked.items()})
+    torch.save({"state_dict": state}, mdir / "checkpoints" / "epoch=3.ckpt")
+    vdir = tmp_path / "hifigan"
+    vdir.mkdir()
+    json.dump(h, open(vdir / "config.json", "w"))
+    torch.save({"generator": {k: torch.from_numpy(np.array(v)) for k, v in hsd.items()}}, vdir / "generator.ckpt")
+    h2, hsd2 = load_meldec_weights(str(vdir), tts_modelpath=str(mdir))
+    assert h2 == h and set(hsd2) == set(baked) and all(np.array_equal(hsd2[k], baked[k]) for k in baked)
+    m1, b1 = pack.pack_model(cfg, sd, h, hsd, "f32")
+    m2, b2 = pack.pack_model(cfg, sd, h, hsd2, "f32")
+    assert m1 == m2 and np.allclose(np.frombuffer(b1, np.float32), np.frombuffer(b2, np.float32), rtol=0, atol=1e-6)
+    # a baked-in vocoder of another architecture is still refused
+    other = zw.folded(zw.hifigan_state_dict(zcfg.hifigan_config("tiny2"), 5))
+    state = {k: torch.from_numpy(np.array(v)) for k, v in sd.items()}
+    state.update({"_meldec." + k: torch.from_numpy(np.array(v)) for k, v in other.items()})
+    torch.save({"state_dict": state}, mdir / "checkpoints" / "epoch=4.ckpt")
+    import pytest
+    with pytest.raises(ValueError):
+        load_meldec_weights(str(vdir), tts_modelpath=str(mdir))

@@ -584,6 +584,28 @@ def test_streaming_resblock_kernels_equal_per_pair_launches(voc):
         ctx.set_int("resstream", 1)
 
 
+def test_streaming_pair_kernel_equals_two_conv_slab_launches():
+    """pairstream.hip (conv1 + conv2 of a C = 128 ResBlock pair in one launch: T in an LDS ring, weights through register rings,
+    x by LDS-DMA into an XOR-swizzled ring) against the two conv-slab launches it replaces: bit-identical waveforms for every
+    kernel size (k = 3 / 7 / 11, all three running-sum modes) -- ragged batches, one-frame utterances, utterances cut into
+    several segments per workgroup (segment seams: halo rows of T and x), more segments than CUs."""
+    ctx = ctx_for("styletts", "v1", "bf16")
+    rng = np.random.default_rng(37)
+    try:
+        for B, Pmax in ((3, 23), (2, 300), (1, 1), (40, 33), (1, 1100), (5, 70)):
+            P = rng.integers(1, Pmax + 1, B).astype(np.int32); P[0] = Pmax
+            mel = np.zeros((B, Pmax, 80), np.float32)
+            for b in range(B):
+                mel[b, :P[b]] = rng.standard_normal((P[b], 80)).astype(np.float32)
+            ctx.set_int("pairstream", -1); ref = ctx.vocode_mel(mel, P)       # no fused kernel at all for C = 128
+            ctx.set_int("pairstream", 1); got = ctx.vocode_mel(mel, P)        # every pair of the C = 128 stage streamed
+            assert np.isfinite(got).all() and np.array_equal(got, ref), (B, Pmax)
+            ctx.set_int("pairstream", 2); dflt = ctx.vocode_mel(mel, P)       # default: k = 3 on the register-resident kernel (bf16 xs add)
+            assert np.isfinite(dflt).all() and np.abs(dflt - ref).max() < 2e-2, (B, Pmax)
+    finally:
+        ctx.set_int("pairstream", 2)
+
+
 def test_rccl_gather_path_on_a_one_rank_communicator():
     """The multi-GPU gather inside libzvx (dlopen of librccl, ncclCommInitRank, grouped ncclSend/ncclRecv on the communication
     stream, the device-side fence that orders a later synthesis behind the gather) exercised on ONE GPU through a real

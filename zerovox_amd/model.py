@@ -80,7 +80,11 @@ def load_meldec_weights(modelspec, tts_modelpath=None):
                 bsd = read_tts_checkpoint(str(tts_modelpath))[1] or None
                 baked = find_tts_checkpoint(str(tts_modelpath))
     if bsd:
-        bad = sorted(k for k in set(bsd) | set(hsd) if k not in bsd or k not in hsd or bsd[k].shape != hsd[k].shape)
+        # The reference bakes the vocoder in AFTER remove_weight_norm() (model.py:115, 247; edit_meldec_in_checkpoint.py:77-84
+        # copies meldec.state_dict()): a Lightning / edited checkpoint holds plain `.weight` tensors, generator.ckpt holds
+        # weight_g / weight_v pairs.  Compare the two in the folded domain (pack._wn accepts either form).
+        fb, fh = zw.folded(bsd), zw.folded(hsd)
+        bad = sorted(k for k in set(fb) | set(fh) if k not in fb or k not in fh or fb[k].shape != fh[k].shape)
         if bad:
             raise ValueError(f"{baked}: baked-in vocoder does not match {spec}/config.json (first mismatching keys: {bad[:4]})")
         hsd = bsd
