@@ -45,6 +45,12 @@ def src_sha16():
     return h.hexdigest()[:16]
 
 
+def workload_key(args):
+    """What a PMC profile must have been taken on to be quoted for this run (profiles/traffic.json carries the same dict)."""
+    return {"config": args.config, "decoder": args.decoder, "vocoder": args.vocoder, "precision": args.precision,
+            "batch": args.batch or (50 if args.config == 5 else 32), "phonemes": args.phonemes}
+
+
 def exchange_comm_id(rank, world, make_id):
     """rank 0's 128-byte RCCL id -> every rank over a plain TCP socket on MASTER_ADDR : (ZVX_RDZV_PORT or MASTER_PORT + 37).
     Deliberately NOT torch.distributed: importing torch after libzvx.so loads torch's bundled copies of librccl / libhsa-runtime
@@ -62,7 +68,7 @@ def exchange_comm_id(rank, world, make_id):
             try:
                 srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
                 srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
-                srv.bind(("127.0.0.1" if addr in ("127.0.0.1", "localhost") else "", port))
+                srv.bind(("127.0.0.1" if addr in ("127.0.0.1", "localhost") else addr, port))       # MASTER_ADDR only, never all interfaces
                 break
             except OSError:
                 srv.close(); srv = None
@@ -70,12 +76,25 @@ def exchange_comm_id(rank, world, make_id):
             raise SystemExit(f"rank 0: none of the rendezvous ports {ports} is free")
         srv.listen(world)
         srv.settimeout(600)
-        served = 0
-        while served < world - 1:
+        served = set()                                 # distinct ranks that have the id: a stray connection (port scan, health
+        while len(served) < world - 1:                  # probe) does not use up a slot, a retrying rank is served again
             conn, _ = srv.accept()
             with conn:
-                conn.sendall(magic + cid)
-            served += 1
+                try:
+                    conn.settimeout(3)
+                    hello = b""
+                    while len(hello) < len(magic) + 4:
+                        chunk = conn.recv(len(magic) + 4 - len(hello))
+                        if not chunk:
+                            break
+                        hello += chunk
+                    if len(hello) == len(magic) + 4 and hello.startswith(magic):
+                        r = int.from_bytes(hello[len(magic):], "little")
+                        if 0 < r < world:
+                            conn.sendall(magic + cid)
+                            served.add(r)
+                except OSError:
+                    pass
         srv.close()
         return cid
     t0, last, need = time.time(), None, len(magic) + 128
@@ -84,6 +103,7 @@ def exchange_comm_id(rank, world, make_id):
             try:
                 with socket.create_connection((addr, port), timeout=5) as c:
                     c.settimeout(3)                 # rank 0 answers at once; anything slower is not rank 0
+                    c.sendall(magic + int(rank).to_bytes(4, "little"))
                     buf = b""
                     while len(buf) < need:
                         chunk = c.recv(need - len(buf))
@@ -96,6 +116,26 @@ def exchange_comm_id(rank, world, make_id):
                 last = e
         time.sleep(0.2)
     raise SystemExit(f"rank {rank}: no RCCL id from rank 0 at {addr}:{ports} ({last})")
+
+
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU, the environment
+    torch.distributed.run would have set); rank 0's JSON line is this process's output."""
+    import socket
+    import subprocess
+    entry = os.environ.get("ZVX_BENCH_ENTRY", os.path.abspath(__file__))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, entry] + argv, env=env))
+    rc = 0
+    for p in procs:
+        rc = p.wait() or rc
+    return rc
 
 
 def flush_c_stdio():
@@ -130,15 +170,20 @@ def cpu_baseline(config, model, T, pad_to):
             n, unit, what = len(out["wav"]), "samples/s", f"1 utterance of the workload ({T} phonemes -> {out['mel_len']} frames -> {len(out['wav'])} samples)"
         elif config == 4:
             mel = np.random.default_rng(7).standard_normal((80, 1024)).astype(np.float32)[:, :512]      # half an utterance keeps the sample within ~30 s
-            n, unit, what = len(O.hifigan_generator(mel, hsd, hcfg)), "samples/s", "the first 512 frames of one utterance of the workload (-> 131072 samples)"
+            n, unit, what = len(O.hifigan_generator(mel, hsd, hcfg)), "samples/s", "HALF an utterance of the workload: its first 512 of 1024 frames (-> 131072 samples)"
         else:
             mels = np.random.default_rng(8).standard_normal((4, 258, 80)).astype(np.float32)
             for m in mels:
                 O.resnet_se34v2(m, sd, cfg)
             n, unit, what = 4, "clips/s", "4 clips of the workload (258-frame mels)"
         dt = time.time() - t0
-    return {"value": n / dt, "unit": unit, "cores": int(cores), "kind": "port",
-            "sample": f"{what} through oracle/zvx_oracle.py (NumPy/BLAS fp32) in {dt:.1f} s"}
+    res = {"value": n / dt, "unit": unit, "cores": int(cores), "kind": "port",
+           "sample": f"{what} through oracle/zvx_oracle.py (NumPy/BLAS fp32) in {dt:.1f} s"}
+    if config == 2:
+        # context, not measured here: the reference's own PyTorch / oneDNN CPU path in the survey container
+        res["reference_torch_cpu_samples_per_s"] = 189000
+        res["reference_torch_cpu_note"] = "gooofy/zerovox inference_ex on 8 cores of the survey container (BASELINE.md section 3); the NumPy port timed here is ~25x slower than that path"
+    return res
 
 
 def main(argv=None, ctx_factory=default_ctx_factory):
@@ -154,9 +199,12 @@ def main(argv=None, ctx_factory=default_ctx_factory):
     ap.add_argument("--precision", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--pcm16", action="store_true", help="int16 PCM waveform rows (halves the gather payload)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--host-out", action="store_true", help="config 2: deliver every step's waveform to host memory (D2H copy inside the timed region), as the reference's tts_ex does")
     ap.add_argument("--profile", type=int, default=2, help="0 none, 1 stage events, 2 + per-launch events on the dominant kernel")
     args = ap.parse_args(argv)
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_ranks(args.gpus, list(sys.argv[1:] if argv is None else argv))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -164,6 +212,8 @@ def main(argv=None, ctx_factory=default_ctx_factory):
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if world > 1 and args.config != 2:
         raise SystemExit("configs 4 / 5 are single-GPU isolation benchmarks")
+    if args.host_out and (world > 1 or args.config != 2):
+        raise SystemExit("--host-out is the single-GPU config-2 variant")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
     from zerovox_amd import synthetic
@@ -190,7 +240,12 @@ def main(argv=None, ctx_factory=default_ctx_factory):
         units_per_step, unit = B * N, "samples/s"
         it = [0]
 
+        host_wav = [None]
+
         def step():
+            if args.host_out:                           # the reference's contract: tts_ex returns host NumPy (synthesize.py:233-239)
+                host_wav[0] = ctx.synthesize(ph, pu, Tlen, spk, dur, pad_to, want_mel=False, pcm16=args.pcm16)["wav"]
+                return
             buf = wav[it[0] & 1]; it[0] += 1
             ctx.synthesize(ph, pu, Tlen, spk, dur, pad_to, want_mel=False, wav_device_ptr=buf, wav_stride=N, no_sync=True, pcm16=args.pcm16)
             if world > 1:
@@ -199,7 +254,9 @@ def main(argv=None, ctx_factory=default_ctx_factory):
                     f"tts_medium_{'styledec' if args.decoder == 'styletts' else 'fs2'} + HiFi-GAN {args.vocoder.upper()}, end-to-end phoneme->waveform"
                     + (f", RCCL waveform gather ({'int16' if args.pcm16 else 'f32'}) to rank 0 each step" if world > 1 else ""))
         cfg_extra = {"global_batch": B * world, "phonemes": T, "frames": L, "samples_per_utt": N, "decoder": args.decoder,
-                     "vocoder": args.vocoder, "pad_to": int(pad_to[0]), "wav_dtype": "int16" if args.pcm16 else "f32"}
+                     "vocoder": args.vocoder, "pad_to": int(pad_to[0]), "wav_dtype": "int16" if args.pcm16 else "f32",
+                     "wav_delivery": "host (synchronous D2H copy of every step's waveform inside the timed region)" if args.host_out else
+                                     "device (rows stay in HBM for the gather / the caller; --host-out times the D2H copy too)"}
     elif args.config == 4:
         B = args.batch or 32
         P = 1024; N = P * hop
@@ -271,7 +328,7 @@ def main(argv=None, ctx_factory=default_ctx_factory):
             ok = bool(np.array_equal(g[:B], own)) and all(bool(np.abs(g[r * B:(r + 1) * B].astype(np.float32)).max() > 0) for r in range(world))
         else:
             ok = True
-        w = ctx.dev_to_host(wav[0], (B, N), wdt)[0].astype(np.float32) / (32760.0 if args.pcm16 else 1.0)
+        w = (host_wav[0] if (args.config == 2 and args.host_out) else ctx.dev_to_host(wav[0], (B, N), wdt))[0].astype(np.float32) / (32760.0 if args.pcm16 else 1.0)
         ok = ok and bool(np.isfinite(w).all()) and 0 < float(np.abs(w).max()) <= 1.0
 
     if rank == 0:
@@ -299,15 +356,24 @@ def main(argv=None, ctx_factory=default_ctx_factory):
             peak = MFMA_PEAK["f32" if (args.precision == "f32" or f32_dom) else "bf16"]
             traffic = traffic_note = None
             pmc = {}
-            try:    # per-launch HBM bytes of this kernel from the rocprofv3 PMC passes of the SAME sources (tools/refresh_profiles.sh)
-                tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
-                if tj.get("src_sha16") == res["src_sha16"] and tj.get("config", 2) == args.config:
+            # per-launch HBM bytes of this kernel from the rocprofv3 PMC passes of the SAME sources on the SAME workload
+            # (tools/refresh_profiles.sh writes one profiles/traffic*.json per profiled command)
+            import glob
+            seen = []
+            for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "traffic*.json"))):
+                try:
+                    tj = json.load(open(f))
+                except Exception:
+                    continue
+                seen.append((os.path.basename(f), tj.get("src_sha16"), tj.get("workload_key")))
+                if tj.get("src_sha16") == res["src_sha16"] and tj.get("workload_key") == workload_key(args):
                     pmc = tj.get(dom["name"], {})
                     traffic = pmc.get("hbm_bytes_per_launch")
-                else:
-                    traffic_note = "profiles/traffic.json was collected on different sources/config: not quoted"
-            except Exception:
-                traffic_note = "profiles/traffic.json missing"
+                    res["traffic_source"] = "profiles/" + os.path.basename(f)
+                    break
+            else:
+                traffic_note = ("no profiles/traffic*.json was collected on these sources AND this workload: not quoted "
+                                f"(found {[(n, sh) for n, sh, _ in seen]})") if seen else "profiles/traffic*.json missing"
             res["roofline"] = {"bound": "mfma", "kernel": dom["name"], "achieved": achieved, "peak": peak,
                                "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic,
                                "launches": dom["launches"], "avg_launch_ms": avg_ms,

@@ -138,6 +138,43 @@ def spk_case(name, Tr, seed):
     save(name, ref_mel=mel, embed=t2n(e)[0, 0], seed=np.array(SEED))
 
 
+def spk_sap_case(name, Tr, seed):
+    """encoder_type 'SAP' (ResNetSE34V2.py:135-143, 199-200): a second reference model whose speaker encoder pools with the
+    attention-weighted mean only (fc over 2560 inputs); everything else as the medium config."""
+    import copy
+    print(f"[spk-sap] {name}")
+    cfg = copy.deepcopy(zcfg.medium_modelcfg("styletts"))
+    cfg["model"]["resnet"]["encoder_type"] = "SAP"
+    zv = ZeroVox(symbols=Symbols(zcfg.PHONES, zcfg.PUNCTS), meldec_model=None, **zcfg.zerovox_kwargs(cfg))
+    sd = zw.tts_state_dict(cfg, SEED)
+    zv.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in sd.items()}, strict=True)
+    zv.eval()
+    mel = np.random.default_rng(seed).standard_normal((Tr, 80)).astype(np.float32)
+    with torch.no_grad():
+        e = zv._spkemb(torch.from_numpy(mel[None]))
+    save(name, ref_mel=mel, embed=t2n(e)[0, 0], seed=np.array(SEED), encoder_type=np.array("SAP"))
+
+
+def v3_cases():
+    """HiFi-GAN V3 at its published width (jik876 config_v3: ResBlock2, hifigan.py:65-86, kernels 3 / 5 / 7, dilations up to 12):
+    the last ResBlock2 of stage 1 (C = 128, k = 7, dilations [3, 12]) on its own, and the whole generator on a short mel."""
+    print("[v3]")
+    r = np.random.default_rng(123)
+    g = ref_generator("v3")
+    h = zcfg.hifigan_config("v3")
+    out = {}
+    with torch.no_grad():
+        C1 = h["upsample_initial_channel"] // 2
+        xr = r.standard_normal((1, C1, 96)).astype(np.float32)
+        out["rb_x"] = xr[0]
+        out["rb2_y"] = t2n(g.resblocks[2](torch.from_numpy(xr)))[0]          # k = 7, dilations [3, 12]
+        out["rb0_y"] = t2n(g.resblocks[0](torch.from_numpy(xr)))[0]          # k = 3, dilations [1, 2]
+        mel = r.standard_normal((80, 20)).astype(np.float32)
+        out["mel"] = mel
+        out["wav"] = t2n(g(torch.from_numpy(mel)))[0]
+    save("blocks_hifigan_v3", **out)
+
+
 def block_cases():
     print("[blocks]")
     r = np.random.default_rng(99)
@@ -222,7 +259,9 @@ def main():
     e2e_case("e2e_fs2_v2_T24", "fastspeech2", "v2", 24, 6, "uniform", 689)
     spk_case("spkemb_T96", 96, 7)
     spk_case("spkemb_T258", 258, 8)
+    spk_sap_case("spkemb_sap_T96", 96, 9)
     block_cases()
+    v3_cases()
     with open(os.path.join(HERE, "MANIFEST.json"), "w") as f:
         json.dump({"generator": "tests/golden/gen_golden.py", "reference": "gooofy/zerovox @ 2025-04-18",
                    "torch": torch.__version__, "numpy": np.__version__, "weight_seed": SEED,

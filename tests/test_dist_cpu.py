@@ -226,3 +226,57 @@ def test_comm_id_rendezvous_world8_over_plain_sockets(monkeypatch):
         t.join(60)
     blocker.close()
     assert sorted(got) == list(range(8)) and all(got[r] == cid for r in range(8))
+
+
+def test_bench_spawns_its_own_ranks_when_launched_bare():
+    """`python bench.py --gpus 2 ...` with no launcher (WORLD_SIZE unset), as the driver starts the N = 1 line: bench.py starts
+    the ranks itself and still prints exactly one JSON line."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["ZVX_BENCH_ENTRY"] = os.path.join(ROOT, "tests", "_bench_stub_main.py")      # the ranks run bench.main with the stub context
+    cmd = [sys.executable, os.path.join(ROOT, "tests", "_bench_stub_main.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--batch", "3", "--phonemes", "8", "--profile", "0", "--no-cpu-baseline"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["steps"] == 2 and r["config"]["global_batch"] == 6 and r["output_ok"] is True
+    assert r["config"]["wav_delivery"].startswith("device")
+
+
+def test_comm_id_rendezvous_ignores_stray_connections(monkeypatch):
+    """A connection that is not a rank (port scan, health probe: connects, sends nothing or junk) must not use up one of rank 0's
+    world - 1 slots; a rank announces itself with magic + rank and is served once per distinct rank."""
+    import socket, threading, time
+    import bench
+    probe = socket.socket(); probe.bind(("127.0.0.1", 0)); base = probe.getsockname()[1]; probe.close()
+    monkeypatch.setenv("MASTER_ADDR", "127.0.0.1")
+    monkeypatch.setenv("ZVX_RDZV_PORT", str(base))
+    cid = bytes(reversed(range(128)))
+    got = {}
+    srv = threading.Thread(target=lambda: got.__setitem__(0, bench.exchange_comm_id(0, 3, lambda: cid)))
+    srv.start()
+    time.sleep(0.3)
+    for junk in (b"", b"GET / HTTP/1.0\r\n\r\n"):
+        with socket.create_connection(("127.0.0.1", base), timeout=5) as c:
+            if junk:
+                c.sendall(junk)
+            time.sleep(0.1)
+    ths = [threading.Thread(target=lambda r=r: got.__setitem__(r, bench.exchange_comm_id(r, 3, lambda: b""))) for r in (1, 2)]
+    for t in ths:
+        t.start()
+    for t in ths + [srv]:
+        t.join(60)
+    assert sorted(got) == [0, 1, 2] and all(got[r] == cid for r in got)
+
+
+def test_traffic_profile_is_quoted_only_for_its_own_workload():
+    """bench.workload_key: a PMC profile taken on V1 must not be quoted on a V3 line, nor config 2's on config 4."""
+    import argparse
+    import bench
+    base = dict(config=2, decoder="styletts", vocoder="v1", precision="bf16", batch=None, phonemes=128)
+    k = bench.workload_key(argparse.Namespace(**base))
+    assert k["batch"] == 32 and k == bench.workload_key(argparse.Namespace(**dict(base, batch=32)))
+    for change in (dict(vocoder="v3"), dict(config=4), dict(decoder="fastspeech2"), dict(precision="f32"), dict(batch=1), dict(config=5)):
+        assert bench.workload_key(argparse.Namespace(**dict(base, **change))) != k

@@ -460,10 +460,14 @@ def test_streamed_vocoding_equals_whole_utterance(prec):
     rng = np.random.default_rng(21)
     mel = rng.standard_normal((150, 80)).astype(np.float32)
     whole = ctx.vocode_mel(mel[None], np.array([150], np.int32))[0]
+    h, hsd = voc_sd("v1")
+    ref = O.hifigan_generator(mel.T, hsd, h)                                 # the oracle's whole-utterance waveform
+    check_wav(whole, ref, prec, "whole-utterance wav", e2e=False)
     for cpc in (1, 3):
         parts = list(zv.vocode_stream(mel, chunk_frames=40, chunks_per_call=cpc))
         assert [len(p) for p in parts] == [40 * 256, 40 * 256, 40 * 256, 30 * 256]
         got = np.concatenate(parts)
+        check_wav(got, ref, prec, f"streamed wav ({cpc} chunks per call) against the oracle", e2e=False)
         if prec == "bf16":
             assert np.array_equal(got, whole)
         else:
@@ -582,6 +586,37 @@ def test_streaming_resblock_kernels_equal_per_pair_launches(voc):
             assert np.isfinite(got).all() and np.array_equal(got, ref), (voc, B, Pmax)
     finally:
         ctx.set_int("resstream", 1)
+
+
+@pytest.mark.parametrize("pcm16", [False, True])
+def test_vocode_mel_with_input_stride_larger_than_longest_utterance(pcm16):
+    """zvx_vocode_mel with Pmax (the input mel's row stride) > max(P): the zero tail of a row ends at max_b(P) * hop -- what
+    include/zvx.h promises and the caller's wav_stride covers -- not at Pmax * hop.  Host output and device output (guard words
+    behind every row and behind the buffer must survive)."""
+    ctx = ctx_for("styletts", "tiny", "bf16")
+    rng = np.random.default_rng(77)
+    B, Pmax = 3, 40
+    P = np.array([9, 17, 4], np.int32)
+    mel = np.zeros((B, Pmax, 80), np.float32)
+    for b in range(B):
+        mel[b, :P[b]] = rng.standard_normal((P[b], 80)).astype(np.float32)
+    tight = ctx.vocode_mel(mel[:, :17], P, pcm16=pcm16)                      # reference: stride = longest utterance
+    wide = ctx.vocode_mel(mel, P, pcm16=pcm16)                               # stride 40 > 17
+    n = 17 * 256
+    assert wide.shape == (B, Pmax * 256) and np.array_equal(wide[:, :n], tight[:, :n]) and not wide[:, n:].any()
+    for b in range(B):
+        assert np.abs(wide[b, :P[b] * 256].astype(np.float32)).max() > 0 and not wide[b, P[b] * 256:].any()
+    # device output with a row stride of exactly max(P) * hop + 8 guard elements
+    ss, dt = (2, np.int16) if pcm16 else (4, np.float32)
+    stride = n + 8
+    guard = np.full((B + 1, stride), 12345, dt)
+    wav_d, mel_d = ctx.dev_alloc(guard.nbytes), ctx.dev_alloc(mel.nbytes)
+    ctx.dev_from_host(wav_d, guard); ctx.dev_from_host(mel_d, mel)
+    ctx.vocode_mel_device(mel_d, P, Pmax, wav_d, stride, pcm16=pcm16)
+    got = ctx.dev_to_host(wav_d, (B + 1, stride), dt)
+    assert np.array_equal(got[:B, :n], tight[:, :n]), "rows"
+    assert (got[:B, n:] == 12345).all() and (got[B] == 12345).all(), "writes past max(P) * hop"
+    ctx.dev_free(wav_d); ctx.dev_free(mel_d)
 
 
 def test_streaming_pair_kernel_equals_two_conv_slab_launches():
@@ -753,6 +788,14 @@ def test_converted_checkpoint_runs_and_baked_in_vocoder_wins(tmp_path):
     a = synth.tts_ex("converted checkpoint", spk, duration=[4] * 19)
     b = ref_synth.tts_ex("converted checkpoint", spk, duration=[4] * 19)
     assert a[2] == b[2] == 76 and np.array_equal(a[0], b[0]) and np.array_equal(a[3], b[3])
+    # ... and equals the ORACLE on the same weights (the baked-in vocoder hsd, not the external one), ids from the text front end
+    ph, pu = synth.transcript2phonemids("converted checkpoint")
+    out = O.inference_ex(sd, hsd, cfg, h, np.array(ph, np.int32), np.array(pu, np.int32), spk.reshape(-1), duration=np.full(len(ph), 4, np.int32), pad_to=689)
+    assert out["mel_len"] == 76 and len(ph) == 19
+    check_f32(a[3], out["mel"], "converted checkpoint: mel against the oracle")
+    check_f32(a[0], out["wav"], "converted checkpoint: wav against the oracle")
+    other = O.inference_ex(sd, hsd_other, cfg, h, np.array(ph, np.int32), np.array(pu, np.int32), spk.reshape(-1), duration=np.full(len(ph), 4, np.int32), pad_to=689)
+    assert np.abs(other["wav"] - a[0]).max() > 1e-3                          # the external generator would have given another waveform
 
 
 def test_demo_cli_prints_the_reference_rtf_lines(capsys, monkeypatch, tmp_path):
@@ -795,6 +838,38 @@ def test_fused_attention_of_the_fs2_decoder():
         check_mel(unfused[b, :L[b]], ref, "bf16", f"unfused attention utt {b}")
         assert np.abs(fused[b, :L[b]] - unfused[b, :L[b]]).max() < 0.08
         assert not fused[b, L[b]:].any()
+
+
+def test_speaker_encoder_sap_pooling_against_reference_golden():
+    """encoder_type 'SAP' against the fixture the REFERENCE produced with that option (tests/golden/gen_golden.py)."""
+    import copy
+    g = np.load(os.path.join(GOLDEN, "spkemb_sap_T96.npz"))
+    cfg = copy.deepcopy(zcfg.medium_modelcfg("styletts"))
+    cfg["model"]["resnet"]["encoder_type"] = "SAP"
+    sd = zw.tts_state_dict(cfg, 0)
+    h, hsd = voc_sd("tiny")
+    for prec in ("f32", "bf16"):
+        man, blob = pack.pack_model(cfg, sd, h, hsd, prec)
+        ctx = _lib.Context(man, blob, 0)
+        try:
+            e = ctx.spkemb(g["ref_mel"][None], np.array([g["ref_mel"].shape[0]], np.int32))[0]
+            assert abs(np.linalg.norm(e) - 1.0) < 1e-3
+            if prec == "f32":
+                check_f32(e, g["embed"], "SAP embed", 5e-5)
+            else:
+                assert float(e @ g["embed"]) > 0.999 and np.abs(e - g["embed"]).max() < 6e-3
+        finally:
+            ctx.close()
+
+
+@pytest.mark.parametrize("prec", ["f32", "bf16"])
+def test_vocoder_v3_against_reference_golden(prec):
+    """HiFi-GAN V3 at its published width (ResBlock2 with dilations up to 12) against the reference's own waveform."""
+    g = np.load(os.path.join(GOLDEN, "blocks_hifigan_v3.npz"))
+    ctx = ctx_for("styletts", "v3", prec)
+    mel = g["mel"].T[None]
+    wav = ctx.vocode_mel(mel, np.array([mel.shape[1]], np.int32))[0]
+    check_wav(wav, g["wav"], prec, "V3 wav", e2e=False)
 
 
 def test_speaker_encoder_sap_pooling():

@@ -105,6 +105,26 @@ def test_hifigan_blocks_match_reference(voc):
         close(y, g[f"{voc}_{key if i else 'up0'}_y"] if i else g[f"{voc}_up0_y"])
 
 
+def test_speaker_encoder_sap_pooling_matches_reference():
+    """encoder_type 'SAP' (ResNetSE34V2.py:135-143, 199-200) against the reference built with that option."""
+    import copy
+    g = np.load(os.path.join(GOLDEN, "spkemb_sap_T96.npz"))
+    cfg = copy.deepcopy(zcfg.medium_modelcfg("styletts"))
+    cfg["model"]["resnet"]["encoder_type"] = str(g["encoder_type"])
+    e = O.resnet_se34v2(g["ref_mel"], zw.tts_state_dict(cfg, 0), cfg)
+    assert abs(np.linalg.norm(e) - 1.0) < 1e-5
+    close(e, g["embed"], 1e-5)
+
+
+def test_hifigan_v3_resblock2_at_published_width_matches_reference():
+    """ResBlock2 (hifigan.py:65-86) at V3's width, incl. the k = 7 block with dilation 12, and the whole V3 generator."""
+    g = np.load(os.path.join(GOLDEN, "blocks_hifigan_v3.npz"))
+    h, hsd = voc_sd("v3")
+    for j in (0, 2):
+        close(O.resblock2(g["rb_x"], hsd, f"resblocks.{j}", h["resblock_kernel_sizes"][j], h["resblock_dilation_sizes"][j]), g[f"rb{j}_y"])
+    close(O.hifigan_generator(g["mel"], hsd, h), g["wav"], 2e-4)
+
+
 def test_manifest_hashes():
     import hashlib, json
     man = json.load(open(os.path.join(GOLDEN, "MANIFEST.json")))

@@ -14,6 +14,7 @@ NAMES = {  # rocprof kernel name pattern -> bench variant name
     r"convreg_kernel<64,": "convreg_bf16_c64", r"convreg_kernel<32,": "convreg_bf16_c32",
     r"gemm_kernel<1, 128, 128": "gemm_bf16_128x128", r"gemm_kernel<0, 128, 128": "gemm_f32_128x128",
     r"resstream_kernel<32,": "resstream_bf16_c32", r"resstream_kernel<64,": "resstream_bf16_c64",
+    r"pairstream128_kernel<": "pairstream_bf16_c128", r"gemm_kernel<1, 256, 64": "gemm_bf16_256x64", r"gemm_kernel<1, 256, 32": "gemm_bf16_256x32",
 }
 
 
@@ -55,7 +56,15 @@ if len(sys.argv) > 5:
         if name in res:
             res[name].update(c)
 sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
-from bench import src_sha16
-json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on `python bench.py --steps 3 --warmup 1 --no-cpu-baseline`",
-           "src_sha16": src_sha16(), "config": int(sys.argv[4]) if len(sys.argv) > 4 else 2, **res}, open(sys.argv[3], "w"), indent=1)
+import argparse
+import bench
+# argv[4]: the bench.py options of the profiled command (e.g. "--config 4"); the key bench.py compares before quoting
+ap = argparse.ArgumentParser()
+for o, d in (("--config", 2), ("--batch", None), ("--phonemes", 128)):
+    ap.add_argument(o, type=int, default=d)
+for o, d in (("--decoder", "styletts"), ("--vocoder", "v1"), ("--precision", "bf16")):
+    ap.add_argument(o, default=d)
+bargs, _ = ap.parse_known_args((sys.argv[4] if len(sys.argv) > 4 else "").split())
+json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on `python bench.py --steps 3 --warmup 1 --no-cpu-baseline " + (sys.argv[4] if len(sys.argv) > 4 else "") + "`",
+           "src_sha16": bench.src_sha16(), "workload_key": bench.workload_key(bargs), **res}, open(sys.argv[3], "w"), indent=1)
 print(json.dumps(res, indent=1))

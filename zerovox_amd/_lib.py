@@ -179,7 +179,8 @@ class Context:
         return mel_len, logd, pitch, energy
 
     def decode(self, B, Lmax):
-        mel = np.empty((B, max(Lmax, 1), self.n_mels), np.float32) if Lmax > 0 else np.zeros((B, 1, self.n_mels), np.float32)
+        # the library writes rows [0, ctx Lmax) of every utterance; a larger (or degenerate) request keeps zeros in the rest
+        mel = np.zeros((B, max(Lmax, 1), self.n_mels), np.float32)
         self._chk(self._lib.zvx_decode(self._h, _ptr(mel), max(Lmax, 1), 0))
         return mel
 
@@ -196,8 +197,9 @@ class Context:
     def vocode(self, B, mel_len, pad_to=None, pcm16=False):
         """wav [B][max(mel_len)*hop]: float32, or int16 PCM (x32760, truncated) with pcm16.  The array is created with
         np.empty on purpose: the library owns every byte it hands back (valid samples, then zeros)."""
-        n = max(int(np.max(mel_len)) * self.hop, 1)
-        wav = np.empty((B, n), np.int16 if pcm16 else np.float32)
+        n0 = int(np.max(mel_len)) * self.hop
+        n = max(n0, 1)
+        wav = (np.empty if n0 > 0 else np.zeros)((B, n), np.int16 if pcm16 else np.float32)    # all lengths 0: nothing is copied back
         pt = _i32(pad_to, (B,)) if pad_to is not None else None
         self._chk(self._lib.zvx_vocode(self._h, _ptr(pt), _ptr(wav), n, ZVX_PCM16 if pcm16 else 0))
         return wav

@@ -426,7 +426,10 @@ void fft_block(zvx_ctx* c, void* x, int dt, int B, int Lmax, const int* len_dev,
         a.bias = c->pf(w.p + ".bv"); a.bias_mode = 2;
         a.out = vt; a.o_bs = (long)H * Lp; a.ldo = Lp;
         // columns in [len, Lmax) hold finite junk (x rows beyond len are never NaN: buffers start zeroed and
-        // only ever receive finite values); P is exactly zero there, so they never contribute
+        // only ever receive finite values); P is exactly zero there, so they never contribute.  The pad columns [Lmax, Lp) are not
+        // written by this GEMM and the buffer is shared between the f32 encoder and the bf16 decoder (stale bits of one can read
+        // as Inf / NaN in the other, and 0 * NaN = NaN in the P.V product): zero them
+        if (Lp > Lmax) HIPCHK(hipMemset2DAsync((char*)vt + (size_t)Lmax * es, (size_t)Lp * es, 0, (size_t)(Lp - Lmax) * es, (size_t)B * H, c->stream));
         c->gemm(a);
     }
     FlashArgs fa;
@@ -992,10 +995,14 @@ void run_vocoder(zvx_ctx* c, const float* mel, int ldm, int Lmel_max, const int*
     c->tag = "voc.post";
     {
         double nout = 0; for (int b = 0; b < B; b++) nout += (double)mel_len_host[b] * c->hop;
+        // rows are zero-filled up to max_b(mel_len) * hop, the extent include/zvx.h promises (and the caller's wav_stride covers):
+        // Lmel_max is only the input's row stride and may be larger
+        int nmax = 0; for (int b = 0; b < B; b++) nmax = std::max(nmax, mel_len_host[b] * c->hop);
+        if ((long)nmax > wav_stride) nmax = (int)wav_stride;
         const int kp = c->t("voc.post_w").dim(0);
         c->timed(2.0 * nout * Cin * kp, nout * (Cin * es + (pcm16 ? 2.0 : 4.0)), [&] {
             launch_conv_post_tanh(A, dt, Cin, (long)Pmax * mul * Cin, c->pf("voc.post_w"), c->t("voc.post_b").host[0], kp,
-                                  Cin, wav_dev, wav_stride, pcm16, B, Lmel_max * c->hop, P_d, c->hop, mel_len_d, c->hop, c->stream);
+                                  Cin, wav_dev, wav_stride, pcm16, B, nmax, P_d, c->hop, mel_len_d, c->hop, c->stream);
         });
     }
     c->tag = "other";
