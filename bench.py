@@ -48,7 +48,8 @@ def src_sha16():
 def workload_key(args):
     """What a PMC profile must have been taken on to be quoted for this run (profiles/traffic.json carries the same dict)."""
     return {"config": args.config, "decoder": args.decoder, "vocoder": args.vocoder, "precision": args.precision,
-            "batch": args.batch or (50 if args.config == 5 else 32), "phonemes": args.phonemes}
+            "batch": args.batch or (50 if args.config == 5 else 32), "phonemes": args.phonemes,
+            "exact_encoder": bool(getattr(args, "exact_encoder", False))}
 
 
 def exchange_comm_id(rank, world, make_id):
@@ -199,6 +200,7 @@ def main(argv=None, ctx_factory=default_ctx_factory):
     ap.add_argument("--precision", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--pcm16", action="store_true", help="int16 PCM waveform rows (halves the gather payload)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--exact-encoder", action="store_true", help="bf16 mode: phoneme encoder on the exact-f32 MFMA instead of 3-plane bf16 split products (bucket ids / durations bit-equal to the f32 path)")
     ap.add_argument("--host-out", action="store_true", help="config 2: deliver every step's waveform to host memory (D2H copy inside the timed region), as the reference's tts_ex does")
     ap.add_argument("--profile", type=int, default=2, help="0 none, 1 stage events, 2 + per-launch events on the dominant kernel")
     args = ap.parse_args(argv)
@@ -220,6 +222,8 @@ def main(argv=None, ctx_factory=default_ctx_factory):
     ctx, model = ctx_factory(args, local_rank)       # raises when libzvx.so / a GPU is missing: there is no CPU fallback
     cfg = model[0]
     hop, sr = cfg["audio"]["hop_size"], cfg["audio"]["sampling_rate"]
+    if args.exact_encoder:
+        ctx.set_int("enc_split", 0)
     if world > 1:
         ctx.comm_init(exchange_comm_id(rank, world, ctx.comm_unique_id), rank, world)
         flush_c_stdio()                              # RCCL's version banner (C stdio, block-buffered on a pipe) goes out now, not after the JSON line
@@ -255,6 +259,8 @@ def main(argv=None, ctx_factory=default_ctx_factory):
                     + (f", RCCL waveform gather ({'int16' if args.pcm16 else 'f32'}) to rank 0 each step" if world > 1 else ""))
         cfg_extra = {"global_batch": B * world, "phonemes": T, "frames": L, "samples_per_utt": N, "decoder": args.decoder,
                      "vocoder": args.vocoder, "pad_to": int(pad_to[0]), "wav_dtype": "int16" if args.pcm16 else "f32",
+                     "encoder_arithmetic": ("exact f32 MFMA" if (args.exact_encoder or args.precision == "f32") else
+                                            "3-plane bf16 split products (f32-class: 5e-5 on the encoder output; --exact-encoder for bit-equal discrete decisions)"),
                      "wav_delivery": "host (synchronous D2H copy of every step's waveform inside the timed region)" if args.host_out else
                                      "device (rows stay in HBM for the gather / the caller; --host-out times the D2H copy too)"}
     elif args.config == 4:

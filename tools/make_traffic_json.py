@@ -64,6 +64,7 @@ for o, d in (("--config", 2), ("--batch", None), ("--phonemes", 128)):
     ap.add_argument(o, type=int, default=d)
 for o, d in (("--decoder", "styletts"), ("--vocoder", "v1"), ("--precision", "bf16")):
     ap.add_argument(o, default=d)
+ap.add_argument("--exact-encoder", action="store_true")
 bargs, _ = ap.parse_known_args((sys.argv[4] if len(sys.argv) > 4 else "").split())
 json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE on `python bench.py --steps 3 --warmup 1 --no-cpu-baseline " + (sys.argv[4] if len(sys.argv) > 4 else "") + "`",
            "src_sha16": bench.src_sha16(), "workload_key": bench.workload_key(bargs), **res}, open(sys.argv[3], "w"), indent=1)

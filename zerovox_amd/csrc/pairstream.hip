@@ -47,6 +47,9 @@ namespace zvx {
 #ifndef PS_PRIO
 #define PS_PRIO 1         // bit 0 / bit 1: conv2's / conv1's epilogue runs at raised wave priority (it competes with the partner's MFMA stream for issue slots)
 #endif
+#ifndef PS_RES_LDS
+#define PS_RES_LDS 1      // conv2's residual rows come from the X ring (read one step before the block's main loop, while they are still there)
+#endif                    // instead of a second trip to global memory
 #ifndef PS_RPF
 #define PS_RPF 1          // conv2: residual / running-sum rows of a block are requested before its main loop (not in its epilogue)
 #endif
@@ -273,6 +276,23 @@ __device__ __forceinline__ void ps_role(const PairArgs& a, unsigned char* lds, c
         // are dropped), so the whole epilogue is branch-free and every load of the block is in flight before the first use.
         int off[4];
         u32x4 rx[4][2], sx[4][2];
+        // Residual x of conv2 block n = X rows seg0 - 2 H2 + n R ..: in the X ring from the end of step n - 1 until the DMA of step
+        // n + 1 overwrites them, i.e. stable during step n.  They are read THEN (MFMA layout: lane = row, 4-channel quads) and kept in
+        // registers until the block's epilogue at step n + 2: two sets alive (rcur: the pending epilogue's, rnext: the next one's).
+        uint2 rcur[4][4], rnext[4][4];
+        auto residual_reads = [&](int blk) __attribute__((always_inline)) {
+            int lv = lane;
+            asm volatile("" : "+v"(lv));
+            unsigned p0 = (unsigned)((long)blk * R % DX) + H1 - H2 + (lv & 31);
+            p0 = min(p0, p0 - (unsigned)DX);
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                unsigned pj = p0 + 32 * j; pj = min(pj, pj - (unsigned)DX);
+                const unsigned char* row = lds + pj * PS_XP + (lv >> 5) * 8;
+#pragma unroll
+                for (int q = 0; q < 4; q++) rnext[j][q] = *(const uint2*)(row + (((ct * 4 + q) ^ (pj & 15u)) << 4));
+            }
+        };
         auto res_rsrc = [&](const void* base, long bs_) __attribute__((always_inline)) {
             return __builtin_amdgcn_make_buffer_rsrc((void*)((unsigned short*)base + (long)b * bs_), 0, len * a.ldx * 2, 0x00020000);
         };
@@ -285,8 +305,10 @@ __device__ __forceinline__ void ps_role(const PairArgs& a, unsigned char* lds, c
             for (int j = 0; j < 4; j++) {
                 const int g = gb + 32 * j + (lv & 31);
                 off[j] = (g >= seg0 && g < seg_end && !(PS_EXP & 4)) ? (g * a.ldx + cA) * 2 : (int)0x80000000;
-                rx[j][0] = __builtin_amdgcn_raw_buffer_load_b128(rsX, off[j], 0, 0);
-                rx[j][1] = __builtin_amdgcn_raw_buffer_load_b128(rsX, off[j] + 32, 0, 0);
+                if (!PS_RES_LDS) {
+                    rx[j][0] = __builtin_amdgcn_raw_buffer_load_b128(rsX, off[j], 0, 0);
+                    rx[j][1] = __builtin_amdgcn_raw_buffer_load_b128(rsX, off[j] + 32, 0, 0);
+                }
             }
             if (AM & 1) {
 #pragma unroll
@@ -310,6 +332,10 @@ __device__ __forceinline__ void ps_role(const PairArgs& a, unsigned char* lds, c
                 for (int q = 0; q < 4; q++) {
                     v[4 * q] = acc[j][4 * q] + bq[q].x; v[4 * q + 1] = acc[j][4 * q + 1] + bq[q].y;
                     v[4 * q + 2] = acc[j][4 * q + 2] + bq[q].z; v[4 * q + 3] = acc[j][4 * q + 3] + bq[q].w;
+                    if (PS_RES_LDS) {
+                        const f32x2 r01 = inv_lrelu2(unpack_bf16x2(rcur[j][q].x), rinv), r23 = inv_lrelu2(unpack_bf16x2(rcur[j][q].y), rinv);
+                        v[4 * q] += r01.x; v[4 * q + 1] += r01.y; v[4 * q + 2] += r23.x; v[4 * q + 3] += r23.y;
+                    }
                 }
 #pragma unroll
                 for (int pr = 0; pr < 2; pr++) {                                // quad pairs (0,1) -> channels cA .. cA+7, (2,3) -> cA+16 ..
@@ -319,10 +345,12 @@ __device__ __forceinline__ void ps_role(const PairArgs& a, unsigned char* lds, c
                         const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[8 * pr + e]), __float_as_uint(v[8 * pr + 4 + e]), false, false);
                         w8[e] = __uint_as_float(r[0]); w8[4 + e] = __uint_as_float(r[1]);
                     }
-                    const u32x4 rr = rx[j][pr];
                     f32x2 t[4] = {(f32x2){w8[0], w8[1]}, (f32x2){w8[2], w8[3]}, (f32x2){w8[4], w8[5]}, (f32x2){w8[6], w8[7]}};
-                    t[0] += inv_lrelu2(unpack_bf16x2(rr.x), rinv); t[1] += inv_lrelu2(unpack_bf16x2(rr.y), rinv);
-                    t[2] += inv_lrelu2(unpack_bf16x2(rr.z), rinv); t[3] += inv_lrelu2(unpack_bf16x2(rr.w), rinv);
+                    if (!PS_RES_LDS) {
+                        const u32x4 rr = rx[j][pr];
+                        t[0] += inv_lrelu2(unpack_bf16x2(rr.x), rinv); t[1] += inv_lrelu2(unpack_bf16x2(rr.y), rinv);
+                        t[2] += inv_lrelu2(unpack_bf16x2(rr.z), rinv); t[3] += inv_lrelu2(unpack_bf16x2(rr.w), rinv);
+                    }
                     if (AM & 1) {
                         const u32x4 ss = sx[j][pr];
                         t[0] += unpack_bf16x2(ss.x); t[1] += unpack_bf16x2(ss.y); t[2] += unpack_bf16x2(ss.z); t[3] += unpack_bf16x2(ss.w);
@@ -367,6 +395,13 @@ __device__ __forceinline__ void ps_role(const PairArgs& a, unsigned char* lds, c
                     if (PS_PRIO & 1) __builtin_amdgcn_s_setprio(0);
                     g2 += R;
                     PS_STAMP(1);
+                }
+                if (PS_RES_LDS) {
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+#pragma unroll
+                        for (int q = 0; q < 4; q++) rcur[j][q] = rnext[j][q];
+                    residual_reads(s);                                         // block s: its epilogue is two steps away
                 }
                 if (s >= 1 && s <= nb) {
                     if (PS_RPF) epilogue_loads(g2);                            // rows of THIS block: in registers long before its epilogue (next step)

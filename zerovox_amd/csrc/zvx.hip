@@ -88,7 +88,7 @@ struct zvx_ctx {
     int use_flash = 1;                     // zvx_set_int("flash", 0): the decoder's attention as score GEMM + softmax + PV GEMM (A/B)
     int voc_chunk = 0;                     // utterances per vocoder ResBlock sub-batch (0 = whole batch)
     int use_resstream = 1;                 // zvx_set_int("resstream", 0): ResBlocks of the narrow stages as per-pair launches (A/B, bit-equal)
-    int use_pairstream = 2;                // zvx_set_int("pairstream", v): C = 128 ResBlock pairs on pairstream.hip: 2 = k >= 7 (default; k = 3 stays on the register-resident resfuse kernel), 1 = every k, 0 = none, -1 = no fused kernel at all for C = 128 (two conv-slab launches per pair: the bit-equality reference)
+    int use_pairstream = 1;                // zvx_set_int("pairstream", v): C = 128 ResBlock pairs on pairstream.hip: 1 = every k (default), 2 = k >= 7 only (k = 3 on the register-resident resfuse kernel, which adds the running sum after rounding to bf16), 0 = none, -1 = no fused kernel at all for C = 128 (two conv-slab launches per pair: the bit-equality reference)
     int shape_log = 0;                     // zvx_set_int("shape_log", 1): one stderr line per timed launch (profile 2)
     int max_frames = 1 << 18;              // hard cap on a predicted mel length (guards the allocation, fs2.py:678-681 has none)
     hipEvent_t stage_ev[ZVX_T_COUNT][2];
