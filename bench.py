@@ -11,7 +11,7 @@
     synthetic weights.  Weak scaling: every rank synthesises its own shard; each step ends with the ONE collective of the
     path, the waveform gather to rank 0 (RCCL send/recv issued inside libzvx, overlapped with the next step's synthesis).
 --config 4 (configs[3]): HiFi-GAN V1 alone on device-resident 1024-frame N(0,1) mels (seed 7), --batch utterances per step.
---config 5 (configs[4]): ResNetSE34V2 speaker encoder on 1000 device-resident 3 s mels; a step = one batch of 50 clips.
+--config 5 (configs[4]): ResNetSE34V2 speaker encoder on 1000 device-resident 3 s mels; a step = one batch of 250 clips.
 
 Timing: W untimed steps, then exactly K steps bracketed by a barrier + full device drain on both sides; MAX over ranks.
 Rank 0 prints ONE JSON line.  No GPU runtime other than libzvx (and, for N > 1, the system librccl it dlopens) is loaded and
@@ -48,7 +48,7 @@ def src_sha16():
 def workload_key(args):
     """What a PMC profile must have been taken on to be quoted for this run (profiles/traffic.json carries the same dict)."""
     return {"config": args.config, "decoder": args.decoder, "vocoder": args.vocoder, "precision": args.precision,
-            "batch": args.batch or (50 if args.config == 5 else 32), "phonemes": args.phonemes,
+            "batch": args.batch or (250 if args.config == 5 else 32), "phonemes": args.phonemes,
             "exact_encoder": bool(getattr(args, "exact_encoder", False))}
 
 
@@ -193,7 +193,7 @@ def main(argv=None, ctx_factory=default_ctx_factory):
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", type=int, default=2, choices=[2, 4, 5])
-    ap.add_argument("--batch", type=int, default=None, help="units per GPU and step (default: 32 utterances / 50 clips)")
+    ap.add_argument("--batch", type=int, default=None, help="units per GPU and step (default: 32 utterances / 250 clips)")
     ap.add_argument("--phonemes", type=int, default=128)
     ap.add_argument("--decoder", default="styletts", choices=["styletts", "fastspeech2"])
     ap.add_argument("--vocoder", default="v1")
@@ -277,7 +277,7 @@ def main(argv=None, ctx_factory=default_ctx_factory):
         workload = f"HiFi-GAN {args.vocoder.upper()} generator alone: batch={B} x 1024-frame N(0,1) mels (seed 7, device-resident) -> {N} samples each"
         cfg_extra = {"global_batch": B, "frames": P, "samples_per_utt": N, "vocoder": args.vocoder}
     else:
-        B = args.batch or 50
+        B = args.batch or 250
         Tr = 258
         mels = np.random.default_rng(8).standard_normal((B, Tr, 80)).astype(np.float32)
         mel_d = ctx.dev_alloc(mels.nbytes); ctx.dev_from_host(mel_d, mels)
@@ -288,7 +288,7 @@ def main(argv=None, ctx_factory=default_ctx_factory):
         def step():
             ctx.spkemb_device(mel_d, lens, B, Tr, emb_d, no_sync=True)
         workload = (f"ResNetSE34V2 speaker encoder: batches of {B} device-resident 3 s reference mels [258, 80] "
-                    f"({args.steps} steps = {args.steps * B} clips; BASELINE configs[4] = 1000 clips = 20 steps of 50)")
+                    f"({args.steps} steps = {args.steps * B} clips; BASELINE configs[4] = 1000 clips = 4 steps of 250)")
         cfg_extra = {"global_batch": B, "ref_frames": Tr}
 
     def fence():

@@ -574,10 +574,10 @@ void launch_pack_weights(const void* w_bf16, int ntaps, int N, int K, void* out,
                        (unsigned short*)out, nkc, total);
 }
 
-template <int BM, int BN, int WM, int WN, bool FULLK, int MINW, int R, int EPI = -1>
+template <int BM, int BN, int WM, int WN, bool FULLK, int MINW, int R, int EPI = -1, int MAXH = 64>
 __global__ __launch_bounds__(256, MINW) void convslab_kernel(const GemmArgs a) {
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-    constexpr int NIT = ((BM + 64) * 8 + 255) / 256;      // staging iterations (halo <= 64 rows)
+    constexpr int NIT = ((BM + MAXH) * 8 + 255) / 256;    // staging iterations (halo_l + halo_r <= MAXH rows)
     static_assert(WM * WN == 4, "4 waves");
     extern __shared__ __attribute__((aligned(16))) unsigned char slab[];
 
@@ -599,6 +599,18 @@ __global__ __launch_bounds__(256, MINW) void convslab_kernel(const GemmArgs a) {
     const int HL = a.halo_l, SR = BM + a.halo_l + a.halo_r;
     const int nkc = (a.K + SLAB_KC - 1) / SLAB_KC, n16 = a.K >> 4, ntaps = a.ntaps;
     const unsigned short* Xp = (const unsigned short*)a.X + (long)b * a.x_bs;
+    // flattened 2-D maps (MAXH > 64 instantiations): in_len is the utterance's valid WIDTH; which of this thread's slab rows are
+    // valid positions of the map is the same for every K-chunk -> one bit per staging iteration
+    const int in_rows = (MAXH > 64 && a.flat_win) ? a.flat_rows : in_len;
+    unsigned rowmask = 0xffffffffu;
+    if (MAXH > 64 && a.flat_win) {
+        rowmask = 0;
+#pragma unroll
+        for (int it = 0; it < NIT; it++) {
+            const int g = m0 - HL + ((tid + it * 256) >> 3);
+            if (g >= 0 && g < in_rows && (g % a.flat_win) < in_len) rowmask |= 1u << it;
+        }
+    }
 
     f32x16 acc[TN][TM];
 #pragma unroll
@@ -666,22 +678,27 @@ __global__ __launch_bounds__(256, MINW) void convslab_kernel(const GemmArgs a) {
     }
 
     for (int kc = 0; kc < nkc; kc++) {
-        // ---- stage the slab: rows [m0-HL, m0+BM+HR) x 64 channels of chunk kc (all loads in flight, then the stores) ----
+        // ---- stage the slab: rows [m0-HL, m0+BM+HR) x 64 channels of chunk kc (FCH iterations of loads in flight, then their stores) ----
         {
-            uint4 sv[NIT];
+            constexpr int FCH = NIT > 10 ? (NIT + 1) / 2 : NIT;      // wide-halo instantiations: two rounds (register budget)
 #pragma unroll
-            for (int it = 0; it < NIT; it++) {
-                const int c = tid + it * 256;
-                const int row = c >> 3, q = c & 7;
-                const int g = m0 - HL + row, k = kc * SLAB_KC + q * 8;
-                sv[it] = make_uint4(0, 0, 0, 0);
-                if (c < SR * 8 && g >= 0 && g < in_len && k < a.K) sv[it] = *(const uint4*)(Xp + (long)g * a.ldx + k);
-            }
-            if (kc) __syncthreads();              // (after the refill loads are in flight) every wave is done with chunk kc-1's slab
+            for (int h0 = 0; h0 < NIT; h0 += FCH) {
+                uint4 sv[FCH];
 #pragma unroll
-            for (int it = 0; it < NIT; it++) {
-                const int c = tid + it * 256;
-                if (c < SR * 8) *(uint4*)(slab + (c >> 3) * SLAB_PITCH + (c & 7) * 16) = sv[it];
+                for (int i = 0; i < FCH; i++) {
+                    const int it = h0 + i;
+                    const int c = tid + it * 256;
+                    const int row = c >> 3, q = c & 7;
+                    const int g = m0 - HL + row, k = kc * SLAB_KC + q * 8;
+                    sv[i] = make_uint4(0, 0, 0, 0);
+                    if (it < NIT && c < SR * 8 && g >= 0 && g < in_rows && k < a.K && ((rowmask >> it) & 1)) sv[i] = *(const uint4*)(Xp + (long)g * a.ldx + k);
+                }
+                if (kc && h0 == 0) __syncthreads();   // (after the refill loads are in flight) every wave is done with chunk kc-1's slab
+#pragma unroll
+                for (int i = 0; i < FCH; i++) {
+                    const int c = tid + (h0 + i) * 256;
+                    if (h0 + i < NIT && c < SR * 8) *(uint4*)(slab + (c >> 3) * SLAB_PITCH + (c & 7) * 16) = sv[i];
+                }
             }
         }
         __syncthreads();                          // (drains this wave's DMAs too: the chunk's first D steps are in the ring)
@@ -776,13 +793,14 @@ __global__ __launch_bounds__(256, MINW) void convslab_kernel(const GemmArgs a) {
 // packed stream) and the main loop is nothing but ds_read_b128 of the LDS slab + MFMA: no weight traffic,
 // no waits on global memory, no barrier between the slab fill and the epilogue.
 // ================================================================================================
-template <int C, int NT, int BM, int WM, int WN, int MINW>
+template <int C, int NT, int BM, int WM, int WN, int MINW, int MAXH = 64>
 __global__ __launch_bounds__(256, MINW) void convreg_kernel(const GemmArgs a) {
     constexpr int TM = BM / WM / 32;
     constexpr int KS = C / 16;                           // k16 steps per tap
     constexpr int PITCH_ = C * 2 + 16;                   // LDS row pitch (80 B / 144 B: conflict-free b128 reads)
     constexpr int CPR = C / 8;                           // 16-byte chunks per row
-    constexpr int NIT = ((BM + 64) * CPR + 255) / 256;
+    constexpr int NIT = ((BM + MAXH) * CPR + 255) / 256;
+    constexpr int FCH = NIT > 12 ? 8 : NIT;              // staging iterations in flight at a time (register budget next to the weights)
     static_assert(WM * WN == 4 && WN * 32 == C, "wave layout");
     extern __shared__ __attribute__((aligned(16))) unsigned char slab[];
 
@@ -809,21 +827,27 @@ __global__ __launch_bounds__(256, MINW) void convreg_kernel(const GemmArgs a) {
 #pragma unroll
             for (int kk = 0; kk < KS; kk++) w[t][kk] = Wq[(t * 4 + kk) * 64];
     }
-    // ---- slab: rows [m0-HL, m0+BM+HR) x C channels, all loads in flight, then the LDS stores ----
+    // ---- slab: rows [m0-HL, m0+BM+HR) x C channels, FCH iterations of loads in flight, then their LDS stores ----
+    // (flattened 2-D maps: in_len is the valid WIDTH; a row is a position of the map iff its column g % flat_win is inside it)
     {
-        uint4 sv[NIT];
+        const bool flat = MAXH > 64 && a.flat_win;
+        const int in_rows = flat ? a.flat_rows : in_len;
 #pragma unroll
-        for (int it = 0; it < NIT; it++) {
-            const int c = tid + it * 256;
-            const int row = c / CPR, q = c % CPR;
-            const int g = m0 - HL + row;
-            sv[it] = make_uint4(0, 0, 0, 0);
-            if (c < SR * CPR && g >= 0 && g < in_len) sv[it] = *(const uint4*)(Xp + (long)g * a.ldx + q * 8);
-        }
+        for (int h0 = 0; h0 < NIT; h0 += FCH) {
+            uint4 sv[FCH];
 #pragma unroll
-        for (int it = 0; it < NIT; it++) {
-            const int c = tid + it * 256;
-            if (c < SR * CPR) *(uint4*)(slab + (c / CPR) * PITCH_ + (c % CPR) * 16) = sv[it];
+            for (int i = 0; i < FCH; i++) {
+                const int c = tid + (h0 + i) * 256;
+                const int row = c / CPR, q = c % CPR;
+                const int g = m0 - HL + row;
+                sv[i] = make_uint4(0, 0, 0, 0);
+                if (h0 + i < NIT && c < SR * CPR && g >= 0 && g < in_rows && (!flat || (g % a.flat_win) < in_len)) sv[i] = *(const uint4*)(Xp + (long)g * a.ldx + q * 8);
+            }
+#pragma unroll
+            for (int i = 0; i < FCH; i++) {
+                const int c = tid + (h0 + i) * 256;
+                if (h0 + i < NIT && c < SR * CPR) *(uint4*)(slab + (c / CPR) * PITCH_ + (c % CPR) * 16) = sv[i];
+            }
         }
     }
     __syncthreads();
@@ -857,6 +881,14 @@ static bool launch_convreg_c(const GemmArgs& a, hipStream_t stream) {
     size_t lds = (size_t)(BM + a.halo_l + a.halo_r) * (C * 2 + 16);
     const size_t stage = (size_t)4 * 32 * (32 * 4 + 16);
     if (lds < stage) lds = stage;
+    if (a.flat_win) {                                     // 3 x 3 over a flattened map: halo = flat_win + 1 rows either side
+        if (a.ntaps != 9 || a.halo_l + a.halo_r > 544 || lds > 160 * 1024) return false;
+        auto kfn = convreg_kernel<C, 9, BM, WM, WN, MINW, 544>;
+        static bool attr_done = false;
+        if (!attr_done) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_done = true; }
+        ZVX_LAUNCH(kfn, grid, dim3(256), lds, stream, a);
+        return true;
+    }
     switch (a.ntaps) {
         case 3: ZVX_LAUNCH((convreg_kernel<C, 3, BM, WM, WN, MINW>), grid, dim3(256), lds, stream, a); return true;
         case 7: ZVX_LAUNCH((convreg_kernel<C, 7, BM, WM, WN, MINW>), grid, dim3(256), lds, stream, a); return true;
@@ -1448,6 +1480,17 @@ static int launch_convslab(GemmArgs a, hipStream_t stream) {
     int hl = 0, hr = 0;
     for (int i = 0; i < a.ntaps; i++) { hl = a.dv[i] < -hl ? -a.dv[i] : hl; hr = a.dv[i] > hr ? a.dv[i] : hr; }
     a.halo_l = hl; a.halo_r = hr;
+    if (a.flat_win) {
+        // stride-1 3 x 3 convolution over flattened [H][W] maps (ResNetSE34V2.py:74-76): weights in registers for C = 32 / 64, the
+        // 256 x 128 register-ring tile with a 160-row halo budget for C = 128 / 256
+        if (a.N == a.K && a.N == 32 && launch_convreg_c<32, 384, 4, 1, 2>(a, stream)) return 14;      // 384 rows: 2.35x halo over-read instead of 3x, two workgroups per CU still fit
+        if (a.N == a.K && a.N == 64 && launch_convreg_c<64, 256, 2, 2, 2>(a, stream)) return 15;
+        if (a.N % 128 || a.K % SLAB_KC || hl + hr > 160) return -4;
+        dim3 grid((a.N / 128) * ((a.M + 255) / 256), a.nbatch);
+        size_t lds = ((size_t)(256 + hl + hr) * SLAB_PITCH + 1023) & ~(size_t)1023;
+        ZVX_LAUNCH((convslab_kernel<256, 128, 2, 2, true, 2, 0, -1, 160>), grid, dim3(256), lds, stream, a);
+        return 7;
+    }
     if (a.N == a.K && (a.ntaps == 3 || a.ntaps == 7 || a.ntaps == 11)) {
         if (a.N == 32 && launch_convreg_c<32, 512, 4, 1, 2>(a, stream)) return 14;
         if (a.N == 64 && launch_convreg_c<64, 256, 2, 2, 2>(a, stream)) return 15;
@@ -1530,6 +1573,22 @@ int launch_gemm(const GemmArgs& a, hipStream_t stream) {
     if (a.ntaps < 1 || a.ntaps > ZVX_MAX_TAPS) return -2;
     // N not a multiple of 4: the last 4-wide store spills into [N, roundup4(N)) of the row (ldo must cover it)
     if (a.N % 4 && (a.bias_mode == 1 || a.res_mode || a.accum_mode || a.post_scale || a.ldo < ((a.N + 3) & ~3))) return -2;
+    if (a.Wp && a.dtype == DT_BF16 && a.wout > 0 && a.stride == 1 && a.ntaps == 9 && a.wout == a.win && a.M == a.hin * a.win && a.nheads == 1 && a.w_bs == 0 &&
+        !a.k_len && a.K % 16 == 0 && a.N % 32 == 0 && a.ldo % 8 == 0 && a.ldx == a.K && !a.res_mode && !a.accum_mode && a.bias_mode != 2 && a.win <= 271) {
+        // 3 x 3 / stride 1 / pad 1 over [hin][win] maps whose LAST column is never a valid position (win = widest utterance + 1, see
+        // run_spkemb): as a 9-tap 1-D convolution over the flattened map.  Columns beyond an utterance's width are masked on the
+        // way into LDS, so the output's invalid columns hold finite junk that every consumer masks the same way.
+        bool ok9 = true;
+        for (int t = 0; t < 9; t++) ok9 = ok9 && a.du[t] == t / 3 - 1 && a.dv[t] == t % 3 - 1;
+        if (ok9 && (a.N == a.K ? (a.N == 32 || a.N == 64 || (a.N % 128 == 0 && 2 * (a.win + 1) <= 160)) : false)) {
+            GemmArgs f = a;
+            f.flat_win = a.win; f.flat_rows = a.hin * a.win;
+            for (int t = 0; t < 9; t++) { f.dv[t] = a.du[t] * a.win + a.dv[t]; f.du[t] = 0; }
+            f.wout = 0; f.out_len = nullptr;               // every row of the flattened map is written
+            const int id = launch_convslab(f, stream);
+            if (id >= 0) return id;
+        }
+    }
     if (a.Wp && a.dtype == DT_BF16 && a.wout <= 0 && a.nheads == 1 && a.w_bs == 0 && !a.k_len && a.K % 16 == 0 && a.N % 8 == 0 && a.ldo % 8 == 0) {
         int lo = 0, hi = 0;
         for (int i = 0; i < a.ntaps; i++) { if (a.dv[i] < lo) lo = a.dv[i]; if (a.dv[i] > hi) hi = a.dv[i]; }

@@ -517,7 +517,7 @@ void launch_conv_post_tanh(const void* x, int x_dt, int ldx, long x_bs, const fl
 // first layer: InstanceNorm1d(F) over time folded in (mean/rstd given) + Conv2d(1->C0,3x3,p1) + ReLU + BN affine
 // one thread = one (f, t) position x 8 output channels (a 16-byte bf16 store; the C0/8 threads of a position write one contiguous row)
 __global__ __launch_bounds__(256) void k_spk_front(const float* mels, int Tmax, const int* lens, int F, const float* mean, const float* rstd,
-                            const float* w, const float* bias, const float* bs, const float* bt, int C0, void* out, int odt) {
+                            const float* w, const float* bias, const float* bs, const float* bt, int C0, void* out, int odt, int Wout) {
     const int b = blockIdx.z, f = blockIdx.y, cpp = C0 >> 3;
     const int id = blockIdx.x * blockDim.x + threadIdx.x, t = id / cpp, c0 = (id % cpp) * 8;
     const int Tb = lens[b];
@@ -533,7 +533,7 @@ __global__ __launch_bounds__(256) void k_spk_front(const float* mels, int Tmax, 
                 v = (mels[((long)b * Tmax + tt) * F + ff] - mean[b * F + ff]) * rstd[b * F + ff];
             xn[i * 3 + j] = v;
         }
-    const long o = (((long)b * F + f) * Tmax + t) * C0 + c0;
+    const long o = (((long)b * F + f) * Wout + t) * C0 + c0;      // output map rows are Wout >= Tmax positions wide
     float r[8];
 #pragma unroll
     for (int e = 0; e < 8; e++) {
@@ -555,10 +555,10 @@ __global__ __launch_bounds__(256) void k_spk_front(const float* mels, int Tmax, 
 }
 void launch_spk_front(const float* mels, int Tmax, const int* lens, int F, const float* mean, const float* rstd,
                       const float* w, const float* bias, const float* bn_scale, const float* bn_shift, int C0,
-                      void* out, int o_dt, int B, hipStream_t s) {
+                      void* out, int o_dt, int B, int Wout, hipStream_t s) {
     const int threads = Tmax * (C0 >> 3);                     // C0 % 8 == 0
     hipLaunchKernelGGL(k_spk_front, dim3((threads + 255) / 256, F, B), dim3(256), 0, s, mels, Tmax, lens, F, mean, rstd, w, bias,
-                       bn_scale, bn_shift, C0, out, o_dt);
+                       bn_scale, bn_shift, C0, out, o_dt, Wout);
 }
 
 __global__ void k_se_fc(const float* partial, int S, int H, const int* W, const float* w1, const float* b1, const float* w2, const float* b2, int C, int Cr, float* scale) {

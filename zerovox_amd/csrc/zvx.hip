@@ -1024,12 +1024,16 @@ void run_spkemb(zvx_ctx* c, const float* ref_mels, const int32_t* lens, int B, i
     int Wmax[4] = {Tmax, 0, 0, 0};
     for (int b = 0; b < B; b++) { int w = lens[b]; for (int l = 0; l < 4; l++) { W[(size_t)l * B + b] = w; w = (w - 1) / 2 + 1; } }
     for (int l = 1; l < 4; l++) Wmax[l] = (Wmax[l - 1] - 1) / 2 + 1;
+    // Map rows are stored one position wider than the widest utterance: that last column is never a valid position, so a
+    // stride-1 3 x 3 convolution may run over the FLATTENED map (the neighbour of a row's last position is masked, not the next
+    // row's first) -- see launch_gemm.  Every consumer masks columns >= W[b] on the way in.
+    int WS[4]; for (int l = 0; l < 4; l++) WS[l] = Wmax[l] + 1;
     int Fh[4]; Fh[0] = F0; for (int l = 1; l < 4; l++) Fh[l] = (Fh[l - 1] - 1) / 2 + 1;
     int* W_d = c->upload_ints("spk.W", W.data(), W.size());
 
     const int C0 = c->rn_filters[0];
     size_t maxel = 0;
-    for (int l = 0; l < 4; l++) maxel = std::max(maxel, (size_t)B * Fh[l] * Wmax[l] * c->rn_filters[l]);
+    for (int l = 0; l < 4; l++) maxel = std::max(maxel, (size_t)B * Fh[l] * WS[l] * c->rn_filters[l]);
     void* mA = c->buf("spk.mA", maxel * es); void* mB = c->buf("spk.mB", maxel * es);
     void* mC = c->buf("spk.mC", maxel * es); void* mD = c->buf("spk.mD", maxel * es);
     float* mean = c->fbuf("spk.mean", (size_t)B * 256 * 16); float* rstd = c->fbuf("spk.rstd", (size_t)B * 256 * 16);
@@ -1038,7 +1042,7 @@ void run_spkemb(zvx_ctx* c, const float* ref_mels, const int32_t* lens, int B, i
     // InstanceNorm1d over time (no affine) folded into the first conv          ResNetSE34V2.py:182-186
     launch_instnorm_stats(mels_d, DT_F32, F0, B, Tmax, W_d, F0, 1e-5f, mean, rstd, c->stream);
     launch_spk_front(mels_d, Tmax, W_d, F0, mean, rstd, c->pf("spk.c1_w"), c->pf("spk.c1_b"), c->pf("spk.bn1_s"), c->pf("spk.bn1_t"), C0,
-                     mA, dt, B, c->stream);
+                     mA, dt, B, WS[0], c->stream);
     void* x = mA; void* o1 = mB; void* o2 = mC; void* rs = mD;
     int lvl = 0, Cin = C0;
     for (size_t li = 0; li < c->rn_layers.size(); li++) {
@@ -1047,7 +1051,7 @@ void run_spkemb(zvx_ctx* c, const float* ref_mels, const int32_t* lens, int B, i
             const std::string p = "spk.l" + std::to_string(li + 1) + "." + std::to_string(bi);
             const int stride = (li > 0 && bi == 0) ? 2 : 1;
             const int lin = lvl, lout = (stride == 2) ? lvl + 1 : lvl;
-            const int Hin = Fh[lin], Win = Wmax[lin], Hout = Fh[lout], Wout = Wmax[lout];
+            const int Hin = Fh[lin], Win = WS[lin], Hout = Fh[lout], Wout = WS[lout];
             const int* win_d = W_d + (size_t)lin * B; const int* wout_d = W_d + (size_t)lout * B;
             auto conv3 = [&](const std::string& wn, const void* in, int cin, int hin, int win, const int* inlen, int st, void* out,
                              const float* bias, int act, const float* ps, const float* pt, int ksz) {
@@ -1082,7 +1086,7 @@ void run_spkemb(zvx_ctx* c, const float* ref_mels, const int32_t* lens, int B, i
         }
     }
     // attention + ASP pooling                                               ResNetSE34V2.py:195-205
-    const int Fp = Fh[3], Wp = Wmax[3], C4 = c->rn_filters[3], D = Fp * C4;
+    const int Fp = Fh[3], Wp = WS[3], C4 = c->rn_filters[3], D = Fp * C4;
     const int* w3_d = W_d + (size_t)3 * B;
     void* ah = c->buf("spk.ah", (size_t)B * Wp * 128 * es);
     float* logits = c->fbuf("spk.logits", (size_t)B * Wp * D);

@@ -47,6 +47,10 @@ struct GemmArgs {
     // row map
     int ntaps; int du[ZVX_MAX_TAPS], dv[ZVX_MAX_TAPS];   // int (not short): uniform-indexed kernarg reads become s_load
     int stride, wout, hin, win; // wout <= 0 -> 1-D (u = 0, v = r)
+    // Filled by launch_gemm when a stride-1 2-D convolution over [hin][win] maps is run on the 1-D conv-slab / conv-reg kernels as a
+    // convolution over the FLATTENED map (tap offset du * win + dv): input row g is valid iff 0 <= g < flat_rows and
+    // (g % flat_win) < in_len[z] (the columns of an utterance's true width); every output row of the map is written
+    int flat_win, flat_rows;
     // epilogue: v = alpha*acc + bias; v += res; v += accum; [accum = v]; v *= out_scale; v = act(v);
     //           v = v*post_scale[n] + post_shift[n]; out = (T)v
     float alpha;
@@ -209,10 +213,10 @@ void launch_conv_post_tanh(const void* x, int x_dt, int ldx, long x_bs, const fl
 void launch_zero_tail_rows(float* x, int ldx, int B, int rows_max, const int* rows, int C, hipStream_t s);
 
 // ---- speaker encoder ----
-// InstanceNorm1d(80) over time + Conv2d(1->C0, 3x3, pad 1) + ReLU + BN affine -> map [b][F][Tmax][C0]
+// InstanceNorm1d(80) over time + Conv2d(1->C0, 3x3, pad 1) + ReLU + BN affine -> map [b][F][Wout][C0] (Wout >= Tmax)
 void launch_spk_front(const float* mels, int Tmax, const int* lens, int F, const float* mean, const float* rstd,
                       const float* w /*[9][C0]*/, const float* bias, const float* bn_scale, const float* bn_shift,
-                      int C0, void* out, int o_dt, int B, hipStream_t s);
+                      int C0, void* out, int o_dt, int B, int Wout, hipStream_t s);
 // SE global average pool, first half: partial[b][s][c] = sum over the s-th of S = se_pool_splits(H, Wmax) row blocks of the
 // valid (f, t) positions of map [b][H][Wmax][C]   (C % 8 == 0, C <= 256)
 int se_pool_splits(int H, int Wmax);
