@@ -139,6 +139,40 @@ def spawn_ranks(n, argv):
     return rc
 
 
+class SmiClockSampler:
+    """Mean current gfx clock (all XCDs) from `amd-smi metric -c`, sampled from a side thread while the timed region runs: the
+    clock the roofline's achieved figure was delivered at (the 2.5 PFLOP/s peak assumes 2.4 GHz).  Host-side only; absent tool or
+    a region shorter than one sample -> no field."""
+
+    def __init__(self, gpu):
+        import threading
+        self.gpu, self.samples, self.stop = gpu, [], False
+        self.th = threading.Thread(target=self._run, daemon=True)
+
+    def _run(self):
+        import subprocess
+        while not self.stop:
+            try:
+                out = subprocess.run(["amd-smi", "metric", "-g", str(self.gpu), "-c", "--json"], capture_output=True, text=True, timeout=10).stdout
+                d = json.loads(out)
+                d = d.get("gpu_data", d) if isinstance(d, dict) else d
+                clk = d[0]["clock"]
+                v = [c["clk"]["value"] for k, c in clk.items() if k.startswith("gfx_") and isinstance(c.get("clk"), dict) and isinstance(c["clk"].get("value"), (int, float))]
+                if v and not self.stop:
+                    self.samples.append(sum(v) / len(v))
+            except Exception:
+                return
+            time.sleep(0.1)
+
+    def __enter__(self):
+        self.th.start()
+        return self
+
+    def __exit__(self, *a):
+        self.stop = True
+        self.th.join(timeout=15)
+
+
 def flush_c_stdio():
     import ctypes
     ctypes.CDLL(None).fflush(None)
@@ -313,11 +347,16 @@ def main(argv=None, ctx_factory=default_ctx_factory):
     ctx.set_int("profile", args.profile)
     ctx.reset_stats()
     fence()
+    smi = SmiClockSampler(local_rank) if rank == 0 else None
+    if smi:
+        smi.__enter__()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     fence()
     elapsed = time.perf_counter() - t0
+    if smi:
+        smi.__exit__()
     stage_ms = ctx.stage_times()
     kstats = ctx.kernel_stats()
     ctx.set_int("profile", 0)
@@ -388,7 +427,10 @@ def main(argv=None, ctx_factory=default_ctx_factory):
                                "alg_GBps": dom["bytes"] / (dom["ms"] * 1e-3) / 1e9}
             if traffic_note:
                 res["roofline"]["traffic_note"] = traffic_note
-            if pmc.get("eff_clock_GHz"):
+            if smi and smi.samples:
+                res["roofline"]["smi_gfx_clock_GHz"] = round(sum(smi.samples) / len(smi.samples) / 1e3, 3)      # amd-smi, during the timed region
+                res["roofline"]["smi_clock_samples"] = len(smi.samples)
+            if pmc.get("eff_clock_GHz") and pmc["eff_clock_GHz"] <= 2.4:   # GRBM_GUI_ACTIVE / duration over-counts on sub-100-us launches: only a physical value is quoted
                 # the same profile's GRBM_GUI_ACTIVE / kernel time and MFMA busy cycles: `peak` above is the 2.4 GHz figure, the
                 # chip sustains less under this load (power budget), and `mfma_busy_frac` is the share of THOSE cycles the pipe works
                 res["roofline"]["profiled_clock_GHz"] = round(pmc["eff_clock_GHz"], 3)

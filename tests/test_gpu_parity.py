@@ -640,13 +640,15 @@ def test_streaming_pair_kernel_equals_two_conv_slab_launches():
     ctx = ctx_for("styletts", "v1", "bf16")
     rng = np.random.default_rng(37)
     try:
-        for B, Pmax in ((3, 23), (2, 300), (1, 1), (40, 33), (1, 1100), (5, 70)):
+        for B, Pmax in ((3, 23), (2, 300), (1, 1), (40, 33), (1, 1100), (5, 70), (9, 420)):
             P = rng.integers(1, Pmax + 1, B).astype(np.int32); P[0] = Pmax
             mel = np.zeros((B, Pmax, 80), np.float32)
             for b in range(B):
                 mel[b, :P[b]] = rng.standard_normal((P[b], 80)).astype(np.float32)
             ctx.set_int("pairstream", -1); ref = ctx.vocode_mel(mel, P)       # no fused kernel at all for C = 128
-            ctx.set_int("pairstream", 1); got = ctx.vocode_mel(mel, P)        # every pair of the C = 128 stage streamed
+            ctx.set_int("pairstream", 3); got = ctx.vocode_mel(mel, P)        # every pair of the C = 128 stage streamed, whatever the job size
+            assert np.isfinite(got).all() and np.array_equal(got, ref), (B, Pmax)
+            ctx.set_int("pairstream", 1); got = ctx.vocode_mel(mel, P)        # default: streamed from ~200 k rows up ((9, 420) is), two launches below
             assert np.isfinite(got).all() and np.array_equal(got, ref), (B, Pmax)
             ctx.set_int("pairstream", 2); alt = ctx.vocode_mel(mel, P)        # k = 3 on the register-resident kernel (running sum added after bf16 rounding)
             assert np.isfinite(alt).all() and np.abs(alt - ref).max() < 2e-2, (B, Pmax)

@@ -1402,7 +1402,7 @@ int launch_resfuse(GemmArgs a, hipStream_t stream) {
     if (h1 > 32) return -1;
     a.halo_l = a.halo_r = h1;
     a.fused = 1;
-    if (a.N == 128 && !a.no_pairstream) {
+    if (a.N == 128 && a.no_pairstream != 1) {
         // C = 128: the streaming pair kernel (pairstream.hip); its epilogue covers exactly what the vocoder asks for
         const int h2 = (a.ntaps - 1) / 2, dil = a.dv1[1] - a.dv1[0];
         bool ok = a.alpha == 1.f && a.bias_mode == 1 && !a.post_scale && (!a.out || a.out_dtype == DT_BF16) && a.res_mode == 2 && a.res_dtype == DT_BF16 &&
@@ -1417,7 +1417,7 @@ int launch_resfuse(GemmArgs a, hipStream_t stream) {
             p.out = a.out; p.o_bs = a.o_bs; p.ldo = a.ldo;
             p.accum = a.accum; p.a_bs = a.a_bs; p.lda = a.lda; p.accum_mode = a.accum ? a.accum_mode : 0;
             p.slope1 = a.slope1; p.res_inv_slope = a.res_inv_slope; p.out_scale = a.out_scale; p.slope = a.act == ACT_LRELU ? a.slope : 1.f;
-            p.len = a.out_len; p.M = a.M; p.nbatch = a.nbatch;
+            p.len = a.out_len; p.M = a.M; p.nbatch = a.nbatch; p.force = a.no_pairstream == 2;
             if (launch_pairstream(p, stream, g_dry_run, g_dry_run ? nullptr : g_ev_start, g_ev_stop)) return 23;
         }
     }

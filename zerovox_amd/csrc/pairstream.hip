@@ -458,6 +458,9 @@ bool launch_pairstream(PairArgs a, hipStream_t stream, bool dry_run, hipEvent_t 
     if (lds > 160 * 1024 || 4 * PS_NDMA * 4 != PS_R) return false;
     const long rows_all = (long)a.M * a.nbatch;
     const int nwg = ps_ncu();
+    // small jobs (one or two utterances): 1024-row segments would leave most CUs without a workgroup and every workgroup with a
+    // pipeline fill per handful of steps -- measured crossover against the two conv-slab launches at ~3 utterances of 896 frames
+    if (rows_all < (long)nwg * 768 && !a.force) return false;
     int S = (int)((rows_all + nwg - 1) / nwg);
     if (S < 1024) S = 1024;
     S = (S + PS_R - 1) / PS_R * PS_R;

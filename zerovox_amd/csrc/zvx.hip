@@ -88,7 +88,7 @@ struct zvx_ctx {
     int use_flash = 1;                     // zvx_set_int("flash", 0): the decoder's attention as score GEMM + softmax + PV GEMM (A/B)
     int voc_chunk = 0;                     // utterances per vocoder ResBlock sub-batch (0 = whole batch)
     int use_resstream = 1;                 // zvx_set_int("resstream", 0): ResBlocks of the narrow stages as per-pair launches (A/B, bit-equal)
-    int use_pairstream = 1;                // zvx_set_int("pairstream", v): C = 128 ResBlock pairs on pairstream.hip: 1 = every k (default), 2 = k >= 7 only (k = 3 on the register-resident resfuse kernel, which adds the running sum after rounding to bf16), 0 = none, -1 = no fused kernel at all for C = 128 (two conv-slab launches per pair: the bit-equality reference)
+    int use_pairstream = 1;                // zvx_set_int("pairstream", v): C = 128 ResBlock pairs on pairstream.hip: 1 = every k (default; jobs under ~200 k rows run the bit-identical two-launch path), 3 = every k and every job size (tests), 2 = k >= 7 only (k = 3 on the register-resident resfuse kernel, which adds the running sum after rounding to bf16), 0 = none, -1 = no fused kernel at all for C = 128 (two conv-slab launches per pair: the bit-equality reference)
     int shape_log = 0;                     // zvx_set_int("shape_log", 1): one stderr line per timed launch (profile 2)
     int max_frames = 1 << 18;              // hard cap on a predicted mel length (guards the allocation, fs2.py:678-681 has none)
     hipEvent_t stage_ev[ZVX_T_COUNT][2];
@@ -953,14 +953,19 @@ void run_vocoder(zvx_ctx* c, const float* mel, int ldm, int Lmel_max, const int*
                             // one launch: xt = lrelu(c1(x_act)+b1) stays in LDS; x' = c2(xt) + b2 + x      hifigan.py:51-55
                             a.X = cur; a.W = w2.dev; a.Wp = c->packed[w2.dev]; a.Wp2 = c->packed[w1.dev];
                             a.bias1 = c->pf(rb + ".c1_" + ts + "_b"); a.slope1 = 0.1f; a.fused = 1;
-                            a.no_pairstream = c->use_pairstream <= 0 || (c->use_pairstream == 2 && k == 3);
+                            a.no_pairstream = (c->use_pairstream <= 0 || (c->use_pairstream == 2 && k == 3)) ? 1 : (c->use_pairstream == 3 ? 2 : 0);
                             set_taps_1d(a, k, 1);
                             for (int q = 0; q < k; q++) a.dv1[q] = (q - (k - 1) / 2) * dil[t];
                             a.bias = c->pf(rb + ".c2_" + ts + "_b");
                             a.flops = 2.0 * 2.0 * Bs * (double)rows * Cout * Cout * k;
                             rb_tail(a);
                             // the fused kernels cover a subset of (C, k, dilation, LDS footprint): ask the launcher (dry run) first
-                            fuse = gemm_variant_of(a) >= 0 && !(c->use_pairstream < 0 && Cout == 128);
+                            const int fv = gemm_variant_of(a);
+                            fuse = fv >= 0 && !(c->use_pairstream < 0 && Cout == 128);
+                            // C = 128 with the pair kernel as the default: where it declines (small jobs), run the two conv-slab launches it
+                            // is bit-identical to, not the register-resident pair kernel (k = 3), whose running-sum rounding differs --
+                            // an utterance must come out the same alone and inside a large batch
+                            if ((c->use_pairstream == 1 || c->use_pairstream == 3) && Cout == 128 && fv != 23) fuse = false;
                         }
                         if (!fuse) {
                             // xt = c1(lrelu(x)); stored as lrelu(xt)                       hifigan.py:51-53

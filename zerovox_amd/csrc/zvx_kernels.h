@@ -36,7 +36,7 @@ struct GemmArgs {
     int halo_l, halo_r;        // filled by the launcher
     // fused ResBlock1 pair (resfuse kernel): out = epilogue(conv2(lrelu(conv1(X) + bias1)) + bias + inverse_lrelu(X))
     const void* Wp2; const float* bias1; int dv1[ZVX_MAX_TAPS]; int fused; float slope1;   // conv1: Wp2/bias1/dv1 (dilated); conv2: Wp/bias/dv
-    int no_pairstream;         // fused: 1 = never the streaming pair kernel of pairstream.hip (A/B switch)
+    int no_pairstream;         // fused: 1 = never the streaming pair kernel of pairstream.hip (A/B switch), 2 = use it even for small jobs (tests)
     int dtype;                 // DType of X and W (same)
     int M, N, K;               // M = max rows per z, N cols, K per tap (multiple of 8 elements bf16 / 4 f32)
     int nbatch, nheads;
@@ -120,6 +120,7 @@ struct PairArgs {
     void* accum; long a_bs; int lda; int accum_mode;   // bf16 running sum xs: bit0 v += xs, bit1 xs = v
     float slope1, res_inv_slope, out_scale, slope; // slope 1 = no output activation
     const int* len; int M, nbatch;
+    int force;                                     // 1: also for jobs below the size where the kernel pays (tests)
     int S, nseg, DX, DT, G0;                       // filled by the launcher: segment rows, segments per utterance, ring rows
     long long* prof;                               // PS_PROFILE builds: [8 waves][main, epilogue, barrier, -] cycle totals of workgroup 0
 };
