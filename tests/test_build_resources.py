@@ -34,5 +34,5 @@ def test_streaming_kernels_stay_within_their_wave_budget(resources):
     rs = {k: v for k, v in resources.items() if "resstream_kernel" in k}
     assert len(rs) >= 8
     for k, v in rs.items():
-        assert v.get("vgpr_spill", 0) <= 8 and v.get("scratch", 0) <= 64, (k, v)        # two 8-wave variants park 2 / 4 registers
+        assert v.get("vgpr_spill", 0) == 0 and v.get("scratch", 0) == 0, (k, v)
         assert v["occupancy"] >= 2, (k, v)                                                # 8 and 12 waves per workgroup need 2 resp. 3 per SIMD

@@ -33,16 +33,58 @@ void resstream_profile_events(hipEvent_t start, hipEvent_t stop) { g_rs_ev_start
 #define RS_RD 64          // rows per DMA block
 #define RS_PF 2           // DMA blocks are requested this many steps before role 0 needs them
 
-// wave -> (role, sub): waves w, w+4, w+8 share a SIMD; the tables give every SIMD a mix of conv1- and conv2-kind roles
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
+}
+
+// The MFMA chain of one block with compile-time operand addressing: fragment i = (tap i / KS, k16 slot i % KS) is read from
+// `base` + an immediate, PD reads ahead of its MFMA (counted lgkmcnt waits; LDS operations complete in order).
+template <int I, int PD, int KS, int DIL, int P>
+__device__ __forceinline__ void rs_read(uint4 (&xf)[PD + 1], unsigned base) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(xf[I % (PD + 1)]) : "v"(base), "n"((I / KS) * DIL * P + (I % KS) * 32));
+}
+template <int I, int PD, int KS, int DIL, int P>
+__device__ __forceinline__ void rs_prefetch(uint4 (&xf)[PD + 1], unsigned base) {
+    if constexpr (I < PD) { rs_read<I, PD, KS, DIL, P>(xf, base); rs_prefetch<I + 1, PD, KS, DIL, P>(xf, base); }
+}
+template <int I, int NW, int PD, int KS, int DIL, int P>
+__device__ __forceinline__ void rs_mma_steps(uint4 (&xf)[PD + 1], const uint4 (&w)[NW], unsigned base, f32x16& acc) {
+    if constexpr (I < NW) {
+        if constexpr (I + PD < NW) rs_read<I + PD, PD, KS, DIL, P>(xf, base);
+        asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(NW - 1 - I >= PD ? PD : NW - 1 - I) : "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w[I]), __builtin_bit_cast(bf16x8, xf[I % (PD + 1)]), acc, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        rs_mma_steps<I + 1, NW, PD, KS, DIL, P>(xf, w, base, acc);
+    }
+}
+
+// wave -> (role, sub): waves w, w+4, w+8 share a SIMD; the tables give every SIMD a mix of conv1- and conv2-kind roles.
+// 12 waves: the conv2 roles carry the long epilogues (residual + two activations) and the last one also the HBM store phase,
+// so SIMDs 0 / 2 get {conv2_0, conv2_1, conv1_0 (+ DMA issue)} and SIMDs 1 / 3 get {conv2_2 (+ stores), conv1_1, conv1_2}.
 template <int NR, int WPR>
-__device__ __forceinline__ void role_of_wave(int w, int& role, int& sub) {
-    if (NR == 6 && WPR == 2) { role = (int)((0x452301453210ull >> (4 * w)) & 15); sub = w >= 6; }
+__device__ __forceinline__ void role_of_wave(int w, int& role, int& sub, bool balanced) {
+    if (NR == 6 && WPR == 2 && balanced) { role = (int)((0x404023235151ull >> (4 * w)) & 15); sub = (w >> 1) & 1; }
+    else if (NR == 6 && WPR == 2) { role = (int)((0x452301453210ull >> (4 * w)) & 15); sub = w >= 6; }
     else if (NR == 4 && WPR == 2) { role = (int)((0x23013210u >> (4 * w)) & 15); sub = w >= 4; }
     else if (NR == 2 && WPR == 4) { role = (int)((0x01011010u >> (4 * w)) & 15); sub = w >> 1; }
     else { role = w % NR; sub = w / NR; }
 }
 
-template <int C, int NT, int NPAIR, int RSPLIT, int AM, bool HAS_OUT>
+// Issue priority of a wave (s_setprio).  After the step barrier every wave of a SIMD starts its MFMA chain at once; with equal
+// priorities the chains interleave, all finish together and the epilogues (VALU) then run with the matrix pipe idle.  With
+// distinct priorities the chains run one after the other and the epilogue of an earlier wave overlaps the MFMAs of the next;
+// the waves with the long epilogue (conv2: residual + two activations) go first.
+template <int NR, int WPR>
+__device__ __forceinline__ int prio_of_wave(int w, bool balanced) {
+    if (NR == 6 && WPR == 2) return balanced ? 3 - (w >> 2) : (int)((0x122223133131ull >> (4 * w)) & 15);
+    return w < 4 ? 2 : 1;
+}
+
+// DP: the dilations of the conv1 roles, one hex digit per pair (0x531 = 1, 3, 5): with the dilation a compile-time constant the
+// row offset of every tap is an immediate of its ds_read_b128 and the MFMA loop carries no address arithmetic at all.
+template <int C, int NT, int NPAIR, int RSPLIT, int AM, bool HAS_OUT, int DP>
 __global__ __launch_bounds__(128 * NPAIR * (C / 32) * RSPLIT) void resstream_kernel(const StreamArgs a) {
     constexpr int NR = 2 * NPAIR, NTL = C / 32, WPR = NTL * RSPLIT;
     constexpr int R = 32 * RSPLIT, KS = C / 16, P = 2 * C + 16, CPP = C / 8 + 1, H2 = (NT - 1) / 2, NW = NT * KS;
@@ -53,12 +95,16 @@ __global__ __launch_bounds__(128 * NPAIR * (C / 32) * RSPLIT) void resstream_ker
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int role, sub;
-    role_of_wave<NR, WPR>(wave, role, sub);
+    role_of_wave<NR, WPR>(wave, role, sub, (a.opt & 2) != 0);
     role = __builtin_amdgcn_readfirstlane(role); sub = __builtin_amdgcn_readfirstlane(sub);
     const int pair = role >> 1, kind = role & 1;
     const int ct = sub % NTL, rs = sub / NTL;
     const int l32 = lane & 31, koff = (lane >> 5) * 16, h4 = 4 * (lane >> 5);
     const bool is_final = role == NR - 1;
+    if (a.opt & 1) {
+        const int pr = __builtin_amdgcn_readfirstlane(prio_of_wave<NR, WPR>(wave, (a.opt & 2) != 0));
+        if (pr == 3) __builtin_amdgcn_s_setprio(3); else if (pr == 2) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(1);
+    }
 
     // ---- chain geometry (wave-uniform) ----
     int my_h = 0, my_H = 0, Hsum = 0;
@@ -119,11 +165,12 @@ __global__ __launch_bounds__(128 * NPAIR * (C / 32) * RSPLIT) void resstream_ker
     // ---- DMA lane offsets (role 0): piece j of a 64-row block = 16-byte slots [64 j, 64 j + 64) of its padded LDS image ----
     const unsigned lds_addr0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
     const int nslots = a.dX0 / RS_RD;                                              // DMA blocks the X0 ring holds
+    const unsigned lane_in = lds_addr0 + in_off + koff + l32 * P;                  // this lane's operand row 0 of the input ring
 
     const float slope1 = a.slope1, rinv = a.res_inv_slope, oscale = a.out_scale, oslope = a.slope;
 
 #ifdef RS_PROFILE
-    unsigned long long tacc[6] = {0, 0, 0, 0, 0, 0}, tlast = 0;
+    unsigned long long tacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast = 0;
 #define RS_STAMP(k) do { if (a.prof) { const unsigned long long t_ = __builtin_readcyclecounter(); tacc[k] += t_ - tlast; tlast = t_; } } while (0)
 #else
 #define RS_STAMP(k) do {} while (0)
@@ -190,41 +237,52 @@ __global__ __launch_bounds__(128 * NPAIR * (C / 32) * RSPLIT) void resstream_ker
         // other roles' MFMAs; its xs rows are requested a step early
         bool pend = false; int pend_g0 = 0;
         uint4 xs[2];
-        const int lo = max(seg0, 0), hi = seg_end;
-        const long rm_off = ct * 32 + (lane & 3) * 8;
-        unsigned short* const accp = (unsigned short*)a.accum + (long)b * a.a_bs + rm_off;
-        unsigned short* const outp = (unsigned short*)a.out + (long)b * a.o_bs + rm_off;
+        // xs / output rows of this segment through raw buffers whose range IS the segment [seg0, seg_end): rows outside it (the
+        // pipeline's lead-in, the tail of the last block) fall out of range -- loads return 0, stores are dropped -- so the store
+        // phase carries no row masks and no 64-bit address arithmetic
+        const int nvalid = seg_end - seg0;
+        const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc((void*)((unsigned short*)a.accum + (long)b * a.a_bs + (long)seg0 * a.lda), 0, a.accum ? nvalid * a.lda * 2 : 0, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsO = __builtin_amdgcn_make_buffer_rsrc((void*)((unsigned short*)a.out + (long)b * a.o_bs + (long)seg0 * a.ldo), 0, a.out ? nvalid * a.ldo * 2 : 0, 0x00020000);
+        const int lane_col = (ct * 32 + (lane & 3) * 8) * 2, lane_row = (lane >> 2) - seg0;
+        auto row_off = [&](int g0, int h, int ld) { return __mul24(g0 + h * 16 + lane_row, ld * 2) + lane_col; };
         auto store_phase = [&]() {
             uint4 o[2];
 #pragma unroll
             for (int h = 0; h < 2; h++) o[h] = *(const uint4*)(stw + (h * 16 + (lane >> 2)) * 80 + (lane & 3) * 16);
+#ifdef RS_PROFILE
+            asm volatile("" :: "v"(o[0].x), "v"(o[1].x));
+            RS_STAMP(7);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            RS_STAMP(8);
+#endif
 #pragma unroll
             for (int h = 0; h < 2; h++) {
-                const int gr = pend_g0 + h * 16 + (lane >> 2);
-                const bool ok = gr >= lo && gr < hi;
-                if (AM) {
+                if (AM & 1 || HAS_OUT) {
                     f32x2 t[4] = {unpack_bf16x2(o[h].x), unpack_bf16x2(o[h].y), unpack_bf16x2(o[h].z), unpack_bf16x2(o[h].w)};
                     if (AM & 1) {
                         t[0] += unpack_bf16x2(xs[h].x); t[1] += unpack_bf16x2(xs[h].y);
                         t[2] += unpack_bf16x2(xs[h].z); t[3] += unpack_bf16x2(xs[h].w);
+                        if (AM & 2) o[h] = make_uint4(pack_bf16x2(t[0].x, t[0].y), pack_bf16x2(t[1].x, t[1].y), pack_bf16x2(t[2].x, t[2].y), pack_bf16x2(t[3].x, t[3].y));
                     }
-                    if ((AM & 2) && ok)
-                        *(u32x4*)(accp + (long)gr * a.lda) = (u32x4){pack_bf16x2(t[0].x, t[0].y), pack_bf16x2(t[1].x, t[1].y),
-                                                                    pack_bf16x2(t[2].x, t[2].y), pack_bf16x2(t[3].x, t[3].y)};
+                    if (AM & 2) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o[h]), rsA, row_off(pend_g0, h, a.lda), 0, 0);
                     if (HAS_OUT) {
+                        if (AM) {
 #pragma unroll
-                        for (int e = 0; e < 4; e++) t[e] = lrelu2(t[e] * oscale, oslope);
-                        o[h] = make_uint4(pack_bf16x2(t[0].x, t[0].y), pack_bf16x2(t[1].x, t[1].y), pack_bf16x2(t[2].x, t[2].y), pack_bf16x2(t[3].x, t[3].y));
+                            for (int e = 0; e < 4; e++) t[e] = lrelu2(t[e] * oscale, oslope);
+                            o[h] = make_uint4(pack_bf16x2(t[0].x, t[0].y), pack_bf16x2(t[1].x, t[1].y), pack_bf16x2(t[2].x, t[2].y), pack_bf16x2(t[3].x, t[3].y));
+                        }
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o[h]), rsO, row_off(pend_g0, h, a.ldo), 0, 0);
                     }
+                } else if (AM & 2) {
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o[h]), rsA, row_off(pend_g0, h, a.lda), 0, 0);   // AM == 2: the staged bf16 rows as they are
                 }
-                if (HAS_OUT && ok) *(uint4*)(outp + (long)gr * a.ldo) = o[h];
             }
         };
 
         // One block of one role.  KIND 0: conv1 (-> T ring), 1: conv2 feeding the next pair (-> X ring), 2: the chain's last conv2.
         // Every LDS read is inline asm with counted lgkmcnt waits (LDS operations complete in order): the B fragments are
         // requested PD ahead of the MFMA that consumes them.
-        auto mma_block = [&]() {
+        auto mma_slow = [&]() {
             constexpr int PD = NW <= 6 ? NW : (NW >= 40 ? 4 : 6);
 #pragma unroll
             for (int e = 0; e < 16; e++) acc[e] = 0.f;
@@ -264,10 +322,34 @@ __global__ __launch_bounds__(128 * NPAIR * (C / 32) * RSPLIT) void resstream_ker
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w[i]), __builtin_bit_cast(bf16x8, xf[i % (PD + 1)]), acc, 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
+        };
+        // The same block when its rows (block + halo) do not wrap around the ring: one base address, every tap / k16 slot an
+        // immediate offset.  Same reads, same MFMA order as mma_slow.
+        auto mma_fast = [&](auto dil_c) {
+            constexpr int DIL = decltype(dil_c)::value;
+            constexpr int PD = NW <= 6 ? NW : (NW >= 40 ? 4 : 6);
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[e] = 0.f;
+            const unsigned base = lane_in + (unsigned)(rd_pos * P);
+            uint4 xf[PD + 1];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            rs_prefetch<0, PD, KS, DIL, P>(xf, base);
+            rs_mma_steps<0, NW, PD, KS, DIL, P>(xf, w, base, acc);
+        };
+        auto mma_block = [&]() {
+            constexpr int D0 = DP & 15, D1 = (DP >> 4) & 15, D2 = (DP >> 8) & 15;
+            const int span = 32 + (NT - 1) * my_dil;
+            if (rd_pos + span > Din) mma_slow();
+            else if (kind) mma_fast(std::integral_constant<int, 1>{});
+            else if (pair == 0) mma_fast(std::integral_constant<int, D0>{});
+            else if (pair == 1) mma_fast(std::integral_constant<int, NPAIR >= 2 ? D1 : D0>{});
+            else mma_fast(std::integral_constant<int, NPAIR >= 3 ? D2 : D0>{});
             rd_pos += R; if (rd_pos >= Din) rd_pos -= Din;
         };
-        auto epilogue_block = [&](auto kind_c) {
+        auto epilogue_block = [&](auto kind_c, auto masked_c) {
             constexpr int KIND = decltype(kind_c)::value;
+            constexpr bool MASKED = decltype(masked_c)::value;                    // false: every row of the block lies inside the utterance
             const int g = g_out0 + l32;                                            // this lane's output row
             const bool inside = g >= 0 && g < len;                                 // streams are zero outside the utterance (every conv zero-pads ITS input)
             float4 bq[4];
@@ -299,17 +381,14 @@ __global__ __launch_bounds__(128 * NPAIR * (C / 32) * RSPLIT) void resstream_ker
                 else if (!AM) { v01 = lrelu2(v01, oslope); v23 = lrelu2(v23, oslope); }                  // no running sum: the output activation is applied here
                 uint2 pk;
                 pk.x = pack_bf16x2(v01.x, v01.y); pk.y = pack_bf16x2(v23.x, v23.y);
-                if (KIND <= 1 && !inside) { pk.x = 0u; pk.y = 0u; }
+                if (KIND <= 1 && MASKED && !inside) { pk.x = 0u; pk.y = 0u; }
                 *(uint2*)(dst + q * 16) = pk;
             }
             if (KIND == 2) {
                 pend = true; pend_g0 = g_out0;
                 if (AM & 1) {                                                      // xs rows of this block: requested now, used by the store phase next step
 #pragma unroll
-                    for (int h = 0; h < 2; h++) {
-                        const int gr = g_out0 + h * 16 + (lane >> 2);
-                        xs[h] = *(const uint4*)(accp + ((gr >= lo && gr < hi) ? (long)gr * a.lda : 0));
-                    }
+                    for (int h = 0; h < 2; h++) xs[h] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rsA, row_off(g_out0, h, a.lda), 0, 0));
                 }
             }
             wr_pos += R; if (wr_pos >= Dout && Dout > 0) wr_pos -= Dout;
@@ -324,21 +403,23 @@ __global__ __launch_bounds__(128 * NPAIR * (C / 32) * RSPLIT) void resstream_ker
                 const int target = need(s + RS_PF) + 1;
                 while (issued < target) dma_block();
             }
-            if (is_final && pend) { store_phase(); pend = false; }
+            if (is_final && pend) { store_phase(); pend = false; RS_STAMP(9); }
             RS_STAMP(1);
             if (blk >= 0 && blk < nact) {
                 mma_block();
-                if (!kind) epilogue_block(std::integral_constant<int, 0>{});
-                else if (!is_final) epilogue_block(std::integral_constant<int, 1>{});
-                else epilogue_block(std::integral_constant<int, 2>{});
+                RS_STAMP(2);
+                const bool interior = g_out0 >= 0 && g_out0 + 32 <= len;          // wave-uniform
+                if (is_final) epilogue_block(std::integral_constant<int, 2>{}, std::false_type{});
+                else if (!kind) { if (interior) epilogue_block(std::integral_constant<int, 0>{}, std::false_type{}); else epilogue_block(std::integral_constant<int, 0>{}, std::true_type{}); }
+                else { if (interior) epilogue_block(std::integral_constant<int, 1>{}, std::false_type{}); else epilogue_block(std::integral_constant<int, 1>{}, std::true_type{}); }
             }
-            RS_STAMP(2);
-            if (role == 0) wait_landed(need(s + 1) + 1);                           // what role 0 reads in the next step has landed
             RS_STAMP(3);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (role == 0) wait_landed(need(s + 1) + 1);                           // what role 0 reads in the next step has landed
             RS_STAMP(4);
-            asm volatile("s_barrier" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             RS_STAMP(5);
+            asm volatile("s_barrier" ::: "memory");
+            RS_STAMP(6);
         }
         if (is_final && pend) store_phase();
         if (role == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // surplus requests of the tail: landed before the next segment re-uses X0
@@ -346,7 +427,7 @@ __global__ __launch_bounds__(128 * NPAIR * (C / 32) * RSPLIT) void resstream_ker
     }
 #ifdef RS_PROFILE
     if (a.prof && blockIdx.x == 0 && lane == 0)
-        for (int k = 0; k < 6; k++) a.prof[(wave * 8 + k)] = (long long)tacc[k], a.prof[wave * 8 + 6] = role, a.prof[wave * 8 + 7] = sub;
+        for (int k = 0; k < 12; k++) a.prof[(wave * 16 + k)] = (long long)tacc[k], a.prof[wave * 16 + 14] = role, a.prof[wave * 16 + 15] = sub;
 #endif
 }
 
@@ -359,7 +440,7 @@ static int ncu() {
     return g_ncu;
 }
 
-template <int C, int NT, int NPAIR, int RSPLIT>
+template <int C, int NT, int NPAIR, int RSPLIT, int DP>
 static bool launch_rs(StreamArgs& a, hipStream_t stream, bool dry_run) {
     constexpr int NTL = C / 32, WPR = NTL * RSPLIT, R = 32 * RSPLIT, P = 2 * C + 16, H2 = (NT - 1) / 2, NR = 2 * NPAIR;
     // ring sizes (rows): see the header comment; X0 also covers the DMA lead and holds whole 64-row DMA blocks
@@ -390,7 +471,7 @@ static bool launch_rs(StreamArgs& a, hipStream_t stream, bool dry_run) {
     if (dry_run) return true;
     const dim3 grid(nsegs < nwg ? nsegs : nwg), block(64 * NR * WPR);
     const int am = a.accum ? a.accum_mode : 0;
-#define RS_GO(AM_, HO_) do { auto kfn = resstream_kernel<C, NT, NPAIR, RSPLIT, AM_, HO_>; \
+#define RS_GO(AM_, HO_) do { auto kfn = resstream_kernel<C, NT, NPAIR, RSPLIT, AM_, HO_, DP>; \
         static bool attr_done = false; \
         if (!attr_done) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_done = true; } \
         if (g_rs_ev_start) hipExtLaunchKernelGGL(kfn, grid, block, lds, stream, g_rs_ev_start, g_rs_ev_stop, 0, a); \
@@ -409,13 +490,17 @@ int launch_resstream(StreamArgs a, hipStream_t stream, bool dry_run) {
     if (!a.out && !(am & 2)) return -1;
     if (a.out && am >= 2) return -1;
     for (int p = 0; p < a.npair; p++) if (a.dil[p] < 1 || !a.W1[p] || !a.W2[p] || !a.b1[p] || !a.b2[p]) return -1;
-#define RS_TRY(C_, NT_, NP_, RSP_) if (a.C == C_ && a.ntaps == NT_ && a.npair == NP_) return launch_rs<C_, NT_, NP_, RSP_>(a, stream, dry_run) ? (C_ == 32 ? 20 : 21) : -1
+    // the dilations are template constants (HiFi-GAN's ResBlock1 sets: 1, 3, 5 -- config.py / hifigan.py:49-56); other sets
+    // take the per-pair path
+    int dp = 0;
+    for (int p = 0; p < a.npair; p++) { if (a.dil[p] > 15) return -1; dp |= a.dil[p] << (4 * p); }
+#define RS_TRY(C_, NT_, NP_, RSP_, DP_) if (a.C == C_ && a.ntaps == NT_ && a.npair == NP_ && dp == DP_) return launch_rs<C_, NT_, NP_, RSP_, DP_>(a, stream, dry_run) ? (C_ == 32 ? 20 : 21) : -1
     // 12 waves (whole ResBlock, 168 registers per wave) where the weight fragments leave room; otherwise 8 waves (256
     // registers): the first two pairs as one chain, the last pair on its own with the rows split over more waves
-    RS_TRY(32, 3, 3, 2); RS_TRY(32, 7, 3, 2); RS_TRY(32, 11, 3, 2);
-    RS_TRY(64, 3, 3, 1);
-    RS_TRY(64, 7, 2, 1); RS_TRY(64, 7, 1, 2);
-    RS_TRY(64, 11, 2, 1); RS_TRY(64, 11, 1, 2);
+    RS_TRY(32, 3, 3, 2, 0x531); RS_TRY(32, 7, 3, 2, 0x531); RS_TRY(32, 11, 3, 2, 0x531);
+    RS_TRY(64, 3, 3, 1, 0x531);
+    RS_TRY(64, 7, 2, 1, 0x31); RS_TRY(64, 7, 1, 2, 0x5);
+    RS_TRY(64, 11, 2, 1, 0x31); RS_TRY(64, 11, 1, 2, 0x5);
 #undef RS_TRY
     return -1;
 }

@@ -101,6 +101,7 @@ struct StreamArgs {
     int dX0, dT, dX[3];                            // filled by the launcher: ring sizes in rows
     double flops;                                  // filled by the launcher
     long long* prof;                               // RS_PROFILE builds: per-wave cycle counters of workgroup 0
+    int opt;                                       // bit 0: staggered wave priorities, bit 1: balanced role -> SIMD table (zvx_set_int("rs_opt", v): A/B switch)
 };
 // variant id (index into gemm_variant_name) or -1 when the shape is not covered; dry_run: decide only, launch nothing
 int launch_resstream(StreamArgs a, hipStream_t stream, bool dry_run);
