@@ -165,6 +165,13 @@ __global__ __launch_bounds__(128 * NPAIR * (C / 32) * RSPLIT) void resstream_ker
     // ---- DMA lane offsets (role 0): piece j of a 64-row block = 16-byte slots [64 j, 64 j + 64) of its padded LDS image ----
     const unsigned lds_addr0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
     const int nslots = a.dX0 / RS_RD;                                              // DMA blocks the X0 ring holds
+    int dma_off[PPW];                                                              // byte offset of this lane's 16 bytes within a DMA block, per piece; pad slot: out of range -> zeros
+#pragma unroll
+    for (int n = 0; n < PPW; n++) {
+        const int j = sub + WPR * n < PPB ? sub + WPR * n : PPB - 1;
+        const int slot = j * 64 + lane, row = slot / CPP, qs = slot % CPP;
+        dma_off[n] = qs == CPP - 1 ? -16 : (row * a.ldx + (qs << 3)) * 2;
+    }
     const unsigned lane_in = lds_addr0 + in_off + koff + l32 * P;                  // this lane's operand row 0 of the input ring
 
     const float slope1 = a.slope1, rinv = a.res_inv_slope, oscale = a.out_scale, oslope = a.slope;
@@ -208,10 +215,10 @@ __global__ __launch_bounds__(128 * NPAIR * (C / 32) * RSPLIT) void resstream_ker
             const unsigned la0 = lds_addr0 + offX + dslot * (RS_RD * P);
 #pragma unroll
             for (int n = 0; n < PPW; n++) {
-                int j = sub + WPR * n; if (j >= PPB) j = PPB - 1;
-                const int slot = j * 64 + lane, row = slot / CPP, qs = slot % CPP;
-                const int vrel = qs == CPP - 1 ? -(1 << 30) : (row * a.ldx + (qs << 3)) * 2;          // pad slot: out of range -> zeros
-                const int voff = vrel < thr ? -16 : vrel;
+                const int j = sub + WPR * n < PPB ? sub + WPR * n : PPB - 1;
+                // interior blocks (g0 >= 0) use the per-lane offsets as precomputed; blocks that start before the utterance
+                // push the rows before it out of range (zeros)
+                const int voff = g0 >= 0 ? dma_off[n] : (dma_off[n] < thr ? -16 : dma_off[n]);
                 const unsigned la = __builtin_amdgcn_readfirstlane(la0 + j * 1024);
                 asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" :: "s"(la), "v"(voff), "s"(rsrc) : "memory", "m0");
             }
