@@ -601,6 +601,25 @@ def test_streaming_resblock_kernels_equal_per_pair_launches(voc):
         ctx.set_int("resstream", 1)
 
 
+def test_benchmark_batch_is_bit_reproducible_over_many_runs():
+    """The hand-scheduled kernels count their outstanding loads (s_waitcnt vmcnt(n)): an off-by-one is a RARE wrong block, not a
+    wrong result every time (round 3: the k = 3 pair kernel let one LDS-DMA piece outlive the step barrier, a wrong 128-row
+    block in ~1 % of runs).  60 runs of the benchmark vocoder batch and 20 of the whole step must agree bit for bit; the
+    encoder's fused f32 attention likewise (same result for an utterance alone and in a batch)."""
+    ctx = ctx_for("styletts", "v1", "bf16")
+    ph, pu, T, spk, dur = synthetic.batch(32, 128, 192, "const7")
+    pad_to = np.full(32, 896, np.int32)
+    r0 = ctx.synthesize(ph, pu, T, spk, dur, pad_to, want_mel=True)
+    for i in range(20):
+        r = ctx.synthesize(ph, pu, T, spk, dur, pad_to, want_mel=True)
+        assert np.array_equal(r["mel"], r0["mel"]) and np.array_equal(r["wav"], r0["wav"]), f"step run {i}"
+    w0 = ctx.vocode_mel(r0["mel"], r0["mel_len"])
+    for i in range(60):
+        assert np.array_equal(ctx.vocode_mel(r0["mel"], r0["mel_len"]), w0), f"vocoder run {i}"
+    one = ctx.synthesize(ph[5:6], pu[5:6], T[5:6], spk[5:6], dur[5:6], pad_to[5:6], want_mel=True)
+    assert np.array_equal(one["mel"][0], r0["mel"][5])
+
+
 @pytest.mark.parametrize("pcm16", [False, True])
 def test_vocode_mel_with_input_stride_larger_than_longest_utterance(pcm16):
     """zvx_vocode_mel with Pmax (the input mel's row stride) > max(P): the zero tail of a row ends at max_b(P) * hop -- what

@@ -19,6 +19,8 @@
 
 #include <hip/hip_ext.h>
 
+#include <type_traits>
+
 namespace zvx {
 
 static thread_local hipEvent_t g_fa_ev_start = nullptr, g_fa_ev_stop = nullptr;
@@ -207,6 +209,215 @@ bool launch_flash_attention(const FlashArgs& a, hipStream_t stream, bool dry_run
     static bool attr_done = false;
     if (!attr_done) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_done = true; }
     const dim3 grid((a.L + FA_BQ - 1) / FA_BQ, a.nbatch * a.nheads), block(256);
+    if (g_fa_ev_start) hipExtLaunchKernelGGL(kfn, grid, block, lds, stream, g_fa_ev_start, g_fa_ev_stop, 0, a);
+    else hipLaunchKernelGGL(kfn, grid, block, lds, stream, a);
+    return true;
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// Exact-f32 attention for the phoneme encoder (fs2.py:47-58, 133-164).  The encoder feeds discrete decisions (bucket ids,
+// durations), so its attention stays in f32 end to end: v_mfma_f32_32x32x2f32 for both products, expf for the softmax.
+// One workgroup = (utterance, head, 32 queries); keys / values stream through LDS in tiles of 128 keys, each in two depth
+// chunks (128 + 136 of d = 264), online softmax state (running max / sum) per query row in registers of the 8 threads that
+// own the row.  Replaces V^T GEMM + score GEMM + softmax + P.V GEMM (+ a memset) of the unfused path: [L][L] scores and
+// probabilities never leave the chip, and Q | K | V come from ONE projection GEMM.
+//   * MFMA operands: lane (i = l % 32, kh = l / 32) supplies element [i][k] of A resp. [k][i] of B for k = 2 step + kh.  The
+//     contraction order is free as long as A and B agree, so one ds_read_b128 at depth 8 j + 4 kh feeds FOUR steps (element s of
+//     both halves); row pitches are 4 x odd dwords, which makes those b128 reads conflict-free.
+//   * key tiles are fixed ([0,128), [128,256) ...) and masked by the utterance's own length, so an utterance's result does
+//     not depend on the batch it travels in.
+// ------------------------------------------------------------------------------------------------
+template <int IT> struct AfTile { float4 v[IT]; };      // a tile's global loads in flight (registers) between fetch and LDS commit
+#define AF_BQ 32
+#define AF_BK 128
+template <int D>
+__global__ __launch_bounds__(256) void attn_f32_kernel(const AttnF32Args a) {
+    constexpr int C0 = 128, C1 = D - C0;                        // depth chunks, multiples of 8
+    constexpr int QP = D + 4, KP = (C1 > C0 ? C1 : C0) + 4, PP = AF_BK + 4;   // pitches in floats: 268, 140, 132 (all 4 x odd)
+    static_assert(C1 % 8 == 0 && C0 % 8 == 0 && (QP / 4) % 2 == 1 && (KP / 4) % 2 == 1 && (PP / 4) % 2 == 1, "chunking / pitches");
+    constexpr int NT1 = (C1 + 31) / 32;                         // column tiles of the second chunk (5: the last one 8 wide)
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    float* const Qs = (float*)lds_raw;                          // [32][QP]
+    float* const Ks = Qs + AF_BQ * QP;                          // [128][KP]   K chunk, then V chunk
+    float* const Ps = Ks + AF_BK * KP;                          // [32][PP]    scores, then probabilities
+    float* const As = Ps + AF_BQ * PP;                          // [32] rescale factor of the running output, then 1 / sum
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l32 = lane & 31, kh = lane >> 5;
+    const int b = blockIdx.y / a.nheads, h = blockIdx.y - b * a.nheads;
+    const int len = a.len ? a.len[b] : a.L;
+    const int q0 = blockIdx.x * AF_BQ;
+    if (q0 >= len) return;
+    const float* const base = a.qkv + (long)b * a.bs + (long)h * D;
+
+    // rows [row0, row0 + NROWS) x columns [0, NCOLS) of a row-major f32 matrix -> LDS tile (rows at or beyond L: zeros).  Every
+    // load of the tile is in flight before the first LDS store (a load -> store loop pays one L2 round trip per iteration).
+    auto tile_fetch = [&](const float* src, int row0, auto nrows_c, auto ncols_c) {
+        constexpr int NROWS = decltype(nrows_c)::value, NCOLS = decltype(ncols_c)::value;
+        constexpr int C4N = NCOLS / 4, N = NROWS * C4N, IT = (N + 255) / 256;
+        AfTile<IT> t;
+#pragma unroll
+        for (int it = 0; it < IT; it++) {
+            const int i = tid + it * 256, r = i / C4N, c4 = i - r * C4N, row = row0 + r;
+            t.v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i < N && row < a.L) t.v[it] = *(const float4*)(src + (long)row * a.ld + c4 * 4);
+        }
+        return t;
+    };
+    auto tile_commit = [&](const auto& t, auto nrows_c, auto ncols_c, float* dst, int pitch) {
+        constexpr int NROWS = decltype(nrows_c)::value, NCOLS = decltype(ncols_c)::value;
+        constexpr int C4N = NCOLS / 4, N = NROWS * C4N, IT = (N + 255) / 256;
+#pragma unroll
+        for (int it = 0; it < IT; it++) {
+            const int i = tid + it * 256, r = i / C4N, c4 = i - r * C4N;
+            if (i < N) *(float4*)(dst + r * pitch + c4 * 4) = t.v[it];
+        }
+    };
+    auto load_tile = [&](const float* src, int row0, auto nrows_c, auto ncols_c, float* dst, int pitch) {
+        tile_commit(tile_fetch(src, row0, nrows_c, ncols_c), nrows_c, ncols_c, dst, pitch);
+    };
+    constexpr std::integral_constant<int, AF_BQ> c_bq{};
+    constexpr std::integral_constant<int, AF_BK> c_bk{};
+    constexpr std::integral_constant<int, D> c_d{};
+    constexpr std::integral_constant<int, C0> c_c0{};
+    constexpr std::integral_constant<int, C1> c_c1{};
+    load_tile(base + a.q_off, q0, c_bq, c_d, Qs, QP);
+
+    f32x16 o0, o1, o2;
+#pragma unroll
+    for (int e = 0; e < 16; e++) { o0[e] = 0.f; o1[e] = 0.f; o2[e] = 0.f; }
+    float m_run = -INFINITY, l_run = 0.f;                       // softmax state of row tid / 8 (all 8 threads of a row hold it)
+    const int srow = tid >> 3, ssub = tid & 7;
+    const float* const qrow = Qs + l32 * QP + 4 * kh;
+    const float* const krow = Ks + (wave * 32 + l32) * KP + 4 * kh;
+    const float* const prow = Ps + l32 * PP + 4 * kh;
+
+    const int ntiles = (len + AF_BK - 1) / AF_BK;
+    for (int kt = 0; kt < ntiles; kt++) {
+        const int k0 = kt * AF_BK;
+        const bool my_keys = k0 + wave * 32 < len;                                  // wave-uniform: this wave's 32 keys hold a valid one
+        // ---- S = Q K^T over the two depth chunks ----
+        f32x16 s, s2;                                                               // two independent MFMA chains (a lone wave per SIMD cannot hide the dependent-issue latency)
+#pragma unroll
+        for (int e = 0; e < 16; e++) { s[e] = 0.f; s2[e] = 0.f; }
+        __syncthreads();                                                            // Ks (V of the previous tile) and Ps are free
+        load_tile(base + a.k_off, k0, c_bk, c_c0, Ks, KP);
+        __syncthreads();
+        const auto k1 = tile_fetch(base + a.k_off + C0, k0, c_bk, c_c1);            // in flight under the chunk-0 products
+        if (my_keys) {
+#pragma unroll
+            for (int j = 0; j < C0 / 8; j++) {
+                const float4 qa = *(const float4*)(qrow + 8 * j), kb = *(const float4*)(krow + 8 * j);
+                s = __builtin_amdgcn_mfma_f32_32x32x2f32(qa.x, kb.x, s, 0, 0, 0);
+                s2 = __builtin_amdgcn_mfma_f32_32x32x2f32(qa.y, kb.y, s2, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x2f32(qa.z, kb.z, s, 0, 0, 0);
+                s2 = __builtin_amdgcn_mfma_f32_32x32x2f32(qa.w, kb.w, s2, 0, 0, 0);
+            }
+        }
+        __syncthreads();
+        tile_commit(k1, c_bk, c_c1, Ks, KP);
+        const auto v0 = tile_fetch(base + a.v_off, k0, c_bk, c_c0);                 // V chunk 0: in flight under the chunk-1 products and the softmax
+        __syncthreads();
+        if (my_keys) {
+#pragma unroll
+            for (int j = 0; j < C1 / 8; j++) {
+                const float4 qa = *(const float4*)(qrow + C0 + 8 * j), kb = *(const float4*)(krow + 8 * j);
+                s = __builtin_amdgcn_mfma_f32_32x32x2f32(qa.x, kb.x, s, 0, 0, 0);
+                s2 = __builtin_amdgcn_mfma_f32_32x32x2f32(qa.y, kb.y, s2, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_32x32x2f32(qa.z, kb.z, s, 0, 0, 0);
+                s2 = __builtin_amdgcn_mfma_f32_32x32x2f32(qa.w, kb.w, s2, 0, 0, 0);
+            }
+            s += s2;
+        }
+        // scores -> LDS: accumulator e of lane (key l32, kh) is query row 8 (e / 4) + 4 kh + e % 4
+#pragma unroll
+        for (int e = 0; e < 16; e++) Ps[(8 * (e >> 2) + 4 * kh + (e & 3)) * PP + wave * 32 + l32] = s[e] * a.scale;
+        __syncthreads();                                                            // K chunk consumed by every wave, scores complete
+        tile_commit(v0, c_bk, c_c0, Ks, KP);
+        const auto v1 = tile_fetch(base + a.v_off + C0, k0, c_bk, c_c1);            // V chunk 1: under the softmax and the chunk-0 P.V
+        {   // ---- online softmax of row srow over this tile's keys (16 per thread) ----
+            float* const pr = Ps + srow * PP + ssub * 16;
+            float v[16];
+#pragma unroll
+            for (int i = 0; i < 4; i++) { const float4 t = *(const float4*)(pr + 4 * i); v[4 * i] = t.x; v[4 * i + 1] = t.y; v[4 * i + 2] = t.z; v[4 * i + 3] = t.w; }
+            const int kbase = k0 + ssub * 16;
+            float m = -INFINITY;
+#pragma unroll
+            for (int i = 0; i < 16; i++) if (kbase + i < len) m = fmaxf(m, v[i]);
+            m = fmaxf(m, __shfl_xor(m, 1, 64)); m = fmaxf(m, __shfl_xor(m, 2, 64)); m = fmaxf(m, __shfl_xor(m, 4, 64));
+            const float m_new = fmaxf(m_run, m);                                    // finite: key k0 < len is valid for every row
+            const float alpha = m_run == -INFINITY ? 0.f : expf(m_run - m_new);
+            float sum = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; i++) { v[i] = kbase + i < len ? expf(v[i] - m_new) : 0.f; sum += v[i]; }
+            sum += __shfl_xor(sum, 1, 64); sum += __shfl_xor(sum, 2, 64); sum += __shfl_xor(sum, 4, 64);
+            l_run = alpha * l_run + sum; m_run = m_new;
+#pragma unroll
+            for (int i = 0; i < 4; i++) *(float4*)(pr + 4 * i) = make_float4(v[4 * i], v[4 * i + 1], v[4 * i + 2], v[4 * i + 3]);
+            if (ssub == 0) As[srow] = alpha;
+        }
+        __syncthreads();
+        // ---- O = alpha O + P V ----
+        {
+            float al[16];
+#pragma unroll
+            for (int g = 0; g < 4; g++) { const float4 t = *(const float4*)(As + 8 * g + 4 * kh); al[4 * g] = t.x; al[4 * g + 1] = t.y; al[4 * g + 2] = t.z; al[4 * g + 3] = t.w; }
+#pragma unroll
+            for (int e = 0; e < 16; e++) { o0[e] *= al[e]; o1[e] *= al[e]; o2[e] *= al[e]; }
+        }
+        // every step of the tile is issued: probabilities beyond the last valid key are exactly zero and V rows there are
+        // finite (zeros beyond L), so they add nothing -- and the loop has no branches for the scheduler to stop at
+        auto pv_tile = [&](f32x16 acc, int col) {                                   // col: column of the chunk this lane supplies
+            const float* const vc = Ks + col + 4 * kh * KP;
+            f32x16 acc2;
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc2[e] = 0.f;
+#pragma unroll
+            for (int j = 0; j < AF_BK / 8; j++) {
+                const float4 pa = *(const float4*)(prow + 8 * j);
+                const float* const vj = vc + 8 * j * KP;
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa.x, vj[0], acc, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(pa.y, vj[KP], acc2, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa.z, vj[2 * KP], acc, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(pa.w, vj[3 * KP], acc2, 0, 0, 0);
+            }
+            return acc + acc2;
+        };
+        o0 = pv_tile(o0, wave * 32 + l32);                                          // columns [32 w, 32 w + 32) of chunk 0
+        __syncthreads();
+        tile_commit(v1, c_bk, c_c1, Ks, KP);
+        __syncthreads();
+        o1 = pv_tile(o1, min(wave * 32 + l32, C1 - 1));                             // columns C0 + [32 w, 32 w + 32)
+        if (NT1 > 4 && wave == 3) o2 = pv_tile(o2, min(128 + l32, C1 - 1));         // the 8-column remainder (C0 + 128 ...)
+    }
+    // ---- out[q][h D + col] = O / sum ----
+    __syncthreads();
+    if (ssub == 0) As[srow] = 1.0f / l_run;
+    __syncthreads();
+    float* const op = a.out + (long)b * a.o_bs + (long)h * D;
+    auto store_tile = [&](const f32x16& acc, int col) {
+        if (col >= D) return;
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+            const int r = 8 * (e >> 2) + 4 * kh + (e & 3), q = q0 + r;
+            if (q < a.L) op[(long)q * a.ldo + col] = q < len ? acc[e] * As[r] : 0.f;
+        }
+    };
+    store_tile(o0, wave * 32 + l32);
+    store_tile(o1, C0 + wave * 32 + l32);
+    if (NT1 > 4 && wave == 3) store_tile(o2, C0 + 128 + l32);
+}
+
+bool launch_attention_f32(const AttnF32Args& a, hipStream_t stream, bool dry_run) {
+    if (a.D != 264 || a.L <= 0 || a.ld % 4 || a.q_off % 4 || a.k_off % 4 || a.v_off % 4) return false;
+    if (dry_run) return true;
+    if ((size_t)a.qkv & 15) return false;
+    constexpr int D = 264, KP = (D - 128) + 4;
+    const size_t lds = sizeof(float) * ((size_t)AF_BQ * (D + 4) + (size_t)AF_BK * KP + (size_t)AF_BQ * (AF_BK + 4) + 32);
+    auto kfn = attn_f32_kernel<264>;
+    static bool attr_done = false;
+    if (!attr_done) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_done = true; }
+    const dim3 grid((a.L + AF_BQ - 1) / AF_BQ, a.nbatch * a.nheads), block(256);
     if (g_fa_ev_start) hipExtLaunchKernelGGL(kfn, grid, block, lds, stream, g_fa_ev_start, g_fa_ev_stop, 0, a);
     else hipLaunchKernelGGL(kfn, grid, block, lds, stream, a);
     return true;

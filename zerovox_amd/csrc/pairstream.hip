@@ -222,10 +222,14 @@ __device__ __forceinline__ void ps_role(const PairArgs& a, unsigned char* lds, c
                             if (j == 3) {
                                 if (!(PS_EXP & 1)) wload(next_off + i * 1024, i);          // the slot just consumed takes the fragment 8 steps on
                                 if (ROLE == 0 && !(PS_EXP & 8)) {
-                                    // this iteration's DMA instructions, spread over its steps (pieces past PS_NDMA: surplus, zero-fill the scratch KiB)
+                                    // this iteration's DMA instructions, spread over its steps (pieces past PS_NDMA: surplus, zero-fill the scratch KiB).
+                                    // ALL of them are issued before step 7: that step's wait then leaves exactly this iteration's 7 + EPI
+                                    // requests outstanding, so after the last iteration every real piece (issued earlier) has landed.
+                                    // (With a piece at step 7 -- (8 e + 4) / EPI for EPI = 4, NT = 3 -- the real piece of the previous
+                                    // iteration's step 7 could still be in flight at the step barrier: seen as a rare wrong block, ~1 % of runs.)
 #pragma unroll
                                     for (int e = 0; e < EPI; e++)
-                                        if (i == (8 * e + 4) / EPI) {
+                                        if (i == (7 * e + 3) / EPI) {
                                             const int pidx = u2 * EPI + e;
                                             dma_piece(rsd, gx, x_wr, ct * PS_NDMA + (pidx < PS_NDMA ? pidx : 0), dma_real && pidx < PS_NDMA);
                                         }

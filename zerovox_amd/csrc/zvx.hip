@@ -85,6 +85,7 @@ struct zvx_ctx {
     int profile_only = -1;                 // >= 0: per-launch events only for this kernel variant (keeps the timed region lean)
     int rs_prof = 0;                       // zvx_set_int("rs_prof", 1): per-wave cycle counters of the streaming kernels (library built with -DRS_PROFILE)
     int enc_split = 0;                     // bf16 mode: the f32 GEMMs of the phoneme encoder / variance adaptor run as 3-plane bf16 GEMMs
+    int use_attn_f32 = 1;                  // zvx_set_int("attn_f32", 0): the encoder's attention as V^T / score / P.V GEMMs + softmax (A/B)
     int use_flash = 1;                     // zvx_set_int("flash", 0): the decoder's attention as score GEMM + softmax + PV GEMM (A/B)
     int voc_chunk = 0;                     // utterances per vocoder ResBlock sub-batch (0 = whole batch)
     int use_resstream = 1;                 // zvx_set_int("resstream", 0): ResBlocks of the narrow stages as per-pair launches (A/B, bit-equal)
@@ -212,6 +213,7 @@ struct zvx_ctx {
             HIPCHK(hipEventElapsedTime(&ms, e.a, e.b));
             if (shape_log && e.variant >= 0) fprintf(stderr, "launch %-24s rows=%-8ld N=%-4d K=%-4d taps=%-2d res=%d fused=%d  %8.3f ms %8.1f TF/s %8.1f GB/s(alg)\n",
                                    gemm_variant_name(e.variant), e.rows, e.N, e.K, e.taps, e.res, e.fused, ms, e.flops / ms / 1e9, e.bytes / ms / 1e6);
+            else if (shape_log) fprintf(stderr, "launch %-24s [%s]  %8.3f ms %8.1f GB/s(alg)\n", "(helper)", e.tag.c_str(), ms, e.bytes / ms / 1e6);
             if (e.variant >= 0) { auto& s = stats[e.variant]; s.launches++; s.ms += ms; s.flops += e.flops; s.bytes += e.bytes; }
             auto& ts = tagstats[e.tag];
             if (!ts.name[0]) snprintf(ts.name, 64, "%s", e.tag.c_str());
@@ -314,6 +316,30 @@ void upload_weights(zvx_ctx* c) {
             }
         }
     }
+    // f32 FFT blocks: Q, K and V projections as ONE GEMM (fs2.py:143-145) -- [Wq; Wk; Wv] and the biases concatenated once here
+    {
+        std::vector<std::pair<std::string, Tensor>> add;
+        for (auto& kv : c->tensors) {
+            const std::string& nm = kv.first;
+            if (nm.size() < 5 || nm.compare(nm.size() - 4, 4, ".wqk") != 0) continue;          // every f32 FFT block: the encoder's, and the FS2 decoder's in f32 mode
+            const std::string pre = nm.substr(0, nm.size() - 4);
+            const Tensor& wqk = kv.second;
+            if (!c->has(pre + ".wv") || !c->has(pre + ".bqk") || !c->has(pre + ".bv") || wqk.dtype != DT_F32 || wqk.dims.size() != 3) continue;
+            const Tensor& wv = c->t(pre + ".wv");
+            if (wv.dtype != DT_F32 || wv.dims.size() != 3 || wv.dim(2) != wqk.dim(2)) continue;
+            Tensor w = wqk; w.dims = {1, wqk.dim(1) + wv.dim(1), wqk.dim(2)}; w.numel = wqk.numel + wv.numel; w.host = nullptr;
+            w.dev = c->buf(pre + ".wqkv", w.numel * 4);
+            HIPCHK(hipMemcpyAsync(w.dev, wqk.dev, wqk.numel * 4, hipMemcpyDeviceToDevice, c->stream));
+            HIPCHK(hipMemcpyAsync((float*)w.dev + wqk.numel, wv.dev, wv.numel * 4, hipMemcpyDeviceToDevice, c->stream));
+            const Tensor& bqk = c->t(pre + ".bqk"); const Tensor& bv = c->t(pre + ".bv");
+            Tensor bb = bqk; bb.dims = {(int)(bqk.numel + bv.numel)}; bb.numel = bqk.numel + bv.numel; bb.host = nullptr;
+            bb.dev = c->buf(pre + ".bqkv", bb.numel * 4);
+            HIPCHK(hipMemcpyAsync(bb.dev, bqk.dev, bqk.numel * 4, hipMemcpyDeviceToDevice, c->stream));
+            HIPCHK(hipMemcpyAsync((float*)bb.dev + bqk.numel, bv.dev, bv.numel * 4, hipMemcpyDeviceToDevice, c->stream));
+            add.emplace_back(pre + ".wqkv", w); add.emplace_back(pre + ".bqkv", bb);
+        }
+        for (auto& kv : add) c->tensors[kv.first] = kv.second;
+    }
     // phoneme encoder (kept in f32 because it feeds discrete decisions): in bf16 mode its static-weight
     // GEMMs run on the bf16 MFMA as 3-plane split products (ops.hip: k_split3), f32-class accuracy at ~5x the f32 MFMA rate.
     // Weights [taps][N][K] -> bf16 [taps][N][wh | wl | wh], fragment-packed like every other slab-kernel weight.
@@ -410,6 +436,26 @@ void fft_block(zvx_ctx* c, void* x, int dt, int B, int Lmax, const int* len_dev,
         a.W = ws.dev; a.ldw = 3 * C; a.w_ts = (long)ws.dim(1) * 3 * C;
         a.flops = 2.0 * (double)a.M * a.nbatch * a.N * C * a.ntaps;                                 // algorithmic (f32) work, not the 3x issued
     };
+    // exact-f32 blocks with merged projection weights: one Q | K | V GEMM + one fused attention launch (attention.hip)
+    AttnF32Args af;
+    memset(&af, 0, sizeof af);
+    af.ld = 3 * H; af.bs = (long)Lmax * 3 * H; af.q_off = 0; af.k_off = H; af.v_off = 2 * H;
+    af.out = (float*)o; af.o_bs = (long)Lmax * H; af.ldo = H; af.len = len_dev; af.L = Lmax; af.D = d; af.nheads = nheads; af.nbatch = B;
+    af.scale = (float)(1.0 / pow((double)d, 0.5));
+    const bool fused_f32 = dt == DT_F32 && c->use_attn_f32 && c->has(w.p + ".wqkv") && launch_attention_f32(af, c->stream, true);
+    if (split) split_of((const float*)x, H, xs);
+    if (fused_f32) {
+        float* qkv = c->fbuf("fft.qkv", (size_t)B * Lmax * 3 * H);
+        GemmArgs a = gemm_base(dt);
+        a.X = x; a.x_bs = (long)Lmax * H; a.ldx = H; a.W = c->t(w.p + ".wqkv").dev; a.ldw = H;
+        a.M = Lmax; a.N = 3 * H; a.K = H; a.nbatch = B; a.in_len = len_dev; a.out_len = len_dev;
+        if (split) { as_split(a, xs, H, w.p + ".wqkv"); a.out_dtype = DT_F32; }
+        a.bias = c->pf(w.p + ".bqkv"); a.bias_mode = 1;
+        a.out = qkv; a.o_bs = (long)Lmax * 3 * H; a.ldo = 3 * H;
+        c->gemm(a);
+        af.qkv = qkv;
+        c->timed(4.0 * B * nheads * (double)Lmax * Lmax * d, (double)B * Lmax * 4.0 * H * 4, [&] { launch_attention_f32(af, c->stream, false); });
+    } else {
     if (split) split_of((const float*)x, H, xs);
     {   // [Q | K] = x Wqk^T + b                                       fs2.py:143-144
         GemmArgs a = gemm_base(dt);
@@ -462,6 +508,7 @@ void fft_block(zvx_ctx* c, void* x, int dt, int B, int Lmax, const int* len_dev,
         a.out = o; a.o_bs = (long)Lmax * H; a.o_hs = d; a.ldo = H;
         a.flops = 2.0 * B * nheads * (double)Lmax * Lmax * d;
         c->gemm(a);
+    }
     }
     }
     {   // y = fc(O) + residual                                         fs2.py:158-162
@@ -1314,6 +1361,7 @@ zvx_status zvx_set_int(zvx_ctx* c, const char* key, int64_t value) {
         else if (std::string(key) == "pairstream") c->use_pairstream = (int)value;
         else if (std::string(key) == "voc_chunk") c->voc_chunk = (int)value;
         else if (std::string(key) == "flash") c->use_flash = (int)value;
+        else if (std::string(key) == "attn_f32") c->use_attn_f32 = (int)value;
         else if (std::string(key) == "enc_split") c->enc_split = (c->dt == DT_BF16 && value && c->has("enc.0.wqk.s3")) ? 1 : 0;
         else if (std::string(key) == "rs_prof") c->rs_prof = (int)value;
         else if (std::string(key) == "rs_opt") c->rs_opt = (int)value;

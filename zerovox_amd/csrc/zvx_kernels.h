@@ -141,6 +141,14 @@ struct FlashArgs {
     float scale;                                         // 1 / sqrt(D)   (fs2.py:49-50)
 };
 bool launch_flash_attention(const FlashArgs& a, hipStream_t stream, bool dry_run);
+// exact-f32 fused attention of the phoneme encoder: Q | K | V columns of one projection buffer, head h at column off + h*D
+struct AttnF32Args {
+    const float* qkv; long bs; int ld; int q_off, k_off, v_off;   // [b][L][ld] f32
+    float* out; long o_bs; int ldo;                               // [b][L][ldo] f32, head h at column h*D
+    const int* len; int L, D, nheads, nbatch;
+    float scale;
+};
+bool launch_attention_f32(const AttnF32Args& a, hipStream_t stream, bool dry_run);   // timed through flash_profile_events
 void flash_profile_events(hipEvent_t start, hipEvent_t stop);
 
 // ------------------------------------------------------------------------------------------------
