@@ -400,7 +400,16 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(const AttnF32Args a) {
 #pragma unroll
         for (int e = 0; e < 16; e++) {
             const int r = 8 * (e >> 2) + 4 * kh + (e & 3), q = q0 + r;
-            if (q < a.L) op[(long)q * a.ldo + col] = q < len ? acc[e] * As[r] : 0.f;
+            if (q < a.L) {
+                const float val = q < len ? acc[e] * As[r] : 0.f;
+                op[(long)q * a.ldo + col] = val;
+                if (a.planes) {                                                     // [hi | hi | lo] bf16 planes for the output projection's split-product GEMM
+                    const unsigned short hi = __builtin_bit_cast(unsigned short, (__bf16)val);
+                    const unsigned short lo = __builtin_bit_cast(unsigned short, (__bf16)(val - __uint_as_float((unsigned)hi << 16)));
+                    unsigned short* const pp = a.planes + ((long)b * a.L + q) * 3 * a.planes_C + h * D + col;
+                    pp[0] = hi; pp[a.planes_C] = hi; pp[2 * a.planes_C] = lo;
+                }
+            }
         }
     };
     store_tile(o0, wave * 32 + l32);

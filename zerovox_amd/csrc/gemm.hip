@@ -461,9 +461,22 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs& a, f32x16 (&acc)[T
                     if (BURST) pk[j][p] = o;
                     else if (ok[p]) *(u32x4*)((unsigned short*)a.out + ooff + (long)r * a.ldo + n) = o;
                 } else if (ok[p]) {
-                    float* op = (float*)a.out + ooff + (long)r * a.ldo + n;
-                    *(float4*)op = make_float4(t[0].x, t[0].y, t[1].x, t[1].y);
-                    *(float4*)(op + 4) = make_float4(t[2].x, t[2].y, t[3].x, t[3].y);
+                    if (!CT && a.out_split3) {
+                        // bf16 split planes [hi | hi | lo] of the f32 result (ops.hip: split2), the operand layout of the next 3-plane GEMM
+                        unsigned short* op = (unsigned short*)a.out + ooff + (long)r * a.ldo + n;
+                        u32x4 hv, lv;
+#pragma unroll
+                        for (int e = 0; e < 4; e++) {
+                            const unsigned hp = pack_bf16x2(t[e].x, t[e].y);
+                            const f32x2 rem = t[e] - unpack_bf16x2(hp);
+                            hv[e] = hp; lv[e] = pack_bf16x2(rem.x, rem.y);
+                        }
+                        *(u32x4*)op = hv; *(u32x4*)(op + a.N) = hv; *(u32x4*)(op + 2 * a.N) = lv;
+                    } else {
+                        float* op = (float*)a.out + ooff + (long)r * a.ldo + n;
+                        *(float4*)op = make_float4(t[0].x, t[0].y, t[1].x, t[1].y);
+                        *(float4*)(op + 4) = make_float4(t[2].x, t[2].y, t[3].x, t[3].y);
+                    }
                 }
             }
         }
@@ -1571,6 +1584,7 @@ void gemm_profile_events(hipEvent_t start, hipEvent_t stop) { g_ev_start = start
 int launch_gemm(const GemmArgs& a, hipStream_t stream) {
     if (a.N <= 0 || a.M <= 0 || a.nbatch <= 0) return -1;
     if (a.ntaps < 1 || a.ntaps > ZVX_MAX_TAPS) return -2;
+    if (a.out_split3 && (a.out_dtype != DT_F32 || a.N % 8 || a.flat_win || a.wout > 0)) return -2;
     // N not a multiple of 4: the last 4-wide store spills into [N, roundup4(N)) of the row (ldo must cover it)
     if (a.N % 4 && (a.bias_mode == 1 || a.res_mode || a.accum_mode || a.post_scale || a.ldo < ((a.N + 3) & ~3))) return -2;
     if (a.Wp && a.dtype == DT_BF16 && a.wout > 0 && a.stride == 1 && a.ntaps == 9 && a.wout == a.win && a.M == a.hin * a.win && a.nheads == 1 && a.w_bs == 0 &&
@@ -1594,6 +1608,7 @@ int launch_gemm(const GemmArgs& a, hipStream_t stream) {
         for (int i = 0; i < a.ntaps; i++) { if (a.dv[i] < lo) lo = a.dv[i]; if (a.dv[i] > hi) hi = a.dv[i]; }
         if (hi - lo <= 64 && hi >= 0 && lo <= 0) return launch_convslab(a, stream);
     }
+    if (a.out_split3) return -2;                                // only the conv-slab epilogue (epilogue_rows) writes split planes
     // tile choice: padded N weighted by the tile's MFMA efficiency, ties -> wider BN
     static const int bns[3] = {128, 64, 32};
     static const double eff[3] = {1.0, 0.75, 0.45};

@@ -107,12 +107,16 @@ void launch_embed(const int* phoneme, const int* puncts, const float* emb, int e
 // ---------------------------------------------------------------- LayerNorm / SCLN, one wave per row
 __global__ void k_layernorm(const void* x, int xdt, int ldx, void* y, int ydt, int ldy, int rows_max, const int* rows,
                             int C, int mode, float eps, const float* gamma, const float* beta, const float* bg,
-                            long bg_bs, const float* post_add) {
+                            long bg_bs, const float* post_add, unsigned short* planes) {
     const int b = blockIdx.y;
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const int nr = rows ? rows[b] : rows_max;
-    if (r >= nr) return;
+    if (r >= nr) {
+        // planes: the [hi | hi | lo] bf16 split of the result for the next split-product GEMM (what k_split3 would write), zeros past the utterance
+        if (planes && r < rows_max) { unsigned short* o = planes + ((long)b * rows_max + r) * 3 * C; for (int c = lane; c < 3 * C; c += 64) o[c] = 0; }
+        return;
+    }
     const long xo = ((long)b * rows_max + r) * ldx, yo = ((long)b * rows_max + r) * ldy;
     float s = 0.f;
     for (int c = lane; c < C; c += 64) s += ld(x, xdt, xo + c);
@@ -130,13 +134,19 @@ __global__ void k_layernorm(const void* x, int xdt, int ldx, void* y, int ydt, i
         float v = (ld(x, xdt, xo + c) - mu) * inv * g + be;
         if (post_add) v += post_add[(long)b * C + c];
         st(y, ydt, yo + c, v);
+        if (planes) {
+            unsigned short hi, lo;
+            split2(v, hi, lo);
+            unsigned short* o = planes + ((long)b * rows_max + r) * 3 * C;
+            o[c] = hi; o[C + c] = hi; o[2 * C + c] = lo;
+        }
     }
 }
 void launch_layernorm(const void* x, int x_dt, int ldx, void* y, int y_dt, int ldy, int B, int rows_max,
                       const int* rows, int C, int mode, float eps, const float* gamma, const float* beta,
-                      const float* bg, long bg_bs, const float* post_add, hipStream_t s) {
+                      const float* bg, long bg_bs, const float* post_add, hipStream_t s, void* split_planes) {
     hipLaunchKernelGGL(k_layernorm, dim3((rows_max + 3) / 4, B), dim3(256), 0, s, x, x_dt, ldx, y, y_dt, ldy, rows_max,
-                       rows, C, mode, eps, gamma, beta, bg, bg_bs, post_add);
+                       rows, C, mode, eps, gamma, beta, bg, bg_bs, post_add, (unsigned short*)split_planes);
 }
 
 // ---------------------------------------------------------------- row softmax with key-length mask

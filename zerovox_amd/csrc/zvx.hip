@@ -85,6 +85,7 @@ struct zvx_ctx {
     int profile_only = -1;                 // >= 0: per-launch events only for this kernel variant (keeps the timed region lean)
     int rs_prof = 0;                       // zvx_set_int("rs_prof", 1): per-wave cycle counters of the streaming kernels (library built with -DRS_PROFILE)
     int enc_split = 0;                     // bf16 mode: the f32 GEMMs of the phoneme encoder / variance adaptor run as 3-plane bf16 GEMMs
+    const void* fft_xs_ready = nullptr;     // fft.xs holds the split planes of this buffer (written by the previous FFT block's last LayerNorm)
     int use_attn_f32 = 1;                  // zvx_set_int("attn_f32", 0): the encoder's attention as V^T / score / P.V GEMMs + softmax (A/B)
     int use_flash = 1;                     // zvx_set_int("flash", 0): the decoder's attention as score GEMM + softmax + PV GEMM (A/B)
     int voc_chunk = 0;                     // utterances per vocoder ResBlock sub-batch (0 = whole batch)
@@ -443,7 +444,11 @@ void fft_block(zvx_ctx* c, void* x, int dt, int B, int Lmax, const int* len_dev,
     af.out = (float*)o; af.o_bs = (long)Lmax * H; af.ldo = H; af.len = len_dev; af.L = Lmax; af.D = d; af.nheads = nheads; af.nbatch = B;
     af.scale = (float)(1.0 / pow((double)d, 0.5));
     const bool fused_f32 = dt == DT_F32 && c->use_attn_f32 && c->has(w.p + ".wqkv") && launch_attention_f32(af, c->stream, true);
-    if (split) split_of((const float*)x, H, xs);
+    // split planes of a GEMM input come from its PRODUCER where that is one of ours (LayerNorm, the fused attention, the k = 9
+    // convolution's epilogue); k_split3 runs only for the block input of the first layer and on the unfused attention path
+    const bool xs_from_producer = split && c->fft_xs_ready == x;
+    if (split && !xs_from_producer) split_of((const float*)x, H, xs);
+    c->fft_xs_ready = nullptr;
     if (fused_f32) {
         float* qkv = c->fbuf("fft.qkv", (size_t)B * Lmax * 3 * H);
         GemmArgs a = gemm_base(dt);
@@ -454,6 +459,7 @@ void fft_block(zvx_ctx* c, void* x, int dt, int B, int Lmax, const int* len_dev,
         a.out = qkv; a.o_bs = (long)Lmax * 3 * H; a.ldo = 3 * H;
         c->gemm(a);
         af.qkv = qkv;
+        if (split) { af.planes = (unsigned short*)xs; af.planes_C = H; }           // o as split planes for the output projection
         c->timed(4.0 * B * nheads * (double)Lmax * Lmax * d, (double)B * Lmax * 4.0 * H * 4, [&] { launch_attention_f32(af, c->stream, false); });
     } else {
     if (split) split_of((const float*)x, H, xs);
@@ -518,13 +524,13 @@ void fft_block(zvx_ctx* c, void* x, int dt, int B, int Lmax, const int* len_dev,
         a.bias = c->pf(w.p + ".bo"); a.bias_mode = 1;
         a.res = x; a.r_bs = (long)Lmax * H; a.ldr = H; a.res_mode = 1; a.res_dtype = dt;
         a.out = y; a.out_dtype = DT_F32; a.o_bs = (long)Lmax * H; a.ldo = H;
-        if (split) { split_of((const float*)o, H, xs); as_split(a, xs, H, w.p + ".wo"); }
+        if (split) { if (!fused_f32) split_of((const float*)o, H, xs); as_split(a, xs, H, w.p + ".wo"); }
         c->gemm(a);
     }
     const double ln_bytes = (double)B * Lmax * H * (4.0 + es);
     c->timed(0, ln_bytes, [&] {
         if (w.scln) launch_layernorm(y, DT_F32, H, x, dt, H, B, Lmax, len_dev, H, 1, 1e-8f, nullptr, nullptr, w.bg, w.bg_bs, nullptr, c->stream);
-        else launch_layernorm(y, DT_F32, H, x, dt, H, B, Lmax, len_dev, H, 0, 1e-5f, c->pf(w.p + ".ln1_g"), c->pf(w.p + ".ln1_b"), nullptr, 0, nullptr, c->stream);
+        else launch_layernorm(y, DT_F32, H, x, dt, H, B, Lmax, len_dev, H, 0, 1e-5f, c->pf(w.p + ".ln1_g"), c->pf(w.p + ".ln1_b"), nullptr, 0, nullptr, c->stream, split ? xs : nullptr);
     });
     {   // h = relu(conv_k9(x))                                         fs2.py:198-200
         GemmArgs a = gemm_base(dt);
@@ -533,7 +539,12 @@ void fft_block(zvx_ctx* c, void* x, int dt, int B, int Lmax, const int* len_dev,
         set_taps_1d(a, c->ffn_k0, 1);
         a.bias = c->pf(w.p + ".b1"); a.bias_mode = 1; a.act = ACT_RELU;
         a.out = hbuf; a.o_bs = (long)Lmax * F; a.ldo = F;
-        if (split) { split_of((const float*)x, H, xs); as_split(a, xs, H, w.p + ".w1"); a.out_dtype = DT_F32; }
+        void* hs = split ? c->buf("fft.hs", (size_t)B * Lmax * 3 * F * 2) : nullptr;
+        if (split) {
+            if (w.scln) split_of((const float*)x, H, xs);                           // (SCLN blocks are never f32 + split today; kept correct)
+            as_split(a, xs, H, w.p + ".w1");
+            a.out_dtype = DT_F32; a.out_split3 = 1; a.out = hs; a.o_bs = (long)Lmax * 3 * F; a.ldo = 3 * F;   // h straight into the planes of the k = 1 convolution
+        }
         c->gemm(a);
     }
     {   // y = conv_k1(h) + residual                                    fs2.py:201-207
@@ -544,13 +555,14 @@ void fft_block(zvx_ctx* c, void* x, int dt, int B, int Lmax, const int* len_dev,
         a.bias = c->pf(w.p + ".b2"); a.bias_mode = 1;
         a.res = x; a.r_bs = (long)Lmax * H; a.ldr = H; a.res_mode = 1; a.res_dtype = dt;
         a.out = y; a.out_dtype = DT_F32; a.o_bs = (long)Lmax * H; a.ldo = H;
-        if (split) { void* hs = c->buf("fft.hs", (size_t)B * Lmax * 3 * F * 2); split_of((const float*)hbuf, F, hs); as_split(a, hs, F, w.p + ".w2"); }
+        if (split) as_split(a, c->buf("fft.hs", (size_t)B * Lmax * 3 * F * 2), F, w.p + ".w2");
         c->gemm(a);
     }
     c->timed(0, ln_bytes, [&] {
         if (w.scln) launch_layernorm(y, DT_F32, H, x, dt, H, B, Lmax, len_dev, H, 1, 1e-8f, nullptr, nullptr, w.bg + 2 * H, w.bg_bs, w.post_add, c->stream);
-        else launch_layernorm(y, DT_F32, H, x, dt, H, B, Lmax, len_dev, H, 0, 1e-5f, c->pf(w.p + ".ln2_g"), c->pf(w.p + ".ln2_b"), nullptr, 0, w.post_add, c->stream);
+        else launch_layernorm(y, DT_F32, H, x, dt, H, B, Lmax, len_dev, H, 0, 1e-5f, c->pf(w.p + ".ln2_g"), c->pf(w.p + ".ln2_b"), nullptr, 0, w.post_add, c->stream, split ? xs : nullptr);
     });
+    if (split && !w.scln) c->fft_xs_ready = x;                                       // the next block on the same buffer finds its input planes in fft.xs
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -628,10 +640,12 @@ void run_encode(zvx_ctx* c, const int32_t* phoneme, const int32_t* puncts, const
     }
     float* x = c->fbuf("enc.x", nid * H);
     launch_embed(ph_d, pu_d, c->pf("enc.emb"), c->emb_dim, c->pf("enc.pemb"), c->punct_dim, pe, x, B, Tmax, T_d, c->stream);
+    c->fft_xs_ready = nullptr;
     for (int i = 0; i < c->enc_layers; i++) {
         FftWeights w{"enc." + std::to_string(i), false, nullptr, 0, (i == c->enc_layers - 1) ? spk_d : nullptr};   // + style (fs2.py:740-741)
         fft_block(c, x, DT_F32, B, Tmax, T_d, c->enc_heads, w);
     }
+    c->fft_xs_ready = nullptr;                                                                       // valid only between consecutive blocks of one stack
     c->stage_end(ZVX_T_ENCODER);
 
     c->stage_begin(ZVX_T_VARIANCE);

@@ -51,6 +51,7 @@ struct GemmArgs {
     // convolution over the FLATTENED map (tap offset du * win + dv): input row g is valid iff 0 <= g < flat_rows and
     // (g % flat_win) < in_len[z] (the columns of an utterance's true width); every output row of the map is written
     int flat_win, flat_rows;
+    int out_split3;            // f32 result written as bf16 split planes [hi | hi | lo] (row = 3 N, ldo elements apart): the input of the next 3-plane GEMM
     // epilogue: v = alpha*acc + bias; v += res; v += accum; [accum = v]; v *= out_scale; v = act(v);
     //           v = v*post_scale[n] + post_shift[n]; out = (T)v
     float alpha;
@@ -145,6 +146,7 @@ bool launch_flash_attention(const FlashArgs& a, hipStream_t stream, bool dry_run
 struct AttnF32Args {
     const float* qkv; long bs; int ld; int q_off, k_off, v_off;   // [b][L][ld] f32
     float* out; long o_bs; int ldo;                               // [b][L][ldo] f32, head h at column h*D
+    unsigned short* planes; int planes_C;                         // optional: the result also as bf16 split planes [hi | hi | lo], rows of 3 planes_C
     const int* len; int L, D, nheads, nbatch;
     float scale;
 };
@@ -172,7 +174,7 @@ void launch_embed(const int* phoneme, const int* puncts, const float* emb, int e
 // post_add [B][C] (may be NULL) is added after the affine (the style-embedding add, fs2.py:740-741).
 void launch_layernorm(const void* x, int x_dt, int ldx, void* y, int y_dt, int ldy, int B, int rows_max,
                       const int* rows, int C, int mode, float eps, const float* gamma, const float* beta,
-                      const float* bg, long bg_bs, const float* post_add, hipStream_t s);
+                      const float* bg, long bg_bs, const float* post_add, hipStream_t s, void* split_planes = nullptr);
 
 // scores [z][L][lds] f32 -> P (dtype) [z][L][ldp]: softmax over n < len[b]; zero-fill [len, roundup8(len))
 void launch_softmax_rows(const float* scores, int lds, void* P, int p_dt, int ldp, int nbatch, int nheads,
