@@ -1430,7 +1430,7 @@ int launch_resfuse(GemmArgs a, hipStream_t stream) {
             p.out = a.out; p.o_bs = a.o_bs; p.ldo = a.ldo;
             p.accum = a.accum; p.a_bs = a.a_bs; p.lda = a.lda; p.accum_mode = a.accum ? a.accum_mode : 0;
             p.slope1 = a.slope1; p.res_inv_slope = a.res_inv_slope; p.out_scale = a.out_scale; p.slope = a.act == ACT_LRELU ? a.slope : 1.f;
-            p.len = a.out_len; p.M = a.M; p.nbatch = a.nbatch; p.force = a.no_pairstream == 2;
+            p.len = a.out_len; p.M = a.M; p.nbatch = a.nbatch; p.force = a.no_pairstream >= 2 ? a.no_pairstream - 1 : 0;       // 2 -> force, 3 -> force with short segments
             if (launch_pairstream(p, stream, g_dry_run, g_dry_run ? nullptr : g_ev_start, g_ev_stop)) return 23;
         }
     }
@@ -1466,6 +1466,9 @@ static const Variant kVariants[] = {
 };
 const char* gemm_variant_name(int id) { return kVariants[id].name; }
 int gemm_num_variants() { return (int)(sizeof(kVariants) / sizeof(kVariants[0])); }
+
+static bool g_slab_small = true;                                  // zvx_set_int("slab_small", 0): no small-tile choice for single requests (A/B)
+void gemm_set_slab_small(int v) { g_slab_small = v != 0; }
 
 template <int BM, int BN, int WM, int WN, int MINW, int R, int EPI = -1>
 static void launch_slab_variant(const GemmArgs& a, dim3 grid, size_t lds, hipStream_t stream) {
@@ -1517,11 +1520,27 @@ static int launch_convslab(GemmArgs a, hipStream_t stream) {
         if (best_cost < 0 || cost < best_cost - 1e-9) { best_cost = cost; best = i; }
     }
     static const int bms[4] = {128, 256, 256, 256};
+    static int ncu = 0;
+    if (!ncu) { int dev = 0; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) ncu = 256; }
+    // single requests (a launch whose 256-row tiles would occupy a fraction of the CUs): 64- / 128-row tiles, 128 channels wide.  The
+    // K loop of a tile is the same whatever its shape, so results do not depend on this choice.
+    if (g_slab_small && a.M > 128 && a.N >= 128 && hl + hr <= 64) {
+        const long wg256 = (long)((a.N + 127) / 128) * ((a.M + 255) / 256) * a.nbatch;
+        if (wg256 * 2 <= ncu) {
+            const bool r64 = wg256 * 4 <= ncu;
+            const int bm = r64 ? 64 : 128;
+            dim3 gs(((a.N + 127) / 128) * ((a.M + bm - 1) / bm), a.nbatch);
+            size_t lds = ((size_t)(bm + hl + hr) * SLAB_PITCH + 1023) & ~(size_t)1023;
+            const size_t stage = (size_t)4 * 32 * (2 * 128 + 16);
+            if (lds < stage) lds = stage;
+            if (r64) launch_slab_variant<64, 128, 2, 2, 2, 0>(a, gs, lds, stream);
+            else launch_slab_variant<128, 128, 2, 2, 2, 0>(a, gs, lds, stream);
+            return 22;
+        }
+    }
     // short utterances (the phoneme encoder: M <= 128 rows each): 256-row tiles would be half empty.  128-row tiles, 128 or 256
     // channels wide, whichever puts more workgroups on the chip while it is not yet full
     if (a.M <= 128 && a.N >= 128) {
-        static int ncu = 0;
-        if (!ncu) { int dev = 0; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) ncu = 256; }
         const int wide = ((a.N + 255) / 256) * a.nbatch;
         const bool narrow = wide < 2 * ncu;
         const int bn = narrow ? 128 : 256;

@@ -466,7 +466,8 @@ bool launch_pairstream(PairArgs a, hipStream_t stream, bool dry_run, hipEvent_t 
     // pipeline fill per handful of steps -- measured crossover against the two conv-slab launches at ~3 utterances of 896 frames
     if (rows_all < (long)nwg * 768 && !a.force) return false;
     int S = (int)((rows_all + nwg - 1) / nwg);
-    if (S < 1024) S = 1024;
+    const int smin = a.force == 2 ? 256 : 1024;                                     // force == 2: two-block segments for single requests (A/B)
+    if (S < smin) S = smin;
     S = (S + PS_R - 1) / PS_R * PS_R;
     a.S = S; a.nseg = (a.M + S - 1) / S;
     if (dry_run) return true;

@@ -470,7 +470,13 @@ static bool launch_rs(StreamArgs& a, hipStream_t stream, bool dry_run) {
     const long rows_all = (long)a.M * a.nbatch;
     const int nwg = ncu();                                                          // one persistent workgroup per CU
     int S = (int)((rows_all + nwg - 1) / nwg);
-    if (S < 2048) S = 2048;
+    // pipeline fill and halo are paid per segment (~6 R + Hsum rows of extra work), so big jobs keep segments >= 2048 rows; a job
+    // that cannot fill the chip with those (single requests) takes shorter ones instead -- idle CUs cost more than redundant rows.
+    // The result does not depend on the segmentation (every row is computed from the same inputs in the same order).
+    if (S < 2048) {
+        const int floor_rows = a.seg_min > 0 ? a.seg_min : 256;                     // seg_min > 0: another floor; < 0: round 2's rule (A/B)
+        S = a.seg_min < 0 ? 2048 : (S < floor_rows ? floor_rows : S);
+    }
     S = (S + R - 1) / R * R;
     a.S = S; a.nseg = (a.M + S - 1) / S;
     const int nsegs = a.nseg * a.nbatch;

@@ -90,8 +90,9 @@ struct zvx_ctx {
     int use_flash = 1;                     // zvx_set_int("flash", 0): the decoder's attention as score GEMM + softmax + PV GEMM (A/B)
     int voc_chunk = 0;                     // utterances per vocoder ResBlock sub-batch (0 = whole batch)
     int use_resstream = 1;                 // zvx_set_int("resstream", 0): ResBlocks of the narrow stages as per-pair launches (A/B, bit-equal)
+    int rs_seg_min = 0;                    // zvx_set_int("rs_seg_min", -1): streaming ResBlock segments never shorter than 2048 rows (A/B of the single-request sizing)
     int rs_opt = 3;                        // zvx_set_int("rs_opt", v): StreamArgs.opt of the streaming ResBlock kernels (bit 0: staggered wave priorities)
-    int use_pairstream = 1;                // zvx_set_int("pairstream", v): C = 128 ResBlock pairs on pairstream.hip: 1 = every k (default; jobs under ~200 k rows run the bit-identical two-launch path), 3 = every k and every job size (tests), 2 = k >= 7 only (k = 3 on the register-resident resfuse kernel, which adds the running sum after rounding to bf16), 0 = none, -1 = no fused kernel at all for C = 128 (two conv-slab launches per pair: the bit-equality reference)
+    int use_pairstream = 1;                // zvx_set_int("pairstream", v): C = 128 ResBlock pairs on pairstream.hip: 1 = every k (default; jobs under ~200 k rows run the bit-identical two-launch path), 3 = every k and every job size (tests), 4 = like 3 with 256-row segments for small jobs, 2 = k >= 7 only (k = 3 on the register-resident resfuse kernel, which adds the running sum after rounding to bf16), 0 = none, -1 = no fused kernel at all for C = 128 (two conv-slab launches per pair: the bit-equality reference)
     int shape_log = 0;                     // zvx_set_int("shape_log", 1): one stderr line per timed launch (profile 2)
     int max_frames = 1 << 18;              // hard cap on a predicted mel length (guards the allocation, fs2.py:678-681 has none)
     hipEvent_t stage_ev[ZVX_T_COUNT][2];
@@ -949,7 +950,7 @@ void run_vocoder(zvx_ctx* c, const float* mel, int ldm, int Lmel_max, const int*
                             sa.b1[q] = c->pf(rb + ".c1_" + ts + "_b"); sa.b2[q] = c->pf(rb + ".c2_" + ts + "_b");
                             sa.dil[q] = dil[t0 + q];
                         }
-                        sa.opt = c->rs_opt;
+                        sa.opt = c->rs_opt; sa.seg_min = c->rs_seg_min;
                         if (c->rs_prof) sa.prof = (long long*)c->buf("rs.prof." + rb + "." + std::to_string(t0), 16 * 16 * 8);   // RS_PROFILE builds only
                         sa.slope1 = 0.1f; sa.res_inv_slope = 10.0f; sa.out_scale = 1.f; sa.slope = 0.1f;
                         sa.len = lens; sa.M = rows; sa.nbatch = Bs; sa.o_bs = (long)rows * Cout; sa.ldo = Cout; sa.a_bs = (long)rows * Cout; sa.lda = Cout;
@@ -1016,7 +1017,7 @@ void run_vocoder(zvx_ctx* c, const float* mel, int ldm, int Lmel_max, const int*
                             // one launch: xt = lrelu(c1(x_act)+b1) stays in LDS; x' = c2(xt) + b2 + x      hifigan.py:51-55
                             a.X = cur; a.W = w2.dev; a.Wp = c->packed[w2.dev]; a.Wp2 = c->packed[w1.dev];
                             a.bias1 = c->pf(rb + ".c1_" + ts + "_b"); a.slope1 = 0.1f; a.fused = 1;
-                            a.no_pairstream = (c->use_pairstream <= 0 || (c->use_pairstream == 2 && k == 3)) ? 1 : (c->use_pairstream == 3 ? 2 : 0);
+                            a.no_pairstream = (c->use_pairstream <= 0 || (c->use_pairstream == 2 && k == 3)) ? 1 : (c->use_pairstream == 3 ? 2 : (c->use_pairstream == 4 ? 3 : 0));
                             set_taps_1d(a, k, 1);
                             for (int q = 0; q < k; q++) a.dv1[q] = (q - (k - 1) / 2) * dil[t];
                             a.bias = c->pf(rb + ".c2_" + ts + "_b");
@@ -1028,7 +1029,7 @@ void run_vocoder(zvx_ctx* c, const float* mel, int ldm, int Lmel_max, const int*
                             // C = 128 with the pair kernel as the default: where it declines (small jobs), run the two conv-slab launches it
                             // is bit-identical to, not the register-resident pair kernel (k = 3), whose running-sum rounding differs --
                             // an utterance must come out the same alone and inside a large batch
-                            if ((c->use_pairstream == 1 || c->use_pairstream == 3) && Cout == 128 && fv != 23) fuse = false;
+                            if ((c->use_pairstream == 1 || c->use_pairstream >= 3) && Cout == 128 && fv != 23) fuse = false;
                         }
                         if (!fuse) {
                             // xt = c1(lrelu(x)); stored as lrelu(xt)                       hifigan.py:51-53
@@ -1379,6 +1380,8 @@ zvx_status zvx_set_int(zvx_ctx* c, const char* key, int64_t value) {
         else if (std::string(key) == "enc_split") c->enc_split = (c->dt == DT_BF16 && value && c->has("enc.0.wqk.s3")) ? 1 : 0;
         else if (std::string(key) == "rs_prof") c->rs_prof = (int)value;
         else if (std::string(key) == "rs_opt") c->rs_opt = (int)value;
+        else if (std::string(key) == "rs_seg_min") c->rs_seg_min = (int)value;
+        else if (std::string(key) == "slab_small") gemm_set_slab_small((int)value);
         else if (std::string(key) == "max_frames") { if (value < 1 || value > (1 << 24)) fail(ZVX_E_INVALID, "max_frames out of range"); c->max_frames = (int)value; }
         else fail(ZVX_E_INVALID, "unknown option '%s'", key);
     });

@@ -36,7 +36,7 @@ struct GemmArgs {
     int halo_l, halo_r;        // filled by the launcher
     // fused ResBlock1 pair (resfuse kernel): out = epilogue(conv2(lrelu(conv1(X) + bias1)) + bias + inverse_lrelu(X))
     const void* Wp2; const float* bias1; int dv1[ZVX_MAX_TAPS]; int fused; float slope1;   // conv1: Wp2/bias1/dv1 (dilated); conv2: Wp/bias/dv
-    int no_pairstream;         // fused: 1 = never the streaming pair kernel of pairstream.hip (A/B switch), 2 = use it even for small jobs (tests)
+    int no_pairstream;         // fused: 1 = never the streaming pair kernel of pairstream.hip (A/B switch), 2 = use it even for small jobs (tests), 3 = ... with 256-row segments
     int dtype;                 // DType of X and W (same)
     int M, N, K;               // M = max rows per z, N cols, K per tap (multiple of 8 elements bf16 / 4 f32)
     int nbatch, nheads;
@@ -72,6 +72,7 @@ struct GemmArgs {
 int launch_gemm(const GemmArgs& a, hipStream_t stream);
 // arm (or disarm with nullptrs) a pair of events that the NEXT launch_gemm / launch_resfuse dispatch carries as its own
 // start / stop timestamps (no marker packets on the stream)
+void gemm_set_slab_small(int v);                                  // 0: conv-slab launches keep 256-row tiles for single requests (A/B)
 void gemm_profile_events(hipEvent_t start, hipEvent_t stop);
 // the kernel variant launch_gemm / launch_resfuse would pick for these arguments (nothing is dispatched)
 int gemm_variant_of(const GemmArgs& a);
@@ -102,6 +103,7 @@ struct StreamArgs {
     int dX0, dT, dX[3];                            // filled by the launcher: ring sizes in rows
     double flops;                                  // filled by the launcher
     long long* prof;                               // RS_PROFILE builds: per-wave cycle counters of workgroup 0
+    int seg_min;                                   // 0: segments as short as 256 rows when the job cannot fill the chip; < 0: never below 2048 (A/B)
     int opt;                                       // bit 0: staggered wave priorities, bit 1: balanced role -> SIMD table (zvx_set_int("rs_opt", v): A/B switch)
 };
 // variant id (index into gemm_variant_name) or -1 when the shape is not covered; dry_run: decide only, launch nothing
@@ -122,7 +124,7 @@ struct PairArgs {
     void* accum; long a_bs; int lda; int accum_mode;   // bf16 running sum xs: bit0 v += xs, bit1 xs = v
     float slope1, res_inv_slope, out_scale, slope; // slope 1 = no output activation
     const int* len; int M, nbatch;
-    int force;                                     // 1: also for jobs below the size where the kernel pays (tests)
+    int force;                                     // 1: also for jobs below the size where the kernel pays (tests); 2: and with 256-row segments
     int S, nseg, DX, DT, G0;                       // filled by the launcher: segment rows, segments per utterance, ring rows
     long long* prof;                               // PS_PROFILE builds: [8 waves][main, epilogue, barrier, -] cycle totals of workgroup 0
 };
