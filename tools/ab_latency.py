@@ -25,9 +25,12 @@ for (B, P) in ((1, 448), (1, 1024), (2, 448), (4, 448)):
         if ref is None: ref = w
         print(f"vocoder B={B} P={P} {name:36s}: {np.median(ts):.3f} ms  bit-equal to the first: {np.array_equal(w, ref)}", flush=True)
 ph, pu, Tl, spk, dur = synthetic.batch(1, 64, 0, "const7"); pad = np.full(1, 448, np.int32)
+ref = None
 for name, sets in variants:
     for k, v in sets.items(): ctx.set_int(k, v)
-    for _ in range(3): ctx.synthesize(ph, pu, Tl, spk, dur, pad, want_mel=False)
+    for _ in range(3): r = ctx.synthesize(ph, pu, Tl, spk, dur, pad, want_mel=True)
+    if ref is None: ref = r
+    print(f"   mel / wav bit-equal to the first variant: {np.array_equal(r['mel'], ref['mel'])} / {np.array_equal(r['wav'], ref['wav'])}")
     t0 = time.time()
     for _ in range(30): ctx.synthesize(ph, pu, Tl, spk, dur, pad, want_mel=False)
     print(f"64-phoneme utterance, {name:36s}: {(time.time() - t0) / 30 * 1e3:.3f} ms per call (host wall, waveform to host)")

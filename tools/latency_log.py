@@ -8,6 +8,8 @@ cfg = zcfg.medium_modelcfg("styletts"); sd = zw.tts_state_dict(cfg, 0)
 h = zcfg.hifigan_config("v1"); hsd = zw.hifigan_state_dict(h, 0)
 man, blob = pack.pack_model(cfg, sd, h, hsd, "bf16")
 ctx = _lib.Context(man, blob, 0)
+for kv in sys.argv[2:]:
+    k, v = kv.split("="); ctx.set_int(k, int(v))
 ph, pu, Tl, spk, dur = synthetic.batch(1, T, 0, "const7")
 pad = np.full(1, 7 * T, np.int32)
 for _ in range(3): ctx.synthesize(ph, pu, Tl, spk, dur, pad, want_mel=False)
