@@ -11,8 +11,8 @@ man, blob = pack.pack_model(cfg, sd, h, hsd, "bf16")
 ctx = _lib.Context(man, blob, 0)
 rng = np.random.default_rng(2)
 variants = (("round-2 sizing", {"rs_seg_min": -1, "pairstream": 1, "slab_small": 0}), ("short resstream segments", {"rs_seg_min": 0, "pairstream": 1, "slab_small": 0}),
-            ("+ small conv-slab tiles", {"rs_seg_min": 0, "pairstream": 1, "slab_small": 1}),
-            ("+ pair kernel, 256-row segments", {"rs_seg_min": 0, "pairstream": 4, "slab_small": 1}))
+            ("+ small conv-slab tiles", {"rs_seg_min": 0, "pairstream": 1, "slab_small": 1}), ("+ 32-channel tiles for one-row-tile launches", {"rs_seg_min": 0, "pairstream": 1, "slab_small": 2}),
+            ("+ pair kernel, 256-row segments", {"rs_seg_min": 0, "pairstream": 4, "slab_small": 2}))
 for (B, P) in ((1, 448), (1, 1024), (2, 448), (4, 448)):
     mel = rng.standard_normal((B, P, 80)).astype(np.float32); L = np.full(B, P, np.int32)
     ref = None

@@ -1467,8 +1467,8 @@ static const Variant kVariants[] = {
 const char* gemm_variant_name(int id) { return kVariants[id].name; }
 int gemm_num_variants() { return (int)(sizeof(kVariants) / sizeof(kVariants[0])); }
 
-static bool g_slab_small = true;                                  // zvx_set_int("slab_small", 0): no small-tile choice for single requests (A/B)
-void gemm_set_slab_small(int v) { g_slab_small = v != 0; }
+static int g_slab_small = 2;                                      // zvx_set_int("slab_small", v): single-request tile choice: 0 none, 1 small row tiles, 2 + 32-channel tiles for one-row-tile launches (A/B)
+void gemm_set_slab_small(int v) { g_slab_small = v; }
 
 template <int BM, int BN, int WM, int WN, int MINW, int R, int EPI = -1>
 static void launch_slab_variant(const GemmArgs& a, dim3 grid, size_t lds, hipStream_t stream) {
@@ -1524,6 +1524,15 @@ static int launch_convslab(GemmArgs a, hipStream_t stream) {
     if (!ncu) { int dev = 0; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) ncu = 256; }
     // single requests (a launch whose 256-row tiles would occupy a fraction of the CUs): 64- / 128-row tiles, 128 channels wide.  The
     // K loop of a tile is the same whatever its shape, so results do not depend on this choice.
+    // a launch of ONE row tile and a handful of 128-channel tiles (a single request's encoder GEMMs): the workgroups stream their
+    // weights at the ~11 B/clk a CU sustains from HBM / Infinity Cache, so the launch is paced by how many CUs take part --
+    // 32-channel tiles put four times as many on the weight stream
+    if (g_slab_small >= 2 && a.M <= 64 && a.nbatch * ((a.N + 127) / 128) * 4 <= ncu && a.N >= 64 && hl + hr <= 64) {
+        dim3 g32((a.N + 31) / 32, a.nbatch);
+        const size_t lds32 = (((size_t)(256 + hl + hr) * SLAB_PITCH + 1023) & ~(size_t)1023) + (size_t)8 * 1024;
+        launch_slab_variant<256, 32, 4, 1, 2, 8>(a, g32, lds32, stream);
+        return 9;
+    }
     if (g_slab_small && a.M > 128 && a.N >= 128 && hl + hr <= 64) {
         const long wg256 = (long)((a.N + 127) / 128) * ((a.M + 255) / 256) * a.nbatch;
         if (wg256 * 2 <= ncu) {
@@ -1550,7 +1559,7 @@ static int launch_convslab(GemmArgs a, hipStream_t stream) {
         if (lds < stage) lds = stage;
         // fewer than two 128 x 128 workgroups per CU: 64-row tiles double the count, and the second workgroup of a CU is what
         // covers the first one's slab fills (these launches are latency-paced, not MFMA-paced)
-        if (narrow && a.M > 64 && ((a.N + 127) / 128) * a.nbatch < 2 * ncu) {
+        if (narrow && a.M > (g_slab_small ? 32 : 64) && ((a.N + 127) / 128) * a.nbatch < 2 * ncu) {   // (M <= 64 with half-empty 128-row tiles: single requests)
             dim3 g64(((a.N + 127) / 128) * ((a.M + 63) / 64), a.nbatch);
             launch_slab_variant<64, 128, 2, 2, 2, 0>(a, g64, lds, stream);
             return 22;

@@ -289,7 +289,28 @@ __global__ __launch_bounds__(256) void k_colstats(const void* x, int xdt, int ld
         }
     };
     if (cok && Wb > 0) load8(base + c0, sh);                  // shift = row 0 of this utterance (valid: Wb > 0)
-    if (cok)
+    if (cok && xdt == DT_BF16) {
+        // four rows of the thread in flight per iteration (same rows, same order of accumulation as the plain loop below); a single
+        // request would otherwise pay one memory round trip per row of its chain (14 for a 448-frame utterance)
+        const unsigned short* xp = (const unsigned short*)x + base + c0;
+        for (int hh = 0; hh < H; hh++)
+            for (int w = g; w < Wb; w += 128) {
+                uint4 t[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) { const int wu = w + 32 * u < Wb ? w + 32 * u : w; t[u] = *(const uint4*)(xp + ((long)hh * Wmax + wu) * ldx); }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    if (w + 32 * u >= Wb) break;
+                    float v[8];
+                    v[0] = __uint_as_float(t[u].x << 16); v[1] = __uint_as_float(t[u].x & 0xffff0000u);
+                    v[2] = __uint_as_float(t[u].y << 16); v[3] = __uint_as_float(t[u].y & 0xffff0000u);
+                    v[4] = __uint_as_float(t[u].z << 16); v[5] = __uint_as_float(t[u].z & 0xffff0000u);
+                    v[6] = __uint_as_float(t[u].w << 16); v[7] = __uint_as_float(t[u].w & 0xffff0000u);
+#pragma unroll
+                    for (int e = 0; e < 8; e++) { const float d = v[e] - sh[e]; s1[e] += d; s2[e] += d * d; }
+                }
+            }
+    } else if (cok)
         for (int hh = 0; hh < H; hh++)
             for (int w = g; w < Wb; w += 32) {
                 float v[8];
@@ -382,6 +403,33 @@ __global__ __launch_bounds__(256) void k_norm_affine_act(const void* x, int xdt,
         sc[e] = r * g; sh[e] = be - m * r * g;                // (x - m) * r * g + be
     }
     const int lend = (l0 + 64 < Lb) ? l0 + 64 : Lb;
+    if (xdt == DT_BF16 && ydt == DT_BF16) {
+        // bf16 -> bf16 (the decoder's InstanceNorm / AdaIN passes): four rows of the wave in flight per iteration.  Neutral at batch 32
+        // (the pass is bandwidth-bound there); a single request runs 16 dependent row round trips per wave otherwise.
+        const unsigned short* xp = (const unsigned short*)x + (long)b * Lmax * ldx + c;
+        unsigned short* yp = (unsigned short*)y + (long)b * Lmax * ldy + c;
+        for (int l = l0 + (threadIdx.x >> 6); l < lend; l += 16) {
+            uint4 t[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) { const int lu = l + 4 * u < lend ? l + 4 * u : l; t[u] = *(const uint4*)(xp + (long)lu * ldx); }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                if (l + 4 * u >= lend) break;
+                float v[8];
+                v[0] = __uint_as_float(t[u].x << 16); v[1] = __uint_as_float(t[u].x & 0xffff0000u);
+                v[2] = __uint_as_float(t[u].y << 16); v[3] = __uint_as_float(t[u].y & 0xffff0000u);
+                v[4] = __uint_as_float(t[u].z << 16); v[5] = __uint_as_float(t[u].z & 0xffff0000u);
+                v[6] = __uint_as_float(t[u].w << 16); v[7] = __uint_as_float(t[u].w & 0xffff0000u);
+#pragma unroll
+                for (int e = 0; e < 8; e++) v[e] = act_apply(v[e] * sc[e] + sh[e], act, slope);
+                uint4 o;
+                o.x = (unsigned)tobf(v[0]) | ((unsigned)tobf(v[1]) << 16); o.y = (unsigned)tobf(v[2]) | ((unsigned)tobf(v[3]) << 16);
+                o.z = (unsigned)tobf(v[4]) | ((unsigned)tobf(v[5]) << 16); o.w = (unsigned)tobf(v[6]) | ((unsigned)tobf(v[7]) << 16);
+                *(uint4*)(yp + (long)(l + 4 * u) * ldy) = o;
+            }
+        }
+        return;
+    }
     for (int l = l0 + (threadIdx.x >> 6); l < lend; l += 4) {
         const long xo = ((long)b * Lmax + l) * ldx + c, yo = ((long)b * Lmax + l) * ldy + c;
         float v[8];
