@@ -601,6 +601,55 @@ def test_streaming_resblock_kernels_equal_per_pair_launches(voc):
         ctx.set_int("resstream", 1)
 
 
+def test_fused_f32_attention_of_the_encoder_matches_the_unfused_products():
+    """attention.hip: attn_f32_kernel (one Q|K|V GEMM + one launch per layer) against V^T / score / P.V GEMMs + softmax: f32
+    round-off apart (different summation order), for ragged batches, one key, T just over one / four 128-key tiles; and an
+    utterance's encoder output does not depend on the batch it travels in (fixed key tiles masked by its own length)."""
+    for prec in ("bf16", "f32"):
+        ctx = ctx_for("styletts", "tiny", prec)
+        rng = np.random.default_rng(3)
+        try:
+            for (B, Tmax) in ((1, 1), (3, 33), (4, 128), (3, 129), (1, 530)):
+                ph, pu, T, spk, dur = synthetic.batch(B, Tmax, 11, "const7")
+                T = rng.integers(1, Tmax + 1, B).astype(np.int32); T[0] = Tmax
+                for b in range(B):
+                    ph[b, T[b]:] = 0; pu[b, T[b]:] = 0; dur[b, T[b]:] = 0
+                outs = {}
+                for mode in (0, 1):
+                    ctx.set_int("attn_f32", mode)
+                    ctx.encode(ph, pu, T, spk, dur)
+                    outs[mode] = ctx.fetch("encoder_out", (B, Tmax, 528)).copy()
+                assert np.isfinite(outs[1]).all()
+                for b in range(B):
+                    assert np.abs(outs[0][b, :T[b]] - outs[1][b, :T[b]]).max() <= 2e-4 * max(1.0, np.abs(outs[0]).max()), (prec, B, Tmax, b)
+                ctx.encode(ph[:1], pu[:1], T[:1], spk[:1], dur[:1])
+                assert np.array_equal(ctx.fetch("encoder_out", (1, Tmax, 528))[0, :T[0]], outs[1][0, :T[0]]), (prec, B, Tmax)
+        finally:
+            ctx.set_int("attn_f32", 1)
+
+
+def test_single_request_sizing_does_not_change_a_bit():
+    """A single request takes shorter streaming-ResBlock segments, 64- / 128-row conv-slab tiles and 32-channel tiles for its
+    one-row-tile GEMMs (zvx_set_int rs_seg_min / slab_small; the pair kernel declines it): launch geometry only -- the utterance
+    is bit-identical to itself computed with the batch geometry, alone and inside a batch of 5."""
+    ctx = ctx_for("styletts", "v1", "bf16")
+    ph, pu, T, spk, dur = synthetic.batch(5, 64, 7, "const7")
+    pad = np.full(5, 448, np.int32)
+    try:
+        ctx.set_int("rs_seg_min", -1); ctx.set_int("slab_small", 0)
+        ref1 = ctx.synthesize(ph[:1], pu[:1], T[:1], spk[:1], dur[:1], pad[:1], want_mel=True)
+        ref5 = ctx.synthesize(ph, pu, T, spk, dur, pad, want_mel=True)
+        assert np.array_equal(ref1["wav"][0], ref5["wav"][0])
+        for seg, small in ((0, 1), (0, 2), (512, 2)):
+            ctx.set_int("rs_seg_min", seg); ctx.set_int("slab_small", small)
+            one = ctx.synthesize(ph[:1], pu[:1], T[:1], spk[:1], dur[:1], pad[:1], want_mel=True)
+            five = ctx.synthesize(ph, pu, T, spk, dur, pad, want_mel=True)
+            assert np.array_equal(one["mel"], ref1["mel"]) and np.array_equal(one["wav"], ref1["wav"]), (seg, small)
+            assert np.array_equal(five["mel"], ref5["mel"]) and np.array_equal(five["wav"], ref5["wav"]), (seg, small)
+    finally:
+        ctx.set_int("rs_seg_min", 0); ctx.set_int("slab_small", 2)
+
+
 def test_benchmark_batch_is_bit_reproducible_over_many_runs():
     """The hand-scheduled kernels count their outstanding loads (s_waitcnt vmcnt(n)): an off-by-one is a RARE wrong block, not a
     wrong result every time (round 3: the k = 3 pair kernel let one LDS-DMA piece outlive the step barrier, a wrong 128-row
