@@ -84,64 +84,72 @@ __device__ __forceinline__ int prio_of_wave(int w, bool balanced) {
 
 // DP: the dilations of the conv1 roles, one hex digit per pair (0x531 = 1, 3, 5): with the dilation a compile-time constant the
 // row offset of every tap is an immediate of its ds_read_b128 and the MFMA loop carries no address arithmetic at all.
-template <int C, int NT, int NPAIR, int RSPLIT, int AM, bool HAS_OUT, int DP>
-__global__ __launch_bounds__(128 * NPAIR * (C / 32) * RSPLIT) void resstream_kernel(const StreamArgs a) {
+// ring geometry of a chain: compile-time (kernel) and launch-time (LDS size, shape checks) from the same formulas
+template <int C, int NT, int NPAIR, int RSPLIT, int DP>
+struct RsGeom {
+    static constexpr int R = 32 * RSPLIT, H2 = (NT - 1) / 2;
+    static constexpr int dil(int p) { return (DP >> (4 * p)) & 15; }
+    static constexpr int h0 = dil(0) * H2;
+    static constexpr int dT = 2 * R + 2 * H2;                                                   // T rings: two blocks + conv2's halo
+    static constexpr int dX0 = (((RS_PF + 2) * R + RS_RD + h0 + H2 + 2 * h0) + RS_RD - 1) / RS_RD * RS_RD;   // covers the DMA lead, whole 64-row blocks
+    static constexpr int dX(int p) {                                                            // X rings of the later pairs (also re-read as residual)
+        return p == 0 ? 0 : (2 * R + 2 * dil(p) * H2 > 3 * R + dil(p) * H2 + H2 ? 2 * R + 2 * dil(p) * H2 : 3 * R + dil(p) * H2 + H2);
+    }
+};
+
+// One role of the chain.  Everything that depends on the role -- which convolution, its dilation, its rings and their sizes, whether it
+// issues the DMA or owns the store phase -- is a compile-time constant here: the step loop of a generic body spent as many scalar
+// instructions on that bookkeeping (66 per step and wave) as vector instructions on the epilogue (76), and a SIMD issues about one
+// instruction per 4 cycles whatever its kind (SQ_ACTIVE_INST_ANY ~ 90 % of the kernel's cycles on the narrow stages).
+template <int C, int NT, int NPAIR, int RSPLIT, int AM, bool HAS_OUT, int DP, int ROLE>
+__device__ __forceinline__ void rs_role(const StreamArgs& a, unsigned char* const lds, const int lane, const int sub, const int wave) {
+    using G = RsGeom<C, NT, NPAIR, RSPLIT, DP>;
     constexpr int NR = 2 * NPAIR, NTL = C / 32, WPR = NTL * RSPLIT;
     constexpr int R = 32 * RSPLIT, KS = C / 16, P = 2 * C + 16, CPP = C / 8 + 1, H2 = (NT - 1) / 2, NW = NT * KS;
     constexpr int PPB = CPP;                        // 1-KiB DMA pieces per 64-row block (64 rows x CPP 16-byte slots / 64 lanes)
     constexpr int PPW = (PPB + WPR - 1) / WPR;      // pieces per issuing wave and block (surplus ones repeat the last piece)
     constexpr int NKC = (C + 63) / 64;
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    int role, sub;
-    role_of_wave<NR, WPR>(wave, role, sub, (a.opt & 2) != 0);
-    role = __builtin_amdgcn_readfirstlane(role); sub = __builtin_amdgcn_readfirstlane(sub);
-    const int pair = role >> 1, kind = role & 1;
+    constexpr int role = ROLE, pair = ROLE >> 1, kind = ROLE & 1;
     const int ct = sub % NTL, rs = sub / NTL;
     const int l32 = lane & 31, koff = (lane >> 5) * 16, h4 = 4 * (lane >> 5);
-    const bool is_final = role == NR - 1;
-    if (a.opt & 1) {
-        const int pr = __builtin_amdgcn_readfirstlane(prio_of_wave<NR, WPR>(wave, (a.opt & 2) != 0));
-        if (pr == 3) __builtin_amdgcn_s_setprio(3); else if (pr == 2) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(1);
-    }
+    constexpr bool is_final = ROLE == NR - 1;
 
     // ---- chain geometry (wave-uniform) ----
     int my_h = 0, my_H = 0, Hsum = 0;
 #pragma unroll
     for (int r = 0; r < NR; r++) {
-        const int h = (r & 1) ? H2 : a.dil[r >> 1] * H2;
+        const int h = (r & 1) ? H2 : G::dil(r >> 1) * H2;
         Hsum += h;
         if (r <= role) my_H += h;
         if (r == role) my_h = h;
     }
-    const int h0 = a.dil[0] * H2;
-    const int my_dil = kind ? 1 : a.dil[pair];
+    const int h0 = G::dil(0) * H2;
+    const int my_dil = kind ? 1 : G::dil(pair);
     const int NB0 = (Hsum + R - 1) / R;
     // LDS map: X0 | T0 | X1 | T1 | X2 | T2 | stage (final role) | bias table
-    int offX = 0, offT = 0, dXp = a.dX0, offXn = 0, dXn = 0;
+    int offX = 0, offT = 0, dXp = G::dX0, offXn = 0, dXn = 0;
     {
-        int cur = a.dX0 * P;
+        int cur = G::dX0 * P;
 #pragma unroll
         for (int p = 0; p < NPAIR; p++) {
             if (p == pair) offT = cur;
-            cur += a.dT * P;
+            cur += G::dT * P;
             if (p + 1 < NPAIR) {
-                if (p + 1 == pair) { offX = cur; dXp = a.dX[p + 1]; }
-                if (p == pair) { offXn = cur; dXn = a.dX[p + 1]; }
-                cur += a.dX[p + 1] * P;
+                if (p + 1 == pair) { offX = cur; dXp = G::dX(p + 1); }
+                if (p == pair) { offXn = cur; dXn = G::dX(p + 1); }
+                cur += G::dX(p + 1) * P;
             }
         }
         offXn = __builtin_amdgcn_readfirstlane(offXn); offX = __builtin_amdgcn_readfirstlane(offX); offT = __builtin_amdgcn_readfirstlane(offT);
         dXp = __builtin_amdgcn_readfirstlane(dXp); dXn = __builtin_amdgcn_readfirstlane(dXn);
     }
-    int ring_end = a.dX0 * P + NPAIR * a.dT * P;
+    int ring_end = G::dX0 * P + NPAIR * G::dT * P;
 #pragma unroll
-    for (int p = 1; p < NPAIR; p++) ring_end += a.dX[p] * P;
+    for (int p = 1; p < NPAIR; p++) ring_end += G::dX(p) * P;
     unsigned char* const stw = lds + ring_end + sub * (32 * 80);                  // final role, per wave: 32 rows x 32 ch bf16, pitch 80
     // rings of this role
-    const int in_off = kind ? offT : offX, Din = kind ? a.dT : dXp;               // operand source
-    const int out_off = kind ? offXn : offT, Dout = kind ? dXn : a.dT;            // destination ring (unused by the final role)
+    const int in_off = kind ? offT : offX, Din = kind ? G::dT : dXp;               // operand source
+    const int out_off = kind ? offXn : offT, Dout = kind ? dXn : G::dT;            // destination ring (unused by the final role)
     const int res_off = offX, Dres = dXp;                                         // conv2: residual source = the pair's input stream
 
     // ---- this wave's weights: conv1 <- W1[pair], conv2 <- W2[pair]; packed stream [nt32][chunk][tap][4 k16 slots], 1 KiB fragments ----
@@ -164,7 +172,7 @@ __global__ __launch_bounds__(128 * NPAIR * (C / 32) * RSPLIT) void resstream_ker
 
     // ---- DMA lane offsets (role 0): piece j of a 64-row block = 16-byte slots [64 j, 64 j + 64) of its padded LDS image ----
     const unsigned lds_addr0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;
-    const int nslots = a.dX0 / RS_RD;                                              // DMA blocks the X0 ring holds
+    const int nslots = G::dX0 / RS_RD;                                              // DMA blocks the X0 ring holds
     int dma_off[PPW];                                                              // byte offset of this lane's 16 bytes within a DMA block, per piece; pad slot: out of range -> zeros
 #pragma unroll
     for (int n = 0; n < PPW; n++) {
@@ -199,7 +207,7 @@ __global__ __launch_bounds__(128 * NPAIR * (C / 32) * RSPLIT) void resstream_ker
         // ring positions at this role's first block (independent of seg0: every segment starts from the same image)
         int rd_pos = role == 0 ? rs * 32 : (Din - 2 * my_h + rs * 32) % Din;
         int wr_pos = rs * 32;
-        int rs_pos = pair == 0 ? (h0 - H2 + rs * 32) : ((Dres - (a.dil[pair] * H2 + H2) % Dres + rs * 32) % Dres);
+        int rs_pos = pair == 0 ? (h0 - H2 + rs * 32) : ((Dres - (G::dil(pair) * H2 + H2) % Dres + rs * 32) % Dres);
         int g_out0 = seg0 - NB0 * R - my_H + rs * 32;                              // global row of this wave's first output row
         f32x16 acc;
 
@@ -438,6 +446,27 @@ __global__ __launch_bounds__(128 * NPAIR * (C / 32) * RSPLIT) void resstream_ker
 #endif
 }
 
+template <int C, int NT, int NPAIR, int RSPLIT, int AM, bool HAS_OUT, int DP>
+__global__ __launch_bounds__(128 * NPAIR * (C / 32) * RSPLIT) void resstream_kernel(const StreamArgs a) {
+    constexpr int NR = 2 * NPAIR, NTL = C / 32, WPR = NTL * RSPLIT;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int role, sub;
+    role_of_wave<NR, WPR>(wave, role, sub, (a.opt & 2) != 0);
+    role = __builtin_amdgcn_readfirstlane(role); sub = __builtin_amdgcn_readfirstlane(sub);
+    if (a.opt & 1) {
+        const int pr = __builtin_amdgcn_readfirstlane(prio_of_wave<NR, WPR>(wave, (a.opt & 2) != 0));
+        if (pr == 3) __builtin_amdgcn_s_setprio(3); else if (pr == 2) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(1);
+    }
+    if (role == 0) rs_role<C, NT, NPAIR, RSPLIT, AM, HAS_OUT, DP, 0>(a, lds, lane, sub, wave);
+    else if (role == 1) rs_role<C, NT, NPAIR, RSPLIT, AM, HAS_OUT, DP, 1>(a, lds, lane, sub, wave);
+    else if (NR > 2 && role == 2) rs_role<C, NT, NPAIR, RSPLIT, AM, HAS_OUT, DP, (NR > 2 ? 2 : 0)>(a, lds, lane, sub, wave);
+    else if (NR > 2 && role == 3) rs_role<C, NT, NPAIR, RSPLIT, AM, HAS_OUT, DP, (NR > 2 ? 3 : 1)>(a, lds, lane, sub, wave);
+    else if (NR > 4 && role == 4) rs_role<C, NT, NPAIR, RSPLIT, AM, HAS_OUT, DP, (NR > 4 ? 4 : 0)>(a, lds, lane, sub, wave);
+    else if (NR > 4) rs_role<C, NT, NPAIR, RSPLIT, AM, HAS_OUT, DP, (NR > 4 ? 5 : 1)>(a, lds, lane, sub, wave);
+}
+
 // ------------------------------------------------------------------------------------------------
 // launcher
 // ------------------------------------------------------------------------------------------------
@@ -450,19 +479,17 @@ static int ncu() {
 template <int C, int NT, int NPAIR, int RSPLIT, int DP>
 static bool launch_rs(StreamArgs& a, hipStream_t stream, bool dry_run) {
     constexpr int NTL = C / 32, WPR = NTL * RSPLIT, R = 32 * RSPLIT, P = 2 * C + 16, H2 = (NT - 1) / 2, NR = 2 * NPAIR;
-    // ring sizes (rows): see the header comment; X0 also covers the DMA lead and holds whole 64-row DMA blocks
-    const int h0 = a.dil[0] * H2;
+    // ring sizes (rows): see the header comment and RsGeom (the kernel uses the same compile-time values)
+    using G = RsGeom<C, NT, NPAIR, RSPLIT, DP>;
+    for (int p = 0; p < NPAIR; p++) if (a.dil[p] != G::dil(p)) return false;
+    const int h0 = G::h0;
     if (2 * h0 + R > 4 * RS_RD) return false;                                       // DMA lead assumed <= 4 blocks in flight
     for (int p = 0; p < NPAIR; p++) if (a.dil[p] * H2 + H2 > R) return false;       // the residual rows of a block lie within the producer's last two blocks
-    a.dT = 2 * R + 2 * H2;
-    a.dX0 = (((RS_PF + 2) * R + RS_RD + h0 + H2 + 2 * h0) + RS_RD - 1) / RS_RD * RS_RD;
+    a.dT = G::dT;
+    a.dX0 = G::dX0;
     size_t rows = a.dX0 + (size_t)NPAIR * a.dT;
     a.dX[0] = 0;
-    for (int p = 1; p < NPAIR; p++) {
-        const int h1 = a.dil[p] * H2;
-        a.dX[p] = std::max(2 * R + 2 * h1, 3 * R + h1 + H2);
-        rows += a.dX[p];
-    }
+    for (int p = 1; p < NPAIR; p++) { a.dX[p] = G::dX(p); rows += a.dX[p]; }
     const size_t lds = rows * P + (size_t)WPR * 32 * 80 + (size_t)NR * C * 4;
     if (lds > 160 * 1024) return false;
     // segments: about one per CU, never shorter than 2048 rows (pipeline fill and halo are paid per segment)
