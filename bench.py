@@ -236,6 +236,7 @@ def main(argv=None, ctx_factory=default_ctx_factory):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--exact-encoder", action="store_true", help="bf16 mode: phoneme encoder on the exact-f32 MFMA instead of 3-plane bf16 split products (bucket ids / durations bit-equal to the f32 path)")
     ap.add_argument("--host-out", action="store_true", help="config 2: deliver every step's waveform to host memory (D2H copy inside the timed region), as the reference's tts_ex does")
+    ap.add_argument("--in-flight", type=int, default=1, help="config 2, one GPU: steps alternate over this many contexts (each its own stream): batch i+1's latency-paced encoder / decoder run under batch i's vocoder")
     ap.add_argument("--profile", type=int, default=2, help="0 none, 1 stage events, 2 + per-launch events on the dominant kernel")
     args = ap.parse_args(argv)
 
@@ -265,6 +266,7 @@ def main(argv=None, ctx_factory=default_ctx_factory):
         ctx.comm_init(None, 0, 1)
 
     T = args.phonemes
+    more_ctx = []                                    # --in-flight: (context, [wav buffers]) beyond the first
     ss = 2 if args.pcm16 else 4
     wdt = np.int16 if args.pcm16 else np.float32
     if args.config == 2:
@@ -280,12 +282,26 @@ def main(argv=None, ctx_factory=default_ctx_factory):
 
         host_wav = [None]
 
+        # --in-flight n (one GPU): n - 1 further contexts, each with its own stream and work buffers; steps go round robin, every step
+        # is still one whole batch and all of them are complete at the closing fence
+        if args.in_flight > 1 and (world > 1 or args.host_out):
+            raise SystemExit("--in-flight > 1 is a one-GPU, device-output mode")
+        for _ in range(max(1, args.in_flight) - 1):
+            c2, _m = ctx_factory(args, local_rank)
+            if args.exact_encoder:
+                c2.set_int("enc_split", 0)
+            c2.comm_init(None, 0, 1)
+            more_ctx.append((c2, [c2.dev_alloc(B * row_bytes) for _ in range(2)]))
+
         def step():
             if args.host_out:                           # the reference's contract: tts_ex returns host NumPy (synthesize.py:233-239)
                 host_wav[0] = ctx.synthesize(ph, pu, Tlen, spk, dur, pad_to, want_mel=False, pcm16=args.pcm16)["wav"]
                 return
-            buf = wav[it[0] & 1]; it[0] += 1
-            ctx.synthesize(ph, pu, Tlen, spk, dur, pad_to, want_mel=False, wav_device_ptr=buf, wav_stride=N, no_sync=True, pcm16=args.pcm16)
+            i = it[0]; it[0] += 1
+            nf = 1 + len(more_ctx)
+            c, bufs = (ctx, wav) if i % nf == 0 else more_ctx[i % nf - 1]
+            buf = bufs[(i // nf) & 1]
+            c.synthesize(ph, pu, Tlen, spk, dur, pad_to, want_mel=False, wav_device_ptr=buf, wav_stride=N, no_sync=True, pcm16=args.pcm16)
             if world > 1:
                 ctx.comm_gather(buf, B * row_bytes, gathered, root=0, no_sync=True)
         workload = (f"batch={B}/GPU x {T}-phoneme utterances, precomputed spk-embed, forced durations=7 -> {L} frames -> {N} samples each; "
@@ -295,6 +311,7 @@ def main(argv=None, ctx_factory=default_ctx_factory):
                      "vocoder": args.vocoder, "pad_to": int(pad_to[0]), "wav_dtype": "int16" if args.pcm16 else "f32",
                      "encoder_arithmetic": ("exact f32 MFMA" if (args.exact_encoder or args.precision == "f32") else
                                             "3-plane bf16 split products (f32-class: 5e-5 on the encoder output; --exact-encoder for bit-equal discrete decisions)"),
+                     "in_flight": max(1, args.in_flight),
                      "wav_delivery": "host (synchronous D2H copy of every step's waveform inside the timed region)" if args.host_out else
                                      "device (rows stay in HBM for the gather / the caller; --host-out times the D2H copy too)"}
     elif args.config == 4:
@@ -326,6 +343,8 @@ def main(argv=None, ctx_factory=default_ctx_factory):
         cfg_extra = {"global_batch": B, "ref_frames": Tr}
 
     def fence():
+        for c2, _b in more_ctx:
+            c2.comm_barrier()
         ctx.comm_barrier()                            # drains both streams of every rank, then all ranks arrive (world 1: just the drain)
 
     for _ in range(args.warmup):
@@ -369,7 +388,7 @@ def main(argv=None, ctx_factory=default_ctx_factory):
     else:
         if world > 1 and rank == 0:
             g = ctx.dev_to_host(gathered, (world * B, N), wdt)
-            own = ctx.dev_to_host(wav[(it[0] - 1) & 1], (B, N), wdt)
+            own = ctx.dev_to_host(wav[(it[0] - 1) & 1], (B, N), wdt)           # (world > 1 runs one context: it[0] counts its steps)
             ok = bool(np.array_equal(g[:B], own)) and all(bool(np.abs(g[r * B:(r + 1) * B].astype(np.float32)).max() > 0) for r in range(world))
         else:
             ok = True

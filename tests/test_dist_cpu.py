@@ -180,6 +180,35 @@ def test_bench_control_flow_world2_with_stub_context():
     assert r["higher_is_better"] is True and r["vs_baseline"] is None
 
 
+def test_bench_in_flight_two_contexts_round_robin(capsys):
+    """bench.py --in-flight 2 (one GPU): steps alternate over two contexts, each double-buffers its own waveform rows, every
+    context is fenced, and the line counts every step once; with more than one rank the option is refused."""
+    import bench
+    from zerovox_amd import config as zcfg
+    made = []
+
+    def factory(args, local_rank):
+        c = StubContext(); c._first = 0
+        made.append(c)
+        return c, (zcfg.medium_modelcfg("styletts"), None, None, None)
+
+    old = {k: os.environ.pop(k, None) for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    try:
+        rc = bench.main(["--in-flight", "2", "--steps", "4", "--warmup", "2", "--batch", "4", "--phonemes", "8", "--profile", "0", "--no-cpu-baseline"],
+                        ctx_factory=factory)
+    finally:
+        os.environ.update({k: v for k, v in old.items() if v is not None})
+    assert rc == 0 and len(made) == 2
+    a = [c[1] for c in made[0].calls if c[0] == "synthesize"]
+    b = [c[1] for c in made[1].calls if c[0] == "synthesize"]
+    assert len(a) == 3 and len(b) == 3                      # 6 steps, round robin
+    assert a[0] != a[1] and a[0] == a[2] and b[0] != b[1]   # each context alternates between ITS two buffers
+    r = json.loads([l for l in capsys.readouterr().out.splitlines() if l.strip()][-1])
+    assert r["steps"] == 4 and r["config"]["in_flight"] == 2 and r["output_ok"] is True
+    total = 4 * r["config"]["samples_per_utt"] * 4
+    assert abs(r["value"] * r["ms_per_step"] * 1e-3 * 4 - total) < 1e-6 * total
+
+
 def test_bench_under_torchrun_with_stub_context():
     """The driver's own launch line (python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
     --master-port P bench.py --gpus N ...): env parsing, the TCPStore rendezvous against the elastic agent's store, one JSON line."""

@@ -34,6 +34,7 @@ profile_workload bench_n1
 python $ROOT/bench.py > $OUT/bench_n1.json 2> $OUT/bench_n1.err
 python $ROOT/bench.py --exact-encoder --no-cpu-baseline > $OUT/bench_n1_exact_encoder.json 2> $OUT/bench_n1_exact_encoder.err
 python $ROOT/bench.py --host-out --no-cpu-baseline > $OUT/bench_n1_host_out.json 2> $OUT/bench_n1_host_out.err
+python $ROOT/bench.py --in-flight 2 --no-cpu-baseline > $OUT/bench_n1_in_flight2.json 2> $OUT/bench_n1_in_flight2.err
 if [ -z "$QUICK" ]; then
   profile_workload cfg4 --config 4
   python $ROOT/bench.py --config 4 > $OUT/bench_cfg4.json 2> $OUT/bench_cfg4.err
