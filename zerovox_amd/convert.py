@@ -31,26 +31,34 @@ _SymbolsStub.__qualname__ = _SymbolsStub.__name__ = "Symbols"
 
 
 def _install_symbols_stub():
+    """Stand-in modules for the one class a ZeroVOX checkpoint pickles; returns the names it added (so that a real `zerovox`
+    package imported later in the same process is not shadowed: the caller removes them again)."""
     if "zerovox.tts.symbols" in sys.modules:
-        return
+        return []
     pkg = types.ModuleType("zerovox"); tts = types.ModuleType("zerovox.tts"); sym = types.ModuleType("zerovox.tts.symbols")
     sym.Symbols = _SymbolsStub
     pkg.tts = tts; tts.symbols = sym
-    sys.modules.update({"zerovox": pkg, "zerovox.tts": tts, "zerovox.tts.symbols": sym})
+    added = {k: v for k, v in {"zerovox": pkg, "zerovox.tts": tts, "zerovox.tts.symbols": sym}.items() if k not in sys.modules}
+    sys.modules.update(added)
+    return list(added)
 
 
 def _safe_load(path):
     """torch.load restricted to tensors/containers (weights_only=True): a downloaded checkpoint must not be able to run
     code.  The only non-tensor class a ZeroVOX Lightning checkpoint pickles is `Symbols` (hyper_parameters); the stand-in
-    is allow-listed explicitly."""
+    is allow-listed explicitly and its stub modules leave sys.modules again once the file is read."""
     import torch
-    _install_symbols_stub()
-    sym = sys.modules["zerovox.tts.symbols"].Symbols
-    if hasattr(torch.serialization, "safe_globals"):
-        with torch.serialization.safe_globals([sym]):
-            return torch.load(path, map_location="cpu", weights_only=True)
-    torch.serialization.add_safe_globals([sym])
-    return torch.load(path, map_location="cpu", weights_only=True)
+    added = _install_symbols_stub()
+    try:
+        sym = sys.modules["zerovox.tts.symbols"].Symbols
+        if hasattr(torch.serialization, "safe_globals"):
+            with torch.serialization.safe_globals([sym]):
+                return torch.load(path, map_location="cpu", weights_only=True)
+        torch.serialization.add_safe_globals([sym])
+        return torch.load(path, map_location="cpu", weights_only=True)
+    finally:
+        for k in added:
+            sys.modules.pop(k, None)
 
 
 def find_tts_checkpoint(modeldir):
