@@ -27,3 +27,18 @@ for nctx in (1, 2, 3, 1, 2):
     dt = time.time() - t0
     print(f"{nctx} context(s): {1e3 * dt / K:.3f} ms per step = {B * N * K / dt / 1e6:.1f} M samples/s", flush=True)
     for c in ctxs: c.close()
+
+# the same through the host API (waveforms delivered to host memory, worker threads): ZeroVox.synthesize_batches
+from zerovox_amd.model import ZeroVox
+m = ZeroVox(cfg, sd, h, hsd, infer_device="cuda:0", precision="bf16")
+batch = dict(phoneme=ph, puncts=pu, T=Tl, style_embed=spk, duration=dur, pad_to=pad)
+for _ in range(3): m.synthesize_batch(ph, pu, Tl, spk, dur, pad, want_mel=False)
+t0 = time.time()
+for _ in range(K): m.synthesize_batch(ph, pu, Tl, spk, dur, pad, want_mel=False)
+dt1 = time.time() - t0
+for n in (2, 3):
+    list(m.synthesize_batches((batch for _ in range(4)), in_flight=n))
+    t0 = time.time()
+    for _r in m.synthesize_batches((batch for _ in range(K)), in_flight=n): pass
+    dt = time.time() - t0
+    print(f"host API, waveforms to host: sequential {1e3 * dt1 / K:.3f} ms per batch, {n} in flight {1e3 * dt / K:.3f} ms per batch ({B * N * K / dt / 1e6:.1f} M samples/s)", flush=True)
