@@ -357,6 +357,8 @@ def main(argv=None, ctx_factory=default_ctx_factory):
         ctx.set_int("profile", 2)
         ctx.set_int("profile_only", -1)
         ctx.reset_stats()
+        if more_ctx:
+            it[0] += (-it[0]) % (1 + len(more_ctx))   # --in-flight: the profiled step must be one of the first context's
         step()
         fence()
         kstats_all, tstats = ctx.kernel_stats(), ctx.tag_stats()
