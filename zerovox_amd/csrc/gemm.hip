@@ -39,6 +39,7 @@ static thread_local bool g_dry_run = false;     // gemm_variant_of(): walk the l
 namespace zvx {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;   // native vector: usable as a tied ("+v") inline-asm operand
 
@@ -296,6 +297,15 @@ __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));      // float pairs: v_pk_add_f32 / v_pk_mul_f32 (two elements per VALU slot)
 __device__ __forceinline__ f32x2 unpack_bf16x2(unsigned u) { return (f32x2){__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u)}; }
+// DT_F16 tensors (the StyleTTS decoder): round-to-nearest-even converts, saturating instead of overflowing to Inf
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack_f16x2(float lo, float hi) {
+    const f16x2_t v = {(_Float16)__builtin_amdgcn_fmed3f(lo, -65504.f, 65504.f), (_Float16)__builtin_amdgcn_fmed3f(hi, -65504.f, 65504.f)};   // 2 v_med3_f32 + v_cvt_pk_f16_f32
+    return __builtin_bit_cast(unsigned, v);
+}
+__device__ __forceinline__ f32x2 unpack_f16x2(unsigned u) { const f16x2_t v = __builtin_bit_cast(f16x2_t, u); return (f32x2){(float)v.x, (float)v.y}; }
+__device__ __forceinline__ unsigned pack16x2(float lo, float hi, bool f16) { return f16 ? pack_f16x2(lo, hi) : pack_bf16x2(lo, hi); }
+__device__ __forceinline__ f32x2 unpack16x2(unsigned u, bool f16) { return f16 ? unpack_f16x2(u) : unpack_bf16x2(u); }
 __device__ __forceinline__ f32x2 lrelu2(f32x2 v, float slope) { const f32x2 m = v * slope; return (f32x2){fmaxf(v.x, m.x), fmaxf(v.y, m.y)}; }     // 0 <= slope <= 1
 __device__ __forceinline__ f32x2 inv_lrelu2(f32x2 y, float inv_slope) { const f32x2 m = y * inv_slope; return (f32x2){fminf(y.x, m.x), fminf(y.y, m.y)}; }  // inv_slope >= 1
 
@@ -328,8 +338,9 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs& a, f32x16 (&acc)[T
     const float slope = CT ? (a.act == ACT_LRELU ? a.slope : 1.f) : a.slope;        // CT: slope 1 = no activation
     const int res_mode = RES_LDS ? 2 : (CT ? ((EPI & 1) ? 2 : 0) : a.res_mode);
     const int accum_mode = CT ? (EPI >> 1) & 3 : a.accum_mode, bias_mode = CT ? 1 : a.bias_mode;
-    const bool has_out = CT ? (EPI >> 3) & 1 : a.out != nullptr, out_bf16 = CT || a.out_dtype == DT_BF16, has_post = !CT && a.post_scale != nullptr;
-    const bool acc_bf16 = CT || a.accum_dtype == DT_BF16, res_bf16 = CT || RES_LDS || a.res_dtype == DT_BF16;
+    const bool has_out = CT ? (EPI >> 3) & 1 : a.out != nullptr, out_bf16 = CT || a.out_dtype != DT_F32, has_post = !CT && a.post_scale != nullptr;
+    const bool acc_bf16 = CT || a.accum_dtype == DT_BF16, res_bf16 = CT || RES_LDS || a.res_dtype != DT_F32;
+    const bool out_f16 = !CT && a.out_dtype == DT_F16, res_f16 = !CT && !RES_LDS && a.res_dtype == DT_F16;    // ("bf16" above reads "16-bit")
     f32x2 bcol[4];
 #pragma unroll
     for (int e = 0; e < 4; e++) bcol[e] = (f32x2){0.f, 0.f};
@@ -405,7 +416,7 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs& a, f32x16 (&acc)[T
             if (res_mode) {
                 f32x2 q[4];
                 if (res_bf16) {
-                    q[0] = unpack_bf16x2(rraw[p].x); q[1] = unpack_bf16x2(rraw[p].y); q[2] = unpack_bf16x2(rraw[p].z); q[3] = unpack_bf16x2(rraw[p].w);
+                    q[0] = unpack16x2(rraw[p].x, res_f16); q[1] = unpack16x2(rraw[p].y, res_f16); q[2] = unpack16x2(rraw[p].z, res_f16); q[3] = unpack16x2(rraw[p].w, res_f16);
                 } else {
                     const float* rp = (const float*)a.res + (ok[p] ? roff + (long)r * a.ldr + n : 0);
                     const float4 t0 = *(const float4*)rp, t1 = *(const float4*)(rp + 4);
@@ -457,7 +468,7 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs& a, f32x16 (&acc)[T
                     t[2] = t[2] * (f32x2){s1.x, s1.y} + (f32x2){h1.x, h1.y}; t[3] = t[3] * (f32x2){s1.z, s1.w} + (f32x2){h1.z, h1.w};
                 }
                 if (out_bf16) {
-                    const u32x4 o = (u32x4){pack_bf16x2(t[0].x, t[0].y), pack_bf16x2(t[1].x, t[1].y), pack_bf16x2(t[2].x, t[2].y), pack_bf16x2(t[3].x, t[3].y)};
+                    const u32x4 o = (u32x4){pack16x2(t[0].x, t[0].y, out_f16), pack16x2(t[1].x, t[1].y, out_f16), pack16x2(t[2].x, t[2].y, out_f16), pack16x2(t[3].x, t[3].y, out_f16)};
                     if (BURST) pk[j][p] = o;
                     else if (ok[p]) *(u32x4*)((unsigned short*)a.out + ooff + (long)r * a.ldo + n) = o;
                 } else if (ok[p]) {
@@ -587,7 +598,8 @@ void launch_pack_weights(const void* w_bf16, int ntaps, int N, int K, void* out,
                        (unsigned short*)out, nkc, total);
 }
 
-template <int BM, int BN, int WM, int WN, bool FULLK, int MINW, int R, int EPI = -1, int MAXH = 64>
+// F16: the operands are IEEE half (v_mfma_f32_32x32x16_f16, same rate), the StyleTTS decoder's launches; everything else is bf16
+template <int BM, int BN, int WM, int WN, bool FULLK, int MINW, int R, int EPI = -1, int MAXH = 64, bool F16 = false>
 __global__ __launch_bounds__(256, MINW) void convslab_kernel(const GemmArgs a) {
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int NIT = ((BM + MAXH) * 8 + 255) / 256;    // staging iterations (halo_l + halo_r <= MAXH rows)
@@ -739,7 +751,8 @@ __global__ __launch_bounds__(256, MINW) void convslab_kernel(const GemmArgs a) {
             for (int i = 0; i < TN; i++)
 #pragma unroll
                 for (int j = 0; j < TM; j++)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[i]),
+                    acc[i][j] = F16 ? __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, wf[i]), __builtin_bit_cast(f16x8, xf[j]), acc[i][j], 0, 0, 0)
+                                    : __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf[i]),
                                                                        __builtin_bit_cast(bf16x8, xf[j]), acc[i][j], 0, 0, 0);
         };
         auto mma_r = [&](uint4 (&xf)[TM], int slot) {
@@ -747,7 +760,8 @@ __global__ __launch_bounds__(256, MINW) void convslab_kernel(const GemmArgs a) {
             for (int i = 0; i < TN; i++)
 #pragma unroll
                 for (int j = 0; j < TM; j++)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wreg[WREG ? slot : 0][i]),
+                    acc[i][j] = F16 ? __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, wreg[WREG ? slot : 0][i]), __builtin_bit_cast(f16x8, xf[j]), acc[i][j], 0, 0, 0)
+                                    : __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wreg[WREG ? slot : 0][i]),
                                                                        __builtin_bit_cast(bf16x8, xf[j]), acc[i][j], 0, 0, 0);
         };
         auto rowoff_of = [&](int tap) {
@@ -1472,6 +1486,13 @@ void gemm_set_slab_small(int v) { g_slab_small = v; }
 
 template <int BM, int BN, int WM, int WN, int MINW, int R, int EPI = -1>
 static void launch_slab_variant(const GemmArgs& a, dim3 grid, size_t lds, hipStream_t stream) {
+    if constexpr (EPI == -1) {
+        if (a.dtype == DT_F16) {                                   // half operands: the run-time-epilogue variants only (the decoder's launches)
+            if (a.K % SLAB_KC == 0) ZVX_LAUNCH((convslab_kernel<BM, BN, WM, WN, true, MINW, R, EPI, 64, true>), grid, dim3(256), lds, stream, a);
+            else ZVX_LAUNCH((convslab_kernel<BM, BN, WM, WN, false, MINW, R, EPI, 64, true>), grid, dim3(256), lds, stream, a);
+            return;
+        }
+    }
     if (a.K % SLAB_KC == 0) ZVX_LAUNCH((convslab_kernel<BM, BN, WM, WN, true, MINW, R, EPI>), grid, dim3(256), lds, stream, a);
     else ZVX_LAUNCH((convslab_kernel<BM, BN, WM, WN, false, MINW, R, EPI>), grid, dim3(256), lds, stream, a);
 }
@@ -1507,7 +1528,7 @@ static int launch_convslab(GemmArgs a, hipStream_t stream) {
         ZVX_LAUNCH((convslab_kernel<256, 128, 2, 2, true, 2, 0, -1, 160>), grid, dim3(256), lds, stream, a);
         return 7;
     }
-    if (a.N == a.K && (a.ntaps == 3 || a.ntaps == 7 || a.ntaps == 11)) {
+    if (a.dtype == DT_BF16 && a.N == a.K && (a.ntaps == 3 || a.ntaps == 7 || a.ntaps == 11)) {
         if (a.N == 32 && launch_convreg_c<32, 512, 4, 1, 2>(a, stream)) return 14;
         if (a.N == 64 && launch_convreg_c<64, 256, 2, 2, 2>(a, stream)) return 15;
     }
@@ -1631,12 +1652,13 @@ int launch_gemm(const GemmArgs& a, hipStream_t stream) {
             if (id >= 0) return id;
         }
     }
-    if (a.Wp && a.dtype == DT_BF16 && a.wout <= 0 && a.nheads == 1 && a.w_bs == 0 && !a.k_len && a.K % 16 == 0 && a.N % 8 == 0 && a.ldo % 8 == 0) {
+    if (a.Wp && a.dtype != DT_F32 && a.wout <= 0 && a.nheads == 1 && a.w_bs == 0 && !a.k_len && a.K % 16 == 0 && a.N % 8 == 0 && a.ldo % 8 == 0) {
         int lo = 0, hi = 0;
         for (int i = 0; i < a.ntaps; i++) { if (a.dv[i] < lo) lo = a.dv[i]; if (a.dv[i] > hi) hi = a.dv[i]; }
         if (hi - lo <= 64 && hi >= 0 && lo <= 0) return launch_convslab(a, stream);
     }
     if (a.out_split3) return -2;                                // only the conv-slab epilogue (epilogue_rows) writes split planes
+    if (a.dtype == DT_F16) return -2;                           // half operands exist on the conv-slab kernel only
     // tile choice: padded N weighted by the tile's MFMA efficiency, ties -> wider BN
     static const int bns[3] = {128, 64, 32};
     static const double eff[3] = {1.0, 0.75, 0.45};

@@ -6,6 +6,7 @@
 namespace zvx {
 
 __device__ __forceinline__ float ld(const void* p, int dt, long i) {
+    if (dt == DT_F16) return (float)((const _Float16*)p)[i];
     return dt == DT_F32 ? ((const float*)p)[i] : __uint_as_float(((unsigned)((const unsigned short*)p)[i]) << 16);
 }
 __device__ __forceinline__ unsigned short tobf(float f) {
@@ -13,7 +14,34 @@ __device__ __forceinline__ unsigned short tobf(float f) {
     u += 0x7fffu + ((u >> 16) & 1u);
     return (unsigned short)(u >> 16);
 }
+// 8 consecutive 16-bit values (one 16-byte load) -> f32, and back; dt = DT_BF16 or DT_F16
+__device__ __forceinline__ void unpack8(const uint4 t, int dt, float v[8]) {
+    if (dt == DT_F16) {
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+        const h2 a = __builtin_bit_cast(h2, t.x), b = __builtin_bit_cast(h2, t.y), c = __builtin_bit_cast(h2, t.z), d = __builtin_bit_cast(h2, t.w);
+        v[0] = (float)a.x; v[1] = (float)a.y; v[2] = (float)b.x; v[3] = (float)b.y; v[4] = (float)c.x; v[5] = (float)c.y; v[6] = (float)d.x; v[7] = (float)d.y;
+    } else {
+        v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u);
+        v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
+        v[4] = __uint_as_float(t.z << 16); v[5] = __uint_as_float(t.z & 0xffff0000u);
+        v[6] = __uint_as_float(t.w << 16); v[7] = __uint_as_float(t.w & 0xffff0000u);
+    }
+}
+__device__ __forceinline__ float clamp_h(float v) { return __builtin_amdgcn_fmed3f(v, -65504.f, 65504.f); }   // f16 stores saturate instead of producing Inf
+__device__ __forceinline__ uint4 pack8(const float v[8], int dt) {
+    uint4 o;
+    if (dt == DT_F16) {
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+        o.x = __builtin_bit_cast(unsigned, (h2){(_Float16)clamp_h(v[0]), (_Float16)clamp_h(v[1])}); o.y = __builtin_bit_cast(unsigned, (h2){(_Float16)clamp_h(v[2]), (_Float16)clamp_h(v[3])});
+        o.z = __builtin_bit_cast(unsigned, (h2){(_Float16)clamp_h(v[4]), (_Float16)clamp_h(v[5])}); o.w = __builtin_bit_cast(unsigned, (h2){(_Float16)clamp_h(v[6]), (_Float16)clamp_h(v[7])});
+    } else {
+        o.x = (unsigned)tobf(v[0]) | ((unsigned)tobf(v[1]) << 16); o.y = (unsigned)tobf(v[2]) | ((unsigned)tobf(v[3]) << 16);
+        o.z = (unsigned)tobf(v[4]) | ((unsigned)tobf(v[5]) << 16); o.w = (unsigned)tobf(v[6]) | ((unsigned)tobf(v[7]) << 16);
+    }
+    return o;
+}
 __device__ __forceinline__ void st(void* p, int dt, long i, float v) {
+    if (dt == DT_F16) { ((_Float16*)p)[i] = (_Float16)clamp_h(v); return; }
     if (dt == DT_F32) ((float*)p)[i] = v; else ((unsigned short*)p)[i] = tobf(v);
 }
 __device__ __forceinline__ float wave_sum(float v) {
@@ -277,19 +305,15 @@ __global__ __launch_bounds__(256) void k_colstats(const void* x, int xdt, int ld
     for (int e = 0; e < 8; e++) { s1[e] = 0.f; s2[e] = 0.f; sh[e] = 0.f; }
     const bool cok = c0 < C;                                  // C % 8 == 0 for every caller
     auto load8 = [&](long off, float v[8]) {
-        if (xdt == DT_BF16) {
-            const uint4 t = *(const uint4*)((const unsigned short*)x + off);
-            v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u);
-            v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
-            v[4] = __uint_as_float(t.z << 16); v[5] = __uint_as_float(t.z & 0xffff0000u);
-            v[6] = __uint_as_float(t.w << 16); v[7] = __uint_as_float(t.w & 0xffff0000u);
+        if (xdt != DT_F32) {
+            unpack8(*(const uint4*)((const unsigned short*)x + off), xdt, v);
         } else {
             const float4 t0 = *(const float4*)((const float*)x + off), t1 = *(const float4*)((const float*)x + off + 4);
             v[0] = t0.x; v[1] = t0.y; v[2] = t0.z; v[3] = t0.w; v[4] = t1.x; v[5] = t1.y; v[6] = t1.z; v[7] = t1.w;
         }
     };
     if (cok && Wb > 0) load8(base + c0, sh);                  // shift = row 0 of this utterance (valid: Wb > 0)
-    if (cok && xdt == DT_BF16) {
+    if (cok && xdt != DT_F32) {
         // four rows of the thread in flight per iteration (same rows, same order of accumulation as the plain loop below); a single
         // request would otherwise pay one memory round trip per row of its chain (14 for a 448-frame utterance)
         const unsigned short* xp = (const unsigned short*)x + base + c0;
@@ -302,10 +326,7 @@ __global__ __launch_bounds__(256) void k_colstats(const void* x, int xdt, int ld
                 for (int u = 0; u < 4; u++) {
                     if (w + 32 * u >= Wb) break;
                     float v[8];
-                    v[0] = __uint_as_float(t[u].x << 16); v[1] = __uint_as_float(t[u].x & 0xffff0000u);
-                    v[2] = __uint_as_float(t[u].y << 16); v[3] = __uint_as_float(t[u].y & 0xffff0000u);
-                    v[4] = __uint_as_float(t[u].z << 16); v[5] = __uint_as_float(t[u].z & 0xffff0000u);
-                    v[6] = __uint_as_float(t[u].w << 16); v[7] = __uint_as_float(t[u].w & 0xffff0000u);
+                    unpack8(t[u], xdt, v);
 #pragma unroll
                     for (int e = 0; e < 8; e++) { const float d = v[e] - sh[e]; s1[e] += d; s2[e] += d * d; }
                 }
@@ -403,8 +424,8 @@ __global__ __launch_bounds__(256) void k_norm_affine_act(const void* x, int xdt,
         sc[e] = r * g; sh[e] = be - m * r * g;                // (x - m) * r * g + be
     }
     const int lend = (l0 + 64 < Lb) ? l0 + 64 : Lb;
-    if (xdt == DT_BF16 && ydt == DT_BF16) {
-        // bf16 -> bf16 (the decoder's InstanceNorm / AdaIN passes): four rows of the wave in flight per iteration.  Neutral at batch 32
+    if (xdt != DT_F32 && ydt != DT_F32) {
+        // 16-bit -> 16-bit (the decoder's InstanceNorm / AdaIN passes): four rows of the wave in flight per iteration.  Neutral at batch 32
         // (the pass is bandwidth-bound there); a single request runs 16 dependent row round trips per wave otherwise.
         const unsigned short* xp = (const unsigned short*)x + (long)b * Lmax * ldx + c;
         unsigned short* yp = (unsigned short*)y + (long)b * Lmax * ldy + c;
@@ -416,16 +437,10 @@ __global__ __launch_bounds__(256) void k_norm_affine_act(const void* x, int xdt,
             for (int u = 0; u < 4; u++) {
                 if (l + 4 * u >= lend) break;
                 float v[8];
-                v[0] = __uint_as_float(t[u].x << 16); v[1] = __uint_as_float(t[u].x & 0xffff0000u);
-                v[2] = __uint_as_float(t[u].y << 16); v[3] = __uint_as_float(t[u].y & 0xffff0000u);
-                v[4] = __uint_as_float(t[u].z << 16); v[5] = __uint_as_float(t[u].z & 0xffff0000u);
-                v[6] = __uint_as_float(t[u].w << 16); v[7] = __uint_as_float(t[u].w & 0xffff0000u);
+                unpack8(t[u], xdt, v);
 #pragma unroll
                 for (int e = 0; e < 8; e++) v[e] = act_apply(v[e] * sc[e] + sh[e], act, slope);
-                uint4 o;
-                o.x = (unsigned)tobf(v[0]) | ((unsigned)tobf(v[1]) << 16); o.y = (unsigned)tobf(v[2]) | ((unsigned)tobf(v[3]) << 16);
-                o.z = (unsigned)tobf(v[4]) | ((unsigned)tobf(v[5]) << 16); o.w = (unsigned)tobf(v[6]) | ((unsigned)tobf(v[7]) << 16);
-                *(uint4*)(yp + (long)(l + 4 * u) * ldy) = o;
+                *(uint4*)(yp + (long)(l + 4 * u) * ldy) = pack8(v, ydt);
             }
         }
         return;
@@ -433,23 +448,16 @@ __global__ __launch_bounds__(256) void k_norm_affine_act(const void* x, int xdt,
     for (int l = l0 + (threadIdx.x >> 6); l < lend; l += 4) {
         const long xo = ((long)b * Lmax + l) * ldx + c, yo = ((long)b * Lmax + l) * ldy + c;
         float v[8];
-        if (xdt == DT_BF16) {
-            const uint4 t = *(const uint4*)((const unsigned short*)x + xo);
-            v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u);
-            v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
-            v[4] = __uint_as_float(t.z << 16); v[5] = __uint_as_float(t.z & 0xffff0000u);
-            v[6] = __uint_as_float(t.w << 16); v[7] = __uint_as_float(t.w & 0xffff0000u);
+        if (xdt != DT_F32) {
+            unpack8(*(const uint4*)((const unsigned short*)x + xo), xdt, v);
         } else {
             const float4 t0 = *(const float4*)((const float*)x + xo), t1 = *(const float4*)((const float*)x + xo + 4);
             v[0] = t0.x; v[1] = t0.y; v[2] = t0.z; v[3] = t0.w; v[4] = t1.x; v[5] = t1.y; v[6] = t1.z; v[7] = t1.w;
         }
 #pragma unroll
         for (int e = 0; e < 8; e++) v[e] = act_apply(v[e] * sc[e] + sh[e], act, slope);
-        if (ydt == DT_BF16) {
-            uint4 t;
-            t.x = (unsigned)tobf(v[0]) | ((unsigned)tobf(v[1]) << 16); t.y = (unsigned)tobf(v[2]) | ((unsigned)tobf(v[3]) << 16);
-            t.z = (unsigned)tobf(v[4]) | ((unsigned)tobf(v[5]) << 16); t.w = (unsigned)tobf(v[6]) | ((unsigned)tobf(v[7]) << 16);
-            *(uint4*)((unsigned short*)y + yo) = t;
+        if (ydt != DT_F32) {
+            *(uint4*)((unsigned short*)y + yo) = pack8(v, ydt);
         } else {
             *(float4*)((float*)y + yo) = make_float4(v[0], v[1], v[2], v[3]);
             *(float4*)((float*)y + yo + 4) = make_float4(v[4], v[5], v[6], v[7]);

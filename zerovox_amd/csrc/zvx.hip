@@ -86,6 +86,7 @@ struct zvx_ctx {
     int rs_prof = 0;                       // zvx_set_int("rs_prof", 1): per-wave cycle counters of the streaming kernels (library built with -DRS_PROFILE)
     int enc_split = 0;                     // bf16 mode: the f32 GEMMs of the phoneme encoder / variance adaptor run as 3-plane bf16 GEMMs
     const void* fft_xs_ready = nullptr;     // fft.xs holds the split planes of this buffer (written by the previous FFT block's last LayerNorm)
+    int dec_f16 = 1;                       // zvx_set_int("dec_f16", 0): StyleTTS decoder activations / weights in bf16 instead of IEEE half (A/B)
     int use_attn_f32 = 1;                  // zvx_set_int("attn_f32", 0): the encoder's attention as V^T / score / P.V GEMMs + softmax (A/B)
     int use_flash = 1;                     // zvx_set_int("flash", 0): the decoder's attention as score GEMM + softmax + PV GEMM (A/B)
     int voc_chunk = 0;                     // utterances per vocoder ResBlock sub-batch (0 = whole batch)
@@ -157,7 +158,7 @@ struct zvx_ctx {
 
     void gemm(GemmArgs& a) {
         if (a.flops <= 0) a.flops = 2.0 * (double)a.M * a.nbatch * a.nheads * (double)a.N * (double)a.K * a.ntaps;
-        if (!a.Wp && a.dtype == DT_BF16) { auto it = packed.find(a.W); if (it != packed.end()) a.Wp = it->second; }
+        if (!a.Wp && a.dtype != DT_F32) { auto it = packed.find(a.W); if (it != packed.end()) a.Wp = it->second; }
         GemmEvent ev{};
         const bool prof = profile >= 2 && (profile_only < 0 || gemm_variant_of(a) == profile_only);
         if (prof) { ev.a = new_event(); ev.b = new_event(); gemm_profile_events(ev.a, ev.b); }
@@ -316,6 +317,31 @@ void upload_weights(zvx_ctx* c) {
                 c->packed[t.dev] = parena + poff;
                 poff += (packed_weight_elems(t.dim(0), t.dim(1), t.dim(2)) * 2 + 255) & ~(size_t)255;
             }
+        }
+    }
+    // StyleTTS decoder in IEEE half (bf16 mode): a second, f16 copy of its convolution weights (cast from the f32 blob, fragment-packed
+    // like the bf16 ones).  Same MFMA rate, 8x smaller rounding error on weights and activations (every tensor there sits behind a
+    // norm: O(1..100), nowhere near 65504; stores saturate).  zvx_set_int("dec_f16", 0) runs the bf16 copies (A/B).
+    if (c->dt == DT_BF16) {
+        std::vector<std::pair<std::string, Tensor>> add16;
+        size_t htotal = 0;
+        for (auto& kv : c->tensors) {
+            const Tensor& t = kv.second;
+            if (kv.first.rfind("sty.", 0) != 0 || t.kind != 'w' || t.dtype != DT_BF16 || t.dims.size() != 3 || t.dim(2) % 8) continue;
+            Tensor hcopy = t; hcopy.dtype = DT_F16; hcopy.kind = 'h';
+            htotal += ((t.numel * 2 + 255) & ~(size_t)255) + ((packed_weight_elems(t.dim(0), t.dim(1), t.dim(2)) * 2 + 255) & ~(size_t)255);
+            add16.emplace_back(kv.first + ".h16", hcopy);
+        }
+        char* harena = htotal ? (char*)c->buf("weights_f16", htotal) : nullptr;
+        size_t hoff = 0;
+        for (auto& kv : add16) {
+            Tensor& t = kv.second;
+            t.dev = harena + hoff; hoff += (t.numel * 2 + 255) & ~(size_t)255;
+            launch_cast(staging + t.off, DT_F32, t.dev, DT_F16, t.numel, c->stream);
+            void* pk = harena + hoff; hoff += (packed_weight_elems(t.dim(0), t.dim(1), t.dim(2)) * 2 + 255) & ~(size_t)255;
+            launch_pack_weights(t.dev, t.dim(0), t.dim(1), t.dim(2), pk, c->stream);
+            c->packed[t.dev] = pk;
+            c->tensors[kv.first] = t;
         }
     }
     // f32 FFT blocks: Q, K and V projections as ONE GEMM (fs2.py:143-145) -- [Wq; Wk; Wv] and the biases concatenated once here
@@ -727,18 +753,18 @@ void decoder_fs2(zvx_ctx* c, const float* feats, const float* spk_d, const int* 
     c->gemm(a);
 }
 
-struct StyCtx { zvx_ctx* c; int B, Lmax; const int* L_d; float* mean; float* rstd; };
+struct StyCtx { zvx_ctx* c; int B, Lmax; const int* L_d; float* mean; float* rstd; int dt; };   // dt: the decoder's activation dtype (bf16 / f16 / f32)
 
 void sty_conv(const StyCtx& s, const std::string& wname, const void* x, int ldx, int Cin, void* out, int ldo, int out_dt,
               int Cout, const void* res, int ldr, float out_scale) {
     zvx_ctx* c = s.c;
-    const Tensor& w = c->t(wname);
-    GemmArgs a = gemm_base(c->dt);
+    const Tensor& w = c->t(s.dt == DT_F16 ? wname + ".h16" : wname);
+    GemmArgs a = gemm_base(s.dt);
     a.X = x; a.x_bs = (long)s.Lmax * ldx; a.ldx = ldx; a.W = w.dev; a.ldw = Cin; a.w_ts = (long)Cout * Cin;
     a.M = s.Lmax; a.N = Cout; a.K = Cin; a.nbatch = s.B; a.in_len = s.L_d; a.out_len = s.L_d;
     set_taps_1d(a, w.dim(0), 1);
     if (c->has(wname + "_b")) { a.bias = c->pf(wname + "_b"); a.bias_mode = 1; }
-    if (res) { a.res = res; a.r_bs = (long)s.Lmax * ldr; a.ldr = ldr; a.res_mode = 1; a.res_dtype = c->dt; }
+    if (res) { a.res = res; a.r_bs = (long)s.Lmax * ldr; a.ldr = ldr; a.res_mode = 1; a.res_dtype = s.dt; }
     a.out_scale = out_scale;
     a.out = out; a.o_bs = (long)s.Lmax * ldo; a.ldo = ldo; a.out_dtype = out_dt;
     c->gemm(a);
@@ -749,18 +775,19 @@ void sty_norm(const StyCtx& s, const void* x, int ldx, int C, void* y, int ldy, 
     const std::string keep = s.c->tag;
     s.c->tag = "decoder.norm";
     s.c->timed(0, (double)s.B * s.Lmax * C * s.c->es() * 3.0, [&] {          // statistics pass (read) + normalise pass (read + write)
-        launch_instnorm_stats(x, s.c->dt, ldx, s.B, s.Lmax, s.L_d, C, 1e-5f, s.mean, s.rstd, s.c->stream);
-        launch_norm_affine_act(x, s.c->dt, ldx, y, s.c->dt, ldy, s.B, s.Lmax, s.L_d, C, s.mean, s.rstd, gamma, beta, g_bs, one_plus,
+        launch_instnorm_stats(x, s.dt, ldx, s.B, s.Lmax, s.L_d, C, 1e-5f, s.mean, s.rstd, s.c->stream);
+        launch_norm_affine_act(x, s.dt, ldx, y, s.dt, ldy, s.B, s.Lmax, s.L_d, C, s.mean, s.rstd, gamma, beta, g_bs, one_plus,
                                act, 0.2f, s.c->stream);
     });
     s.c->tag = keep;
 }
 
 void decoder_styletts(zvx_ctx* c, const float* feats, const float* spk_d, const int* L_d, int B, int Lmax, float* mel) {
-    const int H = c->H, H2 = 2 * H, R = c->res_dim, CW = H2 + R, dt = c->dt;
-    const size_t es = c->es(), rows = (size_t)B * Lmax;
+    const int H = c->H, H2 = 2 * H, R = c->res_dim, CW = H2 + R;
+    const int dt = (c->dt == DT_BF16 && c->dec_f16 && c->has("sty.out.h16")) ? DT_F16 : c->dt;      // 16-bit mode: IEEE half unless switched off
+    const size_t es = dtype_size(dt), rows = (size_t)B * Lmax;
     const float inv_sqrt2 = (float)(1.0 / sqrt(2.0));
-    StyCtx s{c, B, Lmax, L_d, c->fbuf("sty.mean", (size_t)B * CW), c->fbuf("sty.rstd", (size_t)B * CW)};
+    StyCtx s{c, B, Lmax, L_d, c->fbuf("sty.mean", (size_t)B * CW), c->fbuf("sty.rstd", (size_t)B * CW), dt};
     void* e = c->buf("sty.e", rows * H * es);
     void* t0 = c->buf("sty.t0", rows * CW * es);
     void* t1 = c->buf("sty.t1", rows * H2 * es);
@@ -1377,6 +1404,7 @@ zvx_status zvx_set_int(zvx_ctx* c, const char* key, int64_t value) {
         else if (std::string(key) == "voc_chunk") c->voc_chunk = (int)value;
         else if (std::string(key) == "flash") c->use_flash = (int)value;
         else if (std::string(key) == "attn_f32") c->use_attn_f32 = (int)value;
+        else if (std::string(key) == "dec_f16") c->dec_f16 = (int)value;
         else if (std::string(key) == "enc_split") c->enc_split = (c->dt == DT_BF16 && value && c->has("enc.0.wqk.s3")) ? 1 : 0;
         else if (std::string(key) == "rs_prof") c->rs_prof = (int)value;
         else if (std::string(key) == "rs_opt") c->rs_opt = (int)value;
