@@ -10,11 +10,13 @@ Stated tolerances
             path), so log-duration / pitch / energy / features keep the f32 tolerance (2e-4) and every discrete decision
             (duration, pitch / energy bucket) equals the reference's unless the reference value lies within 2e-2 bucket units
             (5e-3 frames) of a rounding boundary (measured: 2 + 11 of 4096 bucket ids move by one against the exact-f32 path).
-            mel: rms err <= 2.5 % of the reference rms and max|err| <= 0.12; waveform in [-1, 1]: rms err <= 6e-3,
-            max|err| <= 3e-2 end-to-end (vocoder alone from an exact mel: rms <= 3e-3, max <= 1.5e-2).  About 2x the measured
-            values (tools/error_budget.py on e2e_styletts_v1_T64: decoder mel 7e-2 max / 1.5e-2 rms; vocoder alone 7e-3 /
-            1.3e-3; decoder error through an exact vocoder 1.2e-2 / 2.2e-3; end to end 1.3e-2 / 2.6e-3): the end-to-end
-            error is the decoder's bf16 activation storage, the vocoder alone meets SURVEY.md 8c's 1e-2 / 2e-3.
+            The StyleTTS decoder (the benchmarked one) runs in IEEE HALF in this mode (f16 weights + activations, the same MFMA
+            rate; bf16 for everything else): its single-product bf16 floor was 7e-2 max / 1.5e-2 rms on the log-mel, above SURVEY
+            8c's 2e-2; in half it measures <= 1.02e-2 max / 0.22 % rms over every fixture.  Limits = SURVEY.md 8c's own:
+            mel (StyleTTS decoder) max|err| <= 2e-2, rms <= 0.4 % of the reference rms; waveform in [-1, 1] max|err| <= 1e-2 and
+            rms <= 2e-3, end to end AND for the vocoder alone (measured <= 8.5e-3 / 1.9e-3 end to end with either decoder,
+            <= 6.3e-3 / 1.3e-3 for the vocoder alone).  The FS2 / SCLN decoder stays in bf16: mel <= 4e-2 / 1 % (measured
+            <= 2.9e-2 / 0.7 %).  ZVX_ERR_LOG=<file> makes every comparison append what it measured.
 """
 import os
 
@@ -68,18 +70,33 @@ def check_f32(a, b, what, tol=2e-4):
     assert mx <= tol * max(1.0, bm), f"{what}: max err {mx:.3e} (ref max {bm:.3g})"
 
 
-def check_mel(a, b, prec, what):
+def _errlog(kind, what, *vals):
+    """ZVX_ERR_LOG=<file>: every 16-bit-mode comparison appends its measured errors (tolerances are set from these with margin)."""
+    path = os.environ.get("ZVX_ERR_LOG")
+    if path:
+        with open(path, "a") as f:
+            f.write(f"{os.environ.get('PYTEST_CURRENT_TEST', '?').split(' ')[0]} | {kind} {what} | " + " ".join(f"{v:.3e}" for v in vals) + "\n")
+
+
+def check_mel(a, b, prec, what, kind="fastspeech2"):
+    """16-bit mode: the StyleTTS decoder runs in IEEE half and is held to SURVEY 8c's 2e-2 abs on the log-mel (measured <= 1.02e-2 /
+    0.22 % rms over every fixture); the FS2 / SCLN decoder runs in bf16 (measured <= 2.9e-2 / 0.7 %): 4e-2 / 1 %."""
     if prec == "f32":
         return check_f32(a, b, what)
     mx, rms, ref_rms, _ = stats(a, b)
-    assert rms <= 0.025 * ref_rms and mx <= 0.12, f"{what}: mel err max {mx:.3e} rms {rms:.3e} (ref rms {ref_rms:.3g})"
+    _errlog("mel", what, mx, rms, ref_rms)
+    lim_mx, lim_rel = (2e-2, 0.004) if kind == "styletts" else (4e-2, 0.01)
+    assert rms <= lim_rel * ref_rms and mx <= lim_mx, f"{what}: mel err max {mx:.3e} rms {rms:.3e} (ref rms {ref_rms:.3g})"
 
 
 def check_wav(a, b, prec, what, e2e=True):
+    """16-bit mode: SURVEY 8c's waveform bound, 1e-2 abs / 2e-3 rms, end to end and for the vocoder alone (measured over every fixture:
+    <= 8.5e-3 / 1.9e-3 end to end with either decoder, <= 6.3e-3 / 1.3e-3 for the vocoder alone)."""
     if prec == "f32":
         return check_f32(a, b, what)
     mx, rms, _, _ = stats(a, b)
-    lim_mx, lim_rms = (3e-2, 6e-3) if e2e else (1.5e-2, 3e-3)
+    _errlog("wav-e2e" if e2e else "wav-voc", what, mx, rms)
+    lim_mx, lim_rms = (1e-2, 2e-3)
     assert mx <= lim_mx and rms <= lim_rms, f"{what}: wav err max {mx:.3e} rms {rms:.3e}"
 
 
@@ -104,7 +121,7 @@ def test_e2e_against_reference_golden(name, prec):
     check_f32(ctx.fetch("encoder_out", (1, T, 528))[0] - g["spk"][None], g["encoder_raw"], "encoder_out")
     check_f32(ctx.fetch("features", (1, ml, 528))[0], g["features"], "features")
     mel = ctx.decode(1, ml)
-    check_mel(mel[0, :ml], g["mel"].T, prec, "mel")
+    check_mel(mel[0, :ml], g["mel"].T, prec, "mel", str(g["decoder_kind"]))
     wav = ctx.vocode(1, mel_len, np.array([int(g["pad_to"])], np.int32))
     assert wav.shape[1] == ml * 256
     check_wav(wav[0], g["wav"], prec, "wav")
@@ -143,7 +160,7 @@ def test_ragged_batch_equals_independent_oracle_calls(kind, voc, prec):
         ref = O.inference_ex(sd, hsd, cfg, h, ph[b, :T], pu[b, :T], spk[b], duration=dur[b, :T], pad_to=int(pad_to[b]))
         ml = ref["mel_len"]
         assert int(out["mel_len"][b]) == ml
-        check_mel(out["mel"][b, :ml], ref["mel"].T, prec, f"mel[{b}]")
+        check_mel(out["mel"][b, :ml], ref["mel"].T, prec, f"mel[{b}]", kind)
         check_wav(out["wav"][b, : ml * 256], ref["wav"], prec, f"wav[{b}]")
 
 
@@ -252,7 +269,7 @@ def test_decoders_alone_against_golden(prec):
     for kind, key in (("styletts", "dec_styletts_y"), ("fastspeech2", "dec_fs2_y")):
         ctx = ctx_for(kind, "tiny", prec)
         mel = ctx.decode_features(g["dec_x"][None], np.array([20], np.int32), g["spk"][None])
-        check_mel(mel[0], g[key], prec, kind)
+        check_mel(mel[0], g[key], prec, kind, kind)
 
 
 @pytest.mark.parametrize("prec", ["f32", "bf16"])
@@ -380,7 +397,7 @@ def test_tiny_utterances(prec):
         ref = O.inference_ex(sd, hsd, cfg, h, ph[b, :T], pu[b, :T], spk[b], duration=dur[b, :T], pad_to=[4, 11][b])
         ml = ref["mel_len"]
         assert int(out["mel_len"][b]) == ml == int(dur[b, :T].sum())
-        check_mel(out["mel"][b, :ml], ref["mel"].T, prec, f"mel[{b}]")
+        check_mel(out["mel"][b, :ml], ref["mel"].T, prec, f"mel[{b}]", "fastspeech2")
         check_wav(out["wav"][b, : ml * 256], ref["wav"], prec, f"wav[{b}]")
 
 
