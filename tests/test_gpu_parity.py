@@ -10,13 +10,12 @@ Stated tolerances
             path), so log-duration / pitch / energy / features keep the f32 tolerance (2e-4) and every discrete decision
             (duration, pitch / energy bucket) equals the reference's unless the reference value lies within 2e-2 bucket units
             (5e-3 frames) of a rounding boundary (measured: 2 + 11 of 4096 bucket ids move by one against the exact-f32 path).
-            The StyleTTS decoder (the benchmarked one) runs in IEEE HALF in this mode (f16 weights + activations, the same MFMA
-            rate; bf16 for everything else): its single-product bf16 floor was 7e-2 max / 1.5e-2 rms on the log-mel, above SURVEY
-            8c's 2e-2; in half it measures <= 1.02e-2 max / 0.22 % rms over every fixture.  Limits = SURVEY.md 8c's own:
-            mel (StyleTTS decoder) max|err| <= 2e-2, rms <= 0.4 % of the reference rms; waveform in [-1, 1] max|err| <= 1e-2 and
-            rms <= 2e-3, end to end AND for the vocoder alone (measured <= 8.5e-3 / 1.9e-3 end to end with either decoder,
-            <= 6.3e-3 / 1.3e-3 for the vocoder alone).  The FS2 / SCLN decoder stays in bf16: mel <= 4e-2 / 1 % (measured
-            <= 2.9e-2 / 0.7 %).  ZVX_ERR_LOG=<file> makes every comparison append what it measured.
+            Both mel decoders run in IEEE HALF in this mode (f16 weights + activations, the same MFMA rate; bf16 for the vocoder
+            and the speaker encoder): their single-product bf16 floor was 7e-2 (StyleTTS) / 2.9e-2 (FS2) max on the log-mel, above
+            SURVEY 8c's 2e-2; in half they measure <= 1.02e-2 / 0.22 % rms and <= 3.6e-3 / 0.09 % over every fixture.  Limits =
+            SURVEY.md 8c's own: mel max|err| <= 2e-2, rms <= 0.4 % of the reference rms; waveform in [-1, 1] max|err| <= 1e-2 and
+            rms <= 2e-3, end to end AND for the vocoder alone (measured <= 8.5e-3 / 1.9e-3 end to end, <= 6.3e-3 / 1.3e-3 for
+            the vocoder alone).  ZVX_ERR_LOG=<file> makes every comparison append what it measured.
 """
 import os
 
@@ -79,13 +78,14 @@ def _errlog(kind, what, *vals):
 
 
 def check_mel(a, b, prec, what, kind="fastspeech2"):
-    """16-bit mode: the StyleTTS decoder runs in IEEE half and is held to SURVEY 8c's 2e-2 abs on the log-mel (measured <= 1.02e-2 /
-    0.22 % rms over every fixture); the FS2 / SCLN decoder runs in bf16 (measured <= 2.9e-2 / 0.7 %): 4e-2 / 1 %."""
+    """16-bit mode: both mel decoders run in IEEE half and are held to SURVEY 8c's 2e-2 abs on the log-mel (measured over every
+    fixture: StyleTTS <= 1.02e-2 / 0.22 % rms, FS2 / SCLN <= 3.6e-3 / 0.09 %).  kind "bf16": a decoder explicitly run in bf16
+    (zvx_set_int flash / dec_f16 0, measured <= 2.9e-2 / 0.7 % for FS2): 4e-2 / 1 %."""
     if prec == "f32":
         return check_f32(a, b, what)
     mx, rms, ref_rms, _ = stats(a, b)
     _errlog("mel", what, mx, rms, ref_rms)
-    lim_mx, lim_rel = (2e-2, 0.004) if kind == "styletts" else (4e-2, 0.01)
+    lim_mx, lim_rel = (4e-2, 0.01) if kind == "bf16" else (2e-2, 0.004)
     assert rms <= lim_rel * ref_rms and mx <= lim_mx, f"{what}: mel err max {mx:.3e} rms {rms:.3e} (ref rms {ref_rms:.3g})"
 
 
@@ -961,7 +961,7 @@ def test_fused_attention_of_the_fs2_decoder():
     for b in range(5):
         ref = O.fs2_decoder(feats[b, :L[b]], spk[b], sd, cfg)
         check_mel(fused[b, :L[b]], ref, "bf16", f"fused attention utt {b}")
-        check_mel(unfused[b, :L[b]], ref, "bf16", f"unfused attention utt {b}")
+        check_mel(unfused[b, :L[b]], ref, "bf16", f"unfused attention utt {b}", "bf16")       # flash 0: the block falls back to bf16
         assert np.abs(fused[b, :L[b]] - unfused[b, :L[b]]).max() < 0.08
         assert not fused[b, L[b]:].any()
 

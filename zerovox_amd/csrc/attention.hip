@@ -30,7 +30,24 @@ void flash_profile_events(hipEvent_t start, hipEvent_t stop) { g_fa_ev_start = s
 #define FA_BK 32
 #define FA_NKB (FA_BK / 32)      // 32-key blocks per tile
 
-template <int D>
+// F16: Q / K / V^T / output (and the probabilities fed to the second product) are IEEE half instead of bf16 (the FS2 decoder in
+// the 16-bit mode, like the StyleTTS decoder: same MFMA rate, 8x smaller rounding error)
+typedef __attribute__((ext_vector_type(8))) _Float16 fa_f16x8;
+template <bool F16>
+__device__ __forceinline__ unsigned fa_pack2(float lo, float hi) {
+    if (F16) {
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+        return __builtin_bit_cast(unsigned, (h2){(_Float16)__builtin_amdgcn_fmed3f(lo, -65504.f, 65504.f), (_Float16)__builtin_amdgcn_fmed3f(hi, -65504.f, 65504.f)});
+    }
+    return pack_bf16x2(lo, hi);
+}
+template <bool F16>
+__device__ __forceinline__ f32x16 fa_mfma(const uint4& a_, const uint4& b_, const f32x16& c_) {
+    if (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(fa_f16x8, a_), __builtin_bit_cast(fa_f16x8, b_), c_, 0, 0, 0);
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a_), __builtin_bit_cast(bf16x8, b_), c_, 0, 0, 0);
+}
+
+template <int D, bool F16>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void flash_attn_kernel(const FlashArgs a) {
     constexpr int KS = (D + 15) / 16, DP = KS * 16;             // k16 steps / padded depth of Q.K
     constexpr int NDB = (D + 31) / 32, DO = NDB * 32;           // 32-row output tiles / padded depth of the output
@@ -119,7 +136,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
             for (int st = 0; st < KS; st++) {
                 const uint4 kf = *(const uint4*)(rowp + st * 32);
-                s[kbk] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kf), __builtin_bit_cast(bf16x8, qf[st]), s[kbk], 0, 0, 0);
+                s[kbk] = fa_mfma<F16>(kf, qf[st], s[kbk]);
             }
         }
         // ---- online softmax over this lane's 32 keys (+ the partner lane's 32): key of element (kbk, g, e) = 32 kbk + 8 g + 4 hi + e ----
@@ -146,7 +163,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 const float p0 = exp2f(s[kbk][4 * g] - m_new), p1 = exp2f(s[kbk][4 * g + 1] - m_new);
                 const float p2 = exp2f(s[kbk][4 * g + 2] - m_new), p3 = exp2f(s[kbk][4 * g + 3] - m_new);
                 rs += (p0 + p1) + (p2 + p3);
-                pk[kbk][2 * g] = pack_bf16x2(p0, p1); pk[kbk][2 * g + 1] = pack_bf16x2(p2, p3);
+                pk[kbk][2 * g] = fa_pack2<F16>(p0, p1); pk[kbk][2 * g + 1] = fa_pack2<F16>(p2, p3);
             }
         l_run = l_run * alpha + rs;
 #pragma unroll
@@ -174,7 +191,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
             for (int st = 0; st < 2 * FA_NKB; st++) {
                 const uint4 vf = *(const uint4*)(rowp + st * 32);
-                o[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vf), __builtin_bit_cast(bf16x8, pf[st]), o[i], 0, 0, 0);
+                o[i] = fa_mfma<F16>(vf, pf[st], o[i]);
             }
         }
         if (t + 1 < ntiles) store_tile((t + 1) & 1);            // the other buffer: last read in tile t-1, behind the barrier below
@@ -191,8 +208,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 const int d = i * 32 + 8 * g + 4 * hi;
                 if (d < D) {                                    // D % 4 == 0
                     uint2 w;
-                    w.x = pack_bf16x2(o[i][4 * g] * inv, o[i][4 * g + 1] * inv);
-                    w.y = pack_bf16x2(o[i][4 * g + 2] * inv, o[i][4 * g + 3] * inv);
+                    w.x = fa_pack2<F16>(o[i][4 * g] * inv, o[i][4 * g + 1] * inv);
+                    w.y = fa_pack2<F16>(o[i][4 * g + 2] * inv, o[i][4 * g + 3] * inv);
                     *(uint2*)(op + d) = w;
                 }
             }
@@ -205,12 +222,20 @@ bool launch_flash_attention(const FlashArgs& a, hipStream_t stream, bool dry_run
     if (dry_run) return true;
     constexpr int D = 264, KS = (D + 15) / 16, DP = KS * 16, DO = (D + 31) / 32 * 32;
     const size_t lds = 2 * ((size_t)FA_BK * (DP * 2 + 16) + (size_t)DO * (FA_BK * 2 + 16));
-    auto kfn = flash_attn_kernel<264>;
-    static bool attr_done = false;
-    if (!attr_done) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_done = true; }
     const dim3 grid((a.L + FA_BQ - 1) / FA_BQ, a.nbatch * a.nheads), block(256);
-    if (g_fa_ev_start) hipExtLaunchKernelGGL(kfn, grid, block, lds, stream, g_fa_ev_start, g_fa_ev_stop, 0, a);
-    else hipLaunchKernelGGL(kfn, grid, block, lds, stream, a);
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)flash_attn_kernel<264, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)flash_attn_kernel<264, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_done = true;
+    }
+    if (a.f16) {
+        if (g_fa_ev_start) hipExtLaunchKernelGGL((flash_attn_kernel<264, true>), grid, block, lds, stream, g_fa_ev_start, g_fa_ev_stop, 0, a);
+        else hipLaunchKernelGGL((flash_attn_kernel<264, true>), grid, block, lds, stream, a);
+    } else {
+        if (g_fa_ev_start) hipExtLaunchKernelGGL((flash_attn_kernel<264, false>), grid, block, lds, stream, g_fa_ev_start, g_fa_ev_stop, 0, a);
+        else hipLaunchKernelGGL((flash_attn_kernel<264, false>), grid, block, lds, stream, a);
+    }
     return true;
 }
 

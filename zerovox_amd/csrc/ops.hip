@@ -72,6 +72,27 @@ void launch_cast(const void* in, int in_dt, void* out, int out_dt, size_t n, hip
     int blocks = (int)((n + 255) / 256); if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(k_cast, dim3(blocks), dim3(256), 0, s, in, in_dt, out, out_dt, n);
 }
+// ---------------------------------------------------------------- 16-bit transpose  [b][rows][ld_in] -> [b][C][ld_out]
+__global__ __launch_bounds__(256) void k_transpose16(const unsigned short* in, int ld_in, unsigned short* out, int ld_out, int rows, int C) {
+    __shared__ unsigned short tile[64][66];
+    const int b = blockIdx.z, r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const unsigned short* ip = in + (long)b * rows * ld_in;
+    unsigned short* op = out + (long)b * C * ld_out;
+    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+        const int r = i >> 6, c = i & 63;
+        tile[r][c] = (r0 + r < rows && c0 + c < C) ? ip[(long)(r0 + r) * ld_in + c0 + c] : (unsigned short)0;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+        const int c = i >> 6, r = i & 63;
+        if (c0 + c < C && r0 + r < ld_out) op[(long)(c0 + c) * ld_out + r0 + r] = (r0 + r < rows) ? tile[r][c] : (unsigned short)0;
+    }
+}
+void launch_transpose16(const void* in, int ld_in, void* out, int ld_out, int B, int rows, int C, hipStream_t s) {
+    if (rows <= 0) return;
+    hipLaunchKernelGGL(k_transpose16, dim3((C + 63) / 64, (ld_out + 63) / 64, B), dim3(256), 0, s, (const unsigned short*)in, ld_in, (unsigned short*)out, ld_out, rows, C);
+}
+
 void launch_f32_to_bf16(const float* in, bf16_t* out, size_t n, hipStream_t s) { launch_cast(in, DT_F32, out, DT_BF16, n, s); }
 
 // ---------------------------------------------------------------- bf16 split planes of an f32 tensor

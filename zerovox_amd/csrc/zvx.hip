@@ -319,7 +319,7 @@ void upload_weights(zvx_ctx* c) {
             }
         }
     }
-    // StyleTTS decoder in IEEE half (bf16 mode): a second, f16 copy of its convolution weights (cast from the f32 blob, fragment-packed
+    // The mel decoders in IEEE half (bf16 mode): a second, f16 copy of their convolution / projection weights (cast from the f32 blob, fragment-packed
     // like the bf16 ones).  Same MFMA rate, 8x smaller rounding error on weights and activations (every tensor there sits behind a
     // norm: O(1..100), nowhere near 65504; stores saturate).  zvx_set_int("dec_f16", 0) runs the bf16 copies (A/B).
     if (c->dt == DT_BF16) {
@@ -327,7 +327,7 @@ void upload_weights(zvx_ctx* c) {
         size_t htotal = 0;
         for (auto& kv : c->tensors) {
             const Tensor& t = kv.second;
-            if (kv.first.rfind("sty.", 0) != 0 || t.kind != 'w' || t.dtype != DT_BF16 || t.dims.size() != 3 || t.dim(2) % 8) continue;
+            if ((kv.first.rfind("sty.", 0) != 0 && kv.first.rfind("dec.", 0) != 0) || t.kind != 'w' || t.dtype != DT_BF16 || t.dims.size() != 3 || t.dim(2) % 8) continue;
             Tensor hcopy = t; hcopy.dtype = DT_F16; hcopy.kind = 'h';
             htotal += ((t.numel * 2 + 255) & ~(size_t)255) + ((packed_weight_elems(t.dim(0), t.dim(1), t.dim(2)) * 2 + 255) & ~(size_t)255);
             add16.emplace_back(kv.first + ".h16", hcopy);
@@ -445,6 +445,8 @@ struct FftWeights { std::string p; bool scln; const float* bg; long bg_bs; const
 void fft_block(zvx_ctx* c, void* x, int dt, int B, int Lmax, const int* len_dev, int nheads, const FftWeights& w) {
     const int H = c->H, d = H / nheads, Lp = (Lmax + 7) & ~7, F = c->ffn_dim;
     const size_t es = dtype_size(dt);
+    const bool h16 = dt == DT_F16;                                               // the 16-bit tensors of this block are IEEE half (weights: the ".h16" copies)
+    auto wdev = [&](const char* n) { return c->t(w.p + n + (h16 ? ".h16" : "")).dev; };
     void* qk = c->buf("fft.qk", (size_t)B * Lmax * 2 * H * es);
     void* vt = c->buf("fft.vt", (size_t)B * H * Lp * es);
     float* sc = c->fbuf("fft.scores", (size_t)B * nheads * Lmax * Lp);
@@ -492,13 +494,23 @@ void fft_block(zvx_ctx* c, void* x, int dt, int B, int Lmax, const int* len_dev,
     if (split) split_of((const float*)x, H, xs);
     {   // [Q | K] = x Wqk^T + b                                       fs2.py:143-144
         GemmArgs a = gemm_base(dt);
-        a.X = x; a.x_bs = (long)Lmax * H; a.ldx = H; a.W = c->t(w.p + ".wqk").dev; a.ldw = H;
+        a.X = x; a.x_bs = (long)Lmax * H; a.ldx = H; a.W = wdev(".wqk"); a.ldw = H;
         a.M = Lmax; a.N = 2 * H; a.K = H; a.nbatch = B; a.in_len = len_dev; a.out_len = len_dev;
         if (split) { as_split(a, xs, H, w.p + ".wqk"); a.out_dtype = DT_F32; }
         a.bias = c->pf(w.p + ".bqk"); a.bias_mode = 1;
         a.out = qk; a.o_bs = (long)Lmax * 2 * H; a.ldo = 2 * H;
         c->gemm(a);
     }
+    if (h16) {   // half: V = x Wv^T + b on the conv-slab kernel (static weights), then one 16-bit transpose to the key-contiguous layout
+        void* vrow = hbuf;                                                       // [B][Lmax][H]: the FFN buffer is idle here
+        GemmArgs a = gemm_base(dt);
+        a.X = x; a.x_bs = (long)Lmax * H; a.ldx = H; a.W = wdev(".wv"); a.ldw = H;
+        a.M = Lmax; a.N = H; a.K = H; a.nbatch = B; a.in_len = len_dev; a.out_len = len_dev;
+        a.bias = c->pf(w.p + ".bv"); a.bias_mode = 1;
+        a.out = vrow; a.o_bs = (long)Lmax * H; a.ldo = H;
+        c->gemm(a);
+        c->timed(0, (double)B * Lmax * H * 4.0, [&] { launch_transpose16(vrow, H, vt, Lp, B, Lmax, H, c->stream); });
+    } else
     {   // V^T[h*d + j][l] = Wv x^T + b  (stored transposed so that P.V is K-contiguous)   fs2.py:145
         GemmArgs a = gemm_base(dt);
         a.X = c->t(w.p + ".wv").dev; a.x_bs = 0; a.ldx = H; a.W = x; a.w_bs = (long)Lmax * H; a.ldw = H;
@@ -517,7 +529,9 @@ void fft_block(zvx_ctx* c, void* x, int dt, int B, int Lmax, const int* len_dev,
     fa.qk = qk; fa.qk_bs = (long)Lmax * 2 * H; fa.ldq = 2 * H; fa.k_off = H; fa.vt = vt; fa.vt_bs = (long)H * Lp; fa.ldv = Lp;
     fa.out = o; fa.o_bs = (long)Lmax * H; fa.ldo = H; fa.len = len_dev; fa.L = Lmax; fa.D = d; fa.nheads = nheads; fa.nbatch = B;
     fa.scale = (float)(1.0 / pow((double)d, 0.5));
-    const bool flash = dt == DT_BF16 && c->use_flash && launch_flash_attention(fa, c->stream, true);
+    fa.f16 = h16;
+    const bool flash = (dt == DT_BF16 || h16) && c->use_flash && launch_flash_attention(fa, c->stream, true);
+    if (h16 && !flash) fail(ZVX_E_UNSUPPORTED, "half-precision FFT block without the fused attention (head depth %d)", d);
     if (flash) {
         // softmax(Q K^T / sqrt(d)) V in one launch, scores and probabilities stay on chip            fs2.py:47-58
         c->timed(4.0 * B * nheads * (double)Lmax * Lmax * d, (double)B * Lmax * (3.0 * H + H) * es, [&] { launch_flash_attention(fa, c->stream, false); });
@@ -546,7 +560,7 @@ void fft_block(zvx_ctx* c, void* x, int dt, int B, int Lmax, const int* len_dev,
     }
     {   // y = fc(O) + residual                                         fs2.py:158-162
         GemmArgs a = gemm_base(dt);
-        a.X = o; a.x_bs = (long)Lmax * H; a.ldx = H; a.W = c->t(w.p + ".wo").dev; a.ldw = H;
+        a.X = o; a.x_bs = (long)Lmax * H; a.ldx = H; a.W = wdev(".wo"); a.ldw = H;
         a.M = Lmax; a.N = H; a.K = H; a.nbatch = B; a.in_len = len_dev; a.out_len = len_dev;
         a.bias = c->pf(w.p + ".bo"); a.bias_mode = 1;
         a.res = x; a.r_bs = (long)Lmax * H; a.ldr = H; a.res_mode = 1; a.res_dtype = dt;
@@ -561,7 +575,7 @@ void fft_block(zvx_ctx* c, void* x, int dt, int B, int Lmax, const int* len_dev,
     });
     {   // h = relu(conv_k9(x))                                         fs2.py:198-200
         GemmArgs a = gemm_base(dt);
-        a.X = x; a.x_bs = (long)Lmax * H; a.ldx = H; a.W = c->t(w.p + ".w1").dev; a.ldw = H; a.w_ts = (long)F * H;
+        a.X = x; a.x_bs = (long)Lmax * H; a.ldx = H; a.W = wdev(".w1"); a.ldw = H; a.w_ts = (long)F * H;
         a.M = Lmax; a.N = F; a.K = H; a.nbatch = B; a.in_len = len_dev; a.out_len = len_dev;
         set_taps_1d(a, c->ffn_k0, 1);
         a.bias = c->pf(w.p + ".b1"); a.bias_mode = 1; a.act = ACT_RELU;
@@ -576,7 +590,7 @@ void fft_block(zvx_ctx* c, void* x, int dt, int B, int Lmax, const int* len_dev,
     }
     {   // y = conv_k1(h) + residual                                    fs2.py:201-207
         GemmArgs a = gemm_base(dt);
-        a.X = hbuf; a.x_bs = (long)Lmax * F; a.ldx = F; a.W = c->t(w.p + ".w2").dev; a.ldw = F; a.w_ts = (long)H * F;
+        a.X = hbuf; a.x_bs = (long)Lmax * F; a.ldx = F; a.W = wdev(".w2"); a.ldw = F; a.w_ts = (long)H * F;
         a.M = Lmax; a.N = H; a.K = F; a.nbatch = B; a.in_len = len_dev; a.out_len = len_dev;
         set_taps_1d(a, c->ffn_k1, 1);
         a.bias = c->pf(w.p + ".b2"); a.bias_mode = 1;
@@ -716,7 +730,9 @@ void run_encode(zvx_ctx* c, const int32_t* phoneme, const int32_t* puncts, const
 // mel decoders
 // ------------------------------------------------------------------------------------------------
 void decoder_fs2(zvx_ctx* c, const float* feats, const float* spk_d, const int* L_d, int B, int Lmax, float* mel) {
-    const int H = c->H, dt = c->dt;
+    const int H = c->H;
+    // 16-bit mode: IEEE half like the StyleTTS decoder (needs the fused attention: head depth 264), zvx_set_int("dec_f16", 0): bf16
+    const int dt = (c->dt == DT_BF16 && c->dec_f16 && c->use_flash && H / c->dec_heads == 264 && c->has("dec.mel_w.h16")) ? DT_F16 : c->dt;
     const float* pe = c->pf("dec.pe");
     if (Lmax > c->t("dec.pe").dim(0)) {                   // fs2.py:287-294: table recomputed for longer inputs
         std::vector<float> tab((size_t)Lmax * H);
@@ -730,7 +746,7 @@ void decoder_fs2(zvx_ctx* c, const float* feats, const float* spk_d, const int* 
         HIPCHK(hipStreamSynchronize(c->stream));
         pe = d;
     }
-    void* x = c->buf("dec.x", (size_t)B * Lmax * H * c->es());
+    void* x = c->buf("dec.x", (size_t)B * Lmax * H * dtype_size(dt));
     launch_add_pe_cast(feats, pe, x, dt, H, B, Lmax, L_d, H, c->stream);
     float* bg = nullptr; long bg_bs = 0;
     if (c->dec_scln) {      // all 2*layers SCLN affine vectors of the call in one GEMM: [b | g] = W s   (fs2.py:85)
@@ -746,7 +762,7 @@ void decoder_fs2(zvx_ctx* c, const float* feats, const float* spk_d, const int* 
         fft_block(c, x, dt, B, Lmax, L_d, c->dec_heads, w);
     }
     GemmArgs a = gemm_base(dt);                             // mel_linear   fs2.py:313
-    a.X = x; a.x_bs = (long)Lmax * H; a.ldx = H; a.W = c->t("dec.mel_w").dev; a.ldw = H;
+    a.X = x; a.x_bs = (long)Lmax * H; a.ldx = H; a.W = c->t(dt == DT_F16 ? "dec.mel_w.h16" : "dec.mel_w").dev; a.ldw = H;
     a.M = Lmax; a.N = c->n_mels; a.K = H; a.nbatch = B; a.in_len = L_d; a.out_len = L_d;
     a.bias = c->pf("dec.mel_b"); a.bias_mode = 1;
     a.out = mel; a.out_dtype = DT_F32; a.o_bs = (long)Lmax * c->n_mels; a.ldo = c->n_mels;

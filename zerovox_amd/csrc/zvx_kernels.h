@@ -143,6 +143,7 @@ struct FlashArgs {
     void* out; long o_bs; int ldo;                       // [b][L][ldo] bf16, head h at column h*D
     const int* len; int L, D, nheads, nbatch;
     float scale;                                         // 1 / sqrt(D)   (fs2.py:49-50)
+    int f16;                                             // the 16-bit tensors are IEEE half instead of bf16
 };
 bool launch_flash_attention(const FlashArgs& a, hipStream_t stream, bool dry_run);
 // exact-f32 fused attention of the phoneme encoder: Q | K | V columns of one projection buffer, head h at column off + h*D
@@ -159,6 +160,8 @@ void flash_profile_events(hipEvent_t start, hipEvent_t stop);
 // ------------------------------------------------------------------------------------------------
 // Small kernels (ops.hip).  T-typed pointers are void* + dtype.
 // ------------------------------------------------------------------------------------------------
+// 16-bit [b][rows][ld_in] (first C columns) -> [b][C][ld_out] (rows on the fast axis; ld_out >= rows): V -> V^T for the fused attention
+void launch_transpose16(const void* in, int ld_in, void* out, int ld_out, int B, int rows, int C, hipStream_t s);
 void launch_f32_to_bf16(const float* in, bf16_t* out, size_t n, hipStream_t s);
 void launch_cast(const void* in, int in_dt, void* out, int out_dt, size_t n, hipStream_t s);
 
