@@ -312,6 +312,8 @@ def main(argv=None, ctx_factory=default_ctx_factory):
                      "encoder_arithmetic": ("exact f32 MFMA" if (args.exact_encoder or args.precision == "f32") else
                                             "3-plane bf16 split products (f32-class: 5e-5 on the encoder output; --exact-encoder for bit-equal discrete decisions)"),
                      "in_flight": max(1, args.in_flight),
+                     "decoder_arithmetic": ("f32" if args.precision == "f32" else
+                                            "IEEE half weights + activations on the f16 MFMA (log-mel within 2e-2 of the f32 reference); vocoder: bf16"),
                      "wav_delivery": "host (synchronous D2H copy of every step's waveform inside the timed region)" if args.host_out else
                                      "device (rows stay in HBM for the gather / the caller; --host-out times the D2H copy too)"}
     elif args.config == 4:
