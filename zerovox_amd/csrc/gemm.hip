@@ -508,7 +508,7 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs& a, f32x16 (&acc)[T
 // Epilogue for "bias + activation -> bf16" with nothing to read (EPI = ZVX_EPI(0, 0, 1): conv1 of a ResBlock pair,
 // polyphase ConvTranspose): the arithmetic runs in the MFMA layout, only the bf16 results cross the LDS stage (half
 // the bytes of the f32 transpose) and come back as whole channel rows for 16-byte stores.
-template <int TM, int TN>
+template <int TM, int TN, bool F16 = false>
 __device__ __forceinline__ void epilogue_direct(const GemmArgs& a, f32x16 (&acc)[TN][TM], int b, int row_base, int col_base,
                                                 int out_len, int lane, unsigned char* stage /* >= 32*(TN*64+16) bytes, this wave's */) {
     constexpr int NW = TN * 32, EP = NW * 2 + 16, LPR = NW / 8, RPP = 64 / LPR, NP = 32 / RPP;
@@ -534,8 +534,8 @@ __device__ __forceinline__ void epilogue_direct(const GemmArgs& a, f32x16 (&acc)
                 const f32x2 v01 = lrelu2((f32x2){acc[i][j][4 * g], acc[i][j][4 * g + 1]} + (f32x2){bb[i][g].x, bb[i][g].y}, slope);
                 const f32x2 v23 = lrelu2((f32x2){acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]} + (f32x2){bb[i][g].z, bb[i][g].w}, slope);
                 uint2 pk;
-                pk.x = pack_bf16x2(v01.x, v01.y);
-                pk.y = pack_bf16x2(v23.x, v23.y);
+                pk.x = pack16x2(v01.x, v01.y, F16);
+                pk.y = pack16x2(v23.x, v23.y, F16);
                 *(uint2*)(stage + (lane & 31) * EP + (i * 32 + 8 * g + h4) * 2) = pk;
             }
 #pragma unroll
@@ -808,7 +808,7 @@ __global__ __launch_bounds__(256, MINW) void convslab_kernel(const GemmArgs a) {
     }
     __syncthreads();                             // every wave is done with the slab: its LDS becomes the transpose stage
     if (EPI == ZVX_EPI(0, 0, 1))
-        epilogue_direct<TM, TN>(a, acc, b, m0 + wr * (BM / WM), n0 + wc * (BN / WN), out_len, lane, slab + wave * (32 * (TN * 64 + 16)));
+        epilogue_direct<TM, TN, F16>(a, acc, b, m0 + wr * (BM / WM), n0 + wc * (BN / WN), out_len, lane, slab + wave * (32 * (TN * 64 + 16)));
     else
         epilogue_rows<TM, TN, 0, EPI>(a, acc, b, m0 + wr * (BM / WM), n0 + wc * (BN / WN), out_len, lane, slab + wave * (32 * (TN * 32 * 4 + 16)));
 }
@@ -1486,8 +1486,8 @@ void gemm_set_slab_small(int v) { g_slab_small = v; }
 
 template <int BM, int BN, int WM, int WN, int MINW, int R, int EPI = -1>
 static void launch_slab_variant(const GemmArgs& a, dim3 grid, size_t lds, hipStream_t stream) {
-    if constexpr (EPI == -1) {
-        if (a.dtype == DT_F16) {                                   // half operands: the run-time-epilogue variants only (the decoder's launches)
+    if constexpr (EPI == -1 || EPI == ZVX_EPI(0, 0, 1)) {
+        if (a.dtype == DT_F16) {                                   // half operands: the run-time epilogue and the "bias + activation -> 16 bit" one (the decoders' launches)
             if (a.K % SLAB_KC == 0) ZVX_LAUNCH((convslab_kernel<BM, BN, WM, WN, true, MINW, R, EPI, 64, true>), grid, dim3(256), lds, stream, a);
             else ZVX_LAUNCH((convslab_kernel<BM, BN, WM, WN, false, MINW, R, EPI, 64, true>), grid, dim3(256), lds, stream, a);
             return;
@@ -1499,7 +1499,7 @@ static void launch_slab_variant(const GemmArgs& a, dim3 grid, size_t lds, hipStr
 
 // compile-time epilogue mode of a launch (see ZVX_EPI), or -1 when it needs the run-time epilogue
 static int epi_mode_of(const GemmArgs& a) {
-    if (a.alpha != 1.f || a.bias_mode != 1 || !a.bias || a.post_scale || (a.out && a.out_dtype != DT_BF16)) return -1;
+    if (a.alpha != 1.f || a.bias_mode != 1 || !a.bias || a.post_scale || (a.out && a.out_dtype != a.dtype) || a.dtype == DT_F32) return -1;
     if (a.act != ACT_NONE && a.act != ACT_LRELU) return -1;
     if (a.res_mode && (a.res_mode != 2 || a.res_dtype != DT_BF16)) return -1;
     const int am = a.accum ? a.accum_mode : 0;
@@ -1507,6 +1507,7 @@ static int epi_mode_of(const GemmArgs& a) {
     if (!am && a.out_scale != 1.f) return -1;
     if (!a.out && !(am & 2)) return -1;
     const int e = ZVX_EPI(a.res_mode ? 1 : 0, am, a.out ? 1 : 0);
+    if (a.dtype == DT_F16 && e != ZVX_EPI(0, 0, 1)) return -1;                     // half: only the read-nothing epilogue has a compile-time variant
     switch (e) {
         case ZVX_EPI(0, 0, 1): case ZVX_EPI(1, 0, 1): case ZVX_EPI(1, 2, 0): case ZVX_EPI(1, 3, 0): case ZVX_EPI(1, 1, 1): return e;
     }
