@@ -51,8 +51,7 @@ def resources():
 def build(force: bool = False, verbose: bool = True) -> str:
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     headers = [os.path.join(CSRC, "zvx_kernels.h"), os.path.join(CSRC, "mfma_util.h"), os.path.join(os.path.dirname(HERE), "include", "zvx.h")]
-    objs = []
-    for src in SOURCES:
+    def compile_one(src):
         s = os.path.join(CSRC, src)
         o = os.path.join(CSRC, src.replace(".hip", ".o"))
         rj = os.path.join(CSRC, src.replace(".hip", ".resources.json"))
@@ -81,7 +80,14 @@ def build(force: bool = False, verbose: bool = True) -> str:
             spilled = {k: v for k, v in res.items() if v.get("vgpr_spill")}
             if spilled and verbose:
                 print(f"note: {len(spilled)} kernels of {src} spill VGPRs: " + ", ".join(f"{k[:60]}({v['vgpr_spill']})" for k, v in list(spilled.items())[:6]), flush=True)
-        objs.append(o)
+        return o
+
+    # the translation units are independent: compile them side by side (gemm.hip alone takes ~3 minutes; sequentially a build from
+    # scratch is ~6).  ZVX_BUILD_JOBS caps the number of concurrent hipcc processes (each needs 1-2 GB).
+    from concurrent.futures import ThreadPoolExecutor
+    jobs = max(1, int(os.environ.get("ZVX_BUILD_JOBS", "4")))
+    with ThreadPoolExecutor(max_workers=jobs) as ex:
+        objs = list(ex.map(compile_one, SOURCES))
     if force or _stale(LIB, objs):
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-ldl", "-o", LIB]
         if verbose:
