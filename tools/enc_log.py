@@ -1,3 +1,4 @@
+"""Per-launch timeline of the encoder + variance adaptor for B utterances of T phonemes (dev aid): python tools/enc_log.py B T"""
 import os, sys
 import numpy as np
 sys.path.insert(0, "/root/repo"); sys.path.insert(0, os.getcwd())
