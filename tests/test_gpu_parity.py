@@ -667,6 +667,31 @@ def test_single_request_sizing_does_not_change_a_bit():
         ctx.set_int("rs_seg_min", 0); ctx.set_int("slab_small", 2)
 
 
+@pytest.mark.parametrize("voc,prec", [("v1", "bf16"), ("v1", "f32"), ("v2", "bf16"), ("v3", "bf16")])
+def test_single_request_overlap_does_not_change_a_bit(voc, prec):
+    """Small batches fuse InstanceNorm into one launch (norm_fuse_maxb), run the duration predictor on a second stream beside the
+    pitch predictor (va_overlap_maxb) and run the non-final conv pairs of a vocoder stage's 2nd / 3rd ResBlock on streams of their
+    own (voc_overlap_maxb).  Scheduling only: the FIRST call of a fresh context (buffers just allocated) and later calls equal the
+    serial schedule bit for bit, for 1, 2 and 4 utterances, ragged."""
+    from zerovox_amd import _lib
+    cfg, sd = tts_sd("styletts"); h, hsd = voc_sd(voc)
+    man, blob = pack.pack_model(cfg, sd, h, hsd, prec)
+    ph, pu, T, spk, dur = synthetic.batch(4, 48, 31, "const7")
+    T = np.array([48, 17, 33, 5], np.int32)
+    for b in range(4): ph[b, T[b]:] = 0; pu[b, T[b]:] = 0; dur[b, T[b]:] = 0
+    ser = _lib.Context(man, blob, 0)
+    for k in ("norm_fuse_maxb", "va_overlap_maxb", "voc_overlap_maxb"): ser.set_int(k, 0)
+    for B in (1, 2, 4):
+        ref = ser.synthesize(ph[:B], pu[:B], T[:B], spk[:B], dur[:B], None, want_mel=True)
+        fresh = _lib.Context(man, blob, 0)            # defaults: all three on
+        for rep in range(3):
+            got = fresh.synthesize(ph[:B], pu[:B], T[:B], spk[:B], dur[:B], None, want_mel=True)
+            assert np.array_equal(got["mel"], ref["mel"]), (B, rep)
+            assert all(np.array_equal(g, r) for g, r in zip(got["wav"], ref["wav"])), (B, rep)
+        fresh.close()
+    ser.close()
+
+
 def test_batches_in_flight_on_two_contexts_equal_the_sequential_calls():
     """ZeroVox.synthesize_batches: batches alternate over two contexts from worker threads (batch i + 1's front end under batch
     i's vocoder); results come back in order and bit-identical to synthesize_batch, for ragged batches of different shapes."""

@@ -58,6 +58,12 @@ struct zvx_ctx {
     hipStream_t stream = nullptr;
     // multi-GPU (zvx_comm_*): communicator, its own stream, and per-buffer "the gather has read this" events
     hipStream_t comm_stream = nullptr;
+    hipStream_t voc_aux[2] = {nullptr, nullptr};   // single requests: the non-final pairs of the 2nd / 3rd ResBlock of a vocoder stage run beside the 1st
+    hipEvent_t voc_ev[3] = {nullptr, nullptr, nullptr};
+    int voc_overlap_maxb = 4;              // zvx_set_int("voc_overlap_maxb", n): batches of at most n utterances use them (0: never; A/B)
+    hipStream_t aux_stream = nullptr;      // second compute stream: the duration predictor of a small batch beside the pitch predictor
+    hipEvent_t ev_aux[2] = {nullptr, nullptr};
+    int va_overlap_maxb = 4;               // zvx_set_int("va_overlap_maxb", n): batches of at most n utterances overlap the two predictors (0: never; A/B)
     ncclComm_t comm = nullptr;
     int rank = 0, world = 1;
     hipEvent_t ev_compute = nullptr;
@@ -86,6 +92,7 @@ struct zvx_ctx {
     int rs_prof = 0;                       // zvx_set_int("rs_prof", 1): per-wave cycle counters of the streaming kernels (library built with -DRS_PROFILE)
     int enc_split = 0;                     // bf16 mode: the f32 GEMMs of the phoneme encoder / variance adaptor run as 3-plane bf16 GEMMs
     const void* fft_xs_ready = nullptr;     // fft.xs holds the split planes of this buffer (written by the previous FFT block's last LayerNorm)
+    int norm_fuse_maxb = 2;                // zvx_set_int("norm_fuse_maxb", n): batches of at most n utterances take the one-launch InstanceNorm of the StyleTTS decoder (0: never; A/B)
     int dec_f16 = 1;                       // zvx_set_int("dec_f16", 0): StyleTTS decoder activations / weights in bf16 instead of IEEE half (A/B)
     int use_attn_f32 = 1;                  // zvx_set_int("attn_f32", 0): the encoder's attention as V^T / score / P.V GEMMs + softmax (A/B)
     int use_flash = 1;                     // zvx_set_int("flash", 0): the decoder's attention as score GEMM + softmax + PV GEMM (A/B)
@@ -609,11 +616,11 @@ void fft_block(zvx_ctx* c, void* x, int dt, int B, int Lmax, const int* len_dev,
 // ------------------------------------------------------------------------------------------------
 // encoder + variance adaptor + length regulator   (fs2.py:732-775)
 // ------------------------------------------------------------------------------------------------
-void variance_predictor(zvx_ctx* c, const char* nm, const float* x, int B, int Tmax, const int* T_dev, float* pred) {
+void variance_predictor(zvx_ctx* c, const char* nm, const float* x, int B, int Tmax, const int* T_dev, float* pred, const char* bufsfx = "") {
     const int H = c->H, Fv = c->vp_dim;
     const std::string p = std::string("va.") + nm;
-    float* h1 = c->fbuf("va.h1", (size_t)B * Tmax * Fv);
-    float* h2 = c->fbuf("va.h2", (size_t)B * Tmax * Fv);
+    float* h1 = c->fbuf(std::string("va.h1") + bufsfx, (size_t)B * Tmax * Fv);      // (own buffers when it runs beside another predictor)
+    float* h2 = c->fbuf(std::string("va.h2") + bufsfx, (size_t)B * Tmax * Fv);
     {
         GemmArgs a = gemm_base(DT_F32);
         a.X = x; a.x_bs = (long)Tmax * H; a.ldx = H; a.W = c->t(p + ".c1").dev; a.ldw = H; a.w_ts = (long)Fv * H;
@@ -696,8 +703,28 @@ void run_encode(zvx_ctx* c, const int32_t* phoneme, const int32_t* puncts, const
     HIPCHK(hipMemsetAsync(logd, 0, nid * 4, c->stream)); HIPCHK(hipMemsetAsync(pitch, 0, nid * 4, c->stream)); HIPCHK(hipMemsetAsync(energy, 0, nid * 4, c->stream));
     int* pidx = c->ibuf("va.pitch_idx", nid); int* eidx = c->ibuf("va.energy_idx", nid);
     HIPCHK(hipMemsetAsync(pidx, 0, nid * 4, c->stream)); HIPCHK(hipMemsetAsync(eidx, 0, nid * 4, c->stream));
-    variance_predictor(c, "dur", x, B, Tmax, T_d, logd);                                               // fs2.py:663
-    variance_predictor(c, "pitch", x, B, Tmax, T_d, pitch);                                            // fs2.py:665-668
+    // The duration and the pitch predictor read the same x and are independent (fs2.py:663-668): for small batches -- launches that
+    // leave most of the chip idle -- the duration predictor runs on a second stream beside the pitch predictor.  Same kernels, same
+    // arithmetic; x is only modified (pitch embedding) after both have read it.
+    if (B <= c->va_overlap_maxb) {
+        if (!c->aux_stream) {
+            HIPCHK(hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
+            HIPCHK(hipEventCreateWithFlags(&c->ev_aux[0], hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&c->ev_aux[1], hipEventDisableTiming));
+        }
+        HIPCHK(hipEventRecord(c->ev_aux[0], c->stream));
+        HIPCHK(hipStreamWaitEvent(c->aux_stream, c->ev_aux[0], 0));
+        {
+            struct Swap { zvx_ctx* c; hipStream_t keep; ~Swap() { c->stream = keep; } } sw{c, c->stream};   // restored on every path out
+            c->stream = c->aux_stream;
+            variance_predictor(c, "dur", x, B, Tmax, T_d, logd, ".dur");
+            HIPCHK(hipEventRecord(c->ev_aux[1], c->aux_stream));
+        }
+        variance_predictor(c, "pitch", x, B, Tmax, T_d, pitch);
+        HIPCHK(hipStreamWaitEvent(c->stream, c->ev_aux[1], 0));
+    } else {
+        variance_predictor(c, "dur", x, B, Tmax, T_d, logd);                                           // fs2.py:663
+        variance_predictor(c, "pitch", x, B, Tmax, T_d, pitch);                                        // fs2.py:665-668
+    }
     launch_bucket_embed_add(pitch, c->pf("va.pitch_emb"), c->n_bins, x, H, H, pidx, B, Tmax, T_d, c->stream);
     variance_predictor(c, "energy", x, B, Tmax, T_d, energy);                                          // fs2.py:669-672
     launch_bucket_embed_add(energy, c->pf("va.energy_emb"), c->n_bins, x, H, H, eidx, B, Tmax, T_d, c->stream);
@@ -791,6 +818,10 @@ void sty_norm(const StyCtx& s, const void* x, int ldx, int C, void* y, int ldy, 
     const std::string keep = s.c->tag;
     s.c->tag = "decoder.norm";
     s.c->timed(0, (double)s.B * s.Lmax * C * s.c->es() * 3.0, [&] {          // statistics pass (read) + normalise pass (read + write)
+        if (s.dt != DT_F32 && s.B <= s.c->norm_fuse_maxb) {       // single requests: one launch (bit-identical)
+            launch_instnorm_fused(x, s.dt, ldx, y, s.dt, ldy, s.B, s.Lmax, s.L_d, C, 1e-5f, s.mean, s.rstd, gamma, beta, g_bs, one_plus, act, 0.2f, s.c->stream);
+            return;
+        }
         launch_instnorm_stats(x, s.dt, ldx, s.B, s.Lmax, s.L_d, C, 1e-5f, s.mean, s.rstd, s.c->stream);
         launch_norm_affine_act(x, s.dt, ldx, y, s.dt, ldy, s.B, s.Lmax, s.L_d, C, s.mean, s.rstd, gamma, beta, g_bs, one_plus,
                                act, 0.2f, s.c->stream);
@@ -911,6 +942,15 @@ void run_vocoder(zvx_ctx* c, const float* mel, int ldm, int Lmel_max, const int*
     void* T1 = c->buf("voc.T1", maxel * es);
     void* PP[2] = {c->buf("voc.PP0", maxel * es), c->buf("voc.PP1", maxel * es)};
     void* XS = c->buf("voc.XS", maxel * es);     // running sum over the resblocks of a stage, in the activation dtype
+    // temporaries of the ResBlocks that run beside the first one (single requests, below).  Taken HERE: a new buffer is zero-filled
+    // on the main stream, which the side streams only follow from the stage-input event on
+    const bool side_ok = nk >= 2 && nk <= 3 && B <= c->voc_overlap_maxb && !(c->voc_chunk > 0 && c->voc_chunk < B);
+    void* sideT1[2] = {nullptr, nullptr}; void* sidePP[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+    if (side_ok)
+        for (int j = 1; j < nk; j++) {
+            sideT1[j - 1] = c->buf("voc.T1." + std::to_string(j), maxel * es);
+            sidePP[j - 1][0] = c->buf("voc.PP0." + std::to_string(j), maxel * es); sidePP[j - 1][1] = c->buf("voc.PP1." + std::to_string(j), maxel * es);
+        }
 
     c->tag = "voc.pre";
     launch_mel_pad(mel, DT_F32, ldm, Lmel_max, mel_len_d, vin, dt, nm, Pmax, P_d, B, nm, c->stream);     // model.py:331-335
@@ -970,7 +1010,35 @@ void run_vocoder(zvx_ctx* c, const float* mel, int ldm, int Lmel_max, const int*
             void* T1s = (char*)T1 + boff; void* XSs = (char*)XS + boff; void* As = (char*)A + boff;
             void* PPs[2] = {(char*)PP[0] + boff, (char*)PP[1] + boff};
             const int* lens = len + b0;
+            // Single requests: the ResBlocks of a stage only meet in the running sum, which their LAST pair updates.  Everything
+            // before that (two of three pairs) runs on a stream of its own for the 2nd and 3rd ResBlock, with its own temporaries;
+            // the last pairs stay on the main stream in the order 1, 2, 3, so xs accumulates exactly as before (bit-identical).
+            // The critical path of a per-pair stage drops from 18 to 10 launches.
+            const bool overlap = side_ok;
+            hipStream_t const main_stream = c->stream;
+            struct Restore { zvx_ctx* c; hipStream_t keep; ~Restore() { c->stream = keep; } } restore{c, main_stream};
+            if (overlap) {
+                for (int q = 0; q < 2; q++) if (!c->voc_aux[q]) HIPCHK(hipStreamCreateWithFlags(&c->voc_aux[q], hipStreamNonBlocking));
+                for (int q = 0; q < 3; q++) if (!c->voc_ev[q]) HIPCHK(hipEventCreateWithFlags(&c->voc_ev[q], hipEventDisableTiming));
+                HIPCHK(hipEventRecord(c->voc_ev[0], main_stream));      // the stage input (and everything the previous stage read) is settled
+            }
             for (int j = 0; j < nk; j++) {
+                hipStream_t const my_aux = (overlap && j >= 1) ? c->voc_aux[j - 1] : nullptr;
+                bool on_aux = false;
+                if (my_aux) {
+                    HIPCHK(hipStreamWaitEvent(my_aux, c->voc_ev[0], 0));
+                    T1s = sideT1[j - 1]; PPs[0] = sidePP[j - 1][0]; PPs[1] = sidePP[j - 1][1];
+                } else {
+                    T1s = (char*)T1 + boff; PPs[0] = (char*)PP[0] + boff; PPs[1] = (char*)PP[1] + boff;
+                }
+                auto to_aux = [&] { if (my_aux && !on_aux) { c->stream = my_aux; on_aux = true; } };
+                auto to_main = [&] {
+                    if (on_aux) {
+                        HIPCHK(hipEventRecord(c->voc_ev[j], my_aux));
+                        c->stream = main_stream; on_aux = false;
+                        HIPCHK(hipStreamWaitEvent(main_stream, c->voc_ev[j], 0));
+                    }
+                };
                 const int k = c->voc_rb_k[j];
                 const std::vector<int>& dil = c->voc_rb_d[j];
                 const int nd = (int)dil.size();
@@ -1007,14 +1075,17 @@ void run_vocoder(zvx_ctx* c, const float* mel, int ldm, int Lmel_max, const int*
                     };
                     if (packed_ok) {
                         StreamArgs whole = chain(0, nd, X0s, true);
+                        to_main();
                         if (c->run_stream(whole)) t_first = nd;
                         else if (nd == 3) {
                             StreamArgs head = chain(0, 2, X0s, false);
                             StreamArgs probe = chain(2, 1, PPs[pp], true);
                             if (launch_resstream(head, c->stream, true) >= 0 && launch_resstream(probe, c->stream, true) >= 0) {
+                                to_aux();
                                 c->run_stream(head);
                                 cur = PPs[pp]; pp ^= 1;
                                 StreamArgs tail = chain(2, 1, cur, true);
+                                to_main();
                                 c->run_stream(tail);
                                 t_first = nd;
                             }
@@ -1023,6 +1094,7 @@ void run_vocoder(zvx_ctx* c, const float* mel, int ldm, int Lmel_max, const int*
                 }
                 for (int t = t_first; t < nd; t++) {
                     const bool last = (t == nd - 1);
+                    if (last) to_main(); else to_aux();
                     const void* cin_buf = cur;
                     auto rb_base = [&] {
                         GemmArgs a = gemm_base(dt);
@@ -1380,6 +1452,9 @@ void zvx_destroy(zvx_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     zvx_comm_destroy(c);
+    for (int i = 0; i < 2; i++) if (c->voc_aux[i]) { (void)hipStreamSynchronize(c->voc_aux[i]); (void)hipStreamDestroy(c->voc_aux[i]); }
+    for (int i = 0; i < 3; i++) if (c->voc_ev[i]) (void)hipEventDestroy(c->voc_ev[i]);
+    if (c->aux_stream) { (void)hipStreamSynchronize(c->aux_stream); (void)hipStreamDestroy(c->aux_stream); (void)hipEventDestroy(c->ev_aux[0]); (void)hipEventDestroy(c->ev_aux[1]); }
     for (auto& kv : c->bufs) if (kv.second.base) (void)hipFree(kv.second.base);
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
     if (c->stream) {
@@ -1421,6 +1496,9 @@ zvx_status zvx_set_int(zvx_ctx* c, const char* key, int64_t value) {
         else if (std::string(key) == "flash") c->use_flash = (int)value;
         else if (std::string(key) == "attn_f32") c->use_attn_f32 = (int)value;
         else if (std::string(key) == "dec_f16") c->dec_f16 = (int)value;
+        else if (std::string(key) == "norm_fuse_maxb") c->norm_fuse_maxb = (int)value;
+        else if (std::string(key) == "va_overlap_maxb") c->va_overlap_maxb = (int)value;
+        else if (std::string(key) == "voc_overlap_maxb") c->voc_overlap_maxb = (int)value;
         else if (std::string(key) == "enc_split") c->enc_split = (c->dt == DT_BF16 && value && c->has("enc.0.wqk.s3")) ? 1 : 0;
         else if (std::string(key) == "rs_prof") c->rs_prof = (int)value;
         else if (std::string(key) == "rs_opt") c->rs_opt = (int)value;

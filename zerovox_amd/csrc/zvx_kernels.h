@@ -161,6 +161,9 @@ void flash_profile_events(hipEvent_t start, hipEvent_t stop);
 // Small kernels (ops.hip).  T-typed pointers are void* + dtype.
 // ------------------------------------------------------------------------------------------------
 // 16-bit [b][rows][ld_in] (first C columns) -> [b][C][ld_out] (rows on the fast axis; ld_out >= rows): V -> V^T for the fused attention
+// single requests: InstanceNorm statistics + affine + activation of a 16-bit tensor in ONE launch (bit-identical to the two-kernel path)
+void launch_instnorm_fused(const void* x, int x_dt, int ldx, void* y, int y_dt, int ldy, int B, int Lmax, const int* L, int C, float eps,
+                           float* mean, float* rstd, const float* gamma, const float* beta, long g_bs, int one_plus, int act, float slope, hipStream_t s);
 void launch_transpose16(const void* in, int ld_in, void* out, int ld_out, int B, int rows, int C, hipStream_t s);
 void launch_f32_to_bf16(const float* in, bf16_t* out, size_t n, hipStream_t s);
 void launch_cast(const void* in, int in_dt, void* out, int out_dt, size_t n, hipStream_t s);
