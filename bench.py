@@ -237,6 +237,7 @@ def main(argv=None, ctx_factory=default_ctx_factory):
     ap.add_argument("--exact-encoder", action="store_true", help="bf16 mode: phoneme encoder on the exact-f32 MFMA instead of 3-plane bf16 split products (bucket ids / durations bit-equal to the f32 path)")
     ap.add_argument("--host-out", action="store_true", help="config 2: deliver every step's waveform to host memory (D2H copy inside the timed region), as the reference's tts_ex does")
     ap.add_argument("--in-flight", type=int, default=1, help="config 2, one GPU: steps alternate over this many contexts (each its own stream): batch i+1's latency-paced encoder / decoder run under batch i's vocoder")
+    ap.add_argument("--set", action="append", default=[], metavar="KEY=INT", help="zvx_set_int(KEY, INT) on every context before the first step (A/B of a runtime switch; echoed in config.overrides)")
     ap.add_argument("--profile", type=int, default=2, help="0 none, 1 stage events, 2 + per-launch events on the dominant kernel")
     args = ap.parse_args(argv)
 
@@ -259,6 +260,8 @@ def main(argv=None, ctx_factory=default_ctx_factory):
     hop, sr = cfg["audio"]["hop_size"], cfg["audio"]["sampling_rate"]
     if args.exact_encoder:
         ctx.set_int("enc_split", 0)
+    overrides = {kv.split("=", 1)[0]: int(kv.split("=", 1)[1]) for kv in args.set}
+    for k, v in overrides.items(): ctx.set_int(k, v)
     if world > 1:
         ctx.comm_init(exchange_comm_id(rank, world, ctx.comm_unique_id), rank, world)
         flush_c_stdio()                              # RCCL's version banner (C stdio, block-buffered on a pipe) goes out now, not after the JSON line
@@ -290,6 +293,7 @@ def main(argv=None, ctx_factory=default_ctx_factory):
             c2, _m = ctx_factory(args, local_rank)
             if args.exact_encoder:
                 c2.set_int("enc_split", 0)
+            for k, v in overrides.items(): c2.set_int(k, v)
             c2.comm_init(None, 0, 1)
             more_ctx.append((c2, [c2.dev_alloc(B * row_bytes) for _ in range(2)]))
 
@@ -409,7 +413,7 @@ def main(argv=None, ctx_factory=default_ctx_factory):
             "value": value, "unit": unit, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
-            "config": {"workload": workload, **cfg_extra},
+            "config": {"workload": workload, **cfg_extra, **({"overrides": overrides} if overrides else {})},
             "stage_ms_last_step": stage_ms, "output_ok": ok, "src_sha16": src_sha16(),
         }
         if unit == "samples/s":
