@@ -38,8 +38,26 @@ def pmc_summary(path):
     return rows
 
 
+def timeline(path, n):
+    """The last n dispatches in start order: offset from the first of them, duration, gap to the latest end before it, queue."""
+    db = sqlite3.connect(path)
+    cur = db.cursor()
+    cols = [r[1] for r in cur.execute("pragma table_info(kernels)").fetchall()]
+    q = "queue_id" if "queue_id" in cols else ("stream_id" if "stream_id" in cols else "0")
+    rows = cur.execute(f"select name, start, end, {q}, grid_x from kernels order by start desc limit {int(n)}").fetchall()[::-1]
+    t0 = rows[0][1]; last_end = rows[0][1]
+    print(f"{'t_us':>9} {'dur_us':>8} {'gap_us':>8} {'q':>3} {'grid':>8}  kernel")
+    for name, st, en, qi, gx in rows:
+        print(f"{(st - t0) / 1e3:9.1f} {(en - st) / 1e3:8.1f} {(st - last_end) / 1e3:8.1f} {qi!s:>3} {gx:8d}  {name[:120]}")
+        last_end = max(last_end, en)
+    busy = sum(r[2] - r[1] for r in rows)
+    print(f"span {(max(r[2] for r in rows) - t0) / 1e3:.1f} us, sum of durations {busy / 1e3:.1f} us, {len(rows)} dispatches")
+
+
 if __name__ == "__main__":
-    if "--pmc" in sys.argv:
+    if "--timeline" in sys.argv:
+        timeline(sys.argv[1], sys.argv[sys.argv.index("--timeline") + 1])
+    elif "--pmc" in sys.argv:
         pmc_summary(sys.argv[1])
     else:
         main()

@@ -85,6 +85,7 @@ struct zvx_ctx {
     // per-call state
     int B = 0, Tmax = 0, Lmax = 0;
     std::vector<int> T_host, mel_len_host;
+    std::vector<int> in_stage;            // host staging of a call's integer inputs (one upload)
     bool have_features = false, have_mel = false;
     // profiling
     int profile = 0;
@@ -144,6 +145,19 @@ struct zvx_ctx {
             d.cap = cap;
         }
         return d.p;
+    }
+    // Several small named buffers as slices of ONE allocation, so that a call zero-fills / uploads them with one operation instead of
+    // one each (a single request is paced by its launch count).  Lookups by name keep working; the slices are re-cut on every call.
+    char* carve(const std::string& pool, const std::vector<std::string>& names, size_t bytes_each, size_t* stride_out) {
+        const size_t stride = (bytes_each + 255) & ~(size_t)255;
+        char* base = (char*)buf(pool, stride * names.size());
+        for (size_t i = 0; i < names.size(); i++) {
+            DevBuf& d = bufs[names[i]];
+            if (d.base) { HIPCHK(hipStreamSynchronize(stream)); HIPCHK(hipFree(d.base)); d.base = nullptr; }
+            d.p = base + i * stride; d.cap = stride;
+        }
+        *stride_out = stride;
+        return base;
     }
     int* ibuf(const std::string& name, size_t n) { return (int*)buf(name, n * sizeof(int)); }
     float* fbuf(const std::string& name, size_t n) { return (float*)buf(name, n * sizeof(float)); }
@@ -663,10 +677,21 @@ void run_encode(zvx_ctx* c, const int32_t* phoneme, const int32_t* puncts, const
     }
     c->B = B; c->Tmax = Tmax; c->have_features = false; c->have_mel = false;
     const size_t nid = (size_t)B * Tmax;
-    int* ph_d = c->upload_ints("in.phoneme", phoneme, nid);
-    int* pu_d = c->upload_ints("in.puncts", puncts, nid);
-    int* T_d = c->upload_ints("in.T", T, B);
-    int* dur_in = duration ? c->upload_ints("in.duration", duration, nid) : nullptr;
+    // the integer inputs travel as one upload
+    size_t in_stride = 0;
+    char* in_base = c->carve("in.ints", {"in.phoneme", "in.puncts", "in.duration", "in.T"}, std::max(nid, (size_t)B) * 4, &in_stride);
+    c->in_stage.resize(in_stride * 4 / sizeof(int));
+    {
+        int* hs = c->in_stage.data();
+        const size_t st = in_stride / sizeof(int);
+        memcpy(hs, phoneme, nid * 4); memcpy(hs + st, puncts, nid * 4);
+        if (duration) memcpy(hs + 2 * st, duration, nid * 4);
+        memcpy(hs + 3 * st, T, (size_t)B * 4);
+        HIPCHK(hipMemcpyAsync(in_base, hs, in_stride * 4, hipMemcpyHostToDevice, c->stream));
+    }
+    int* ph_d = (int*)in_base; int* pu_d = (int*)(in_base + in_stride);
+    int* dur_in = duration ? (int*)(in_base + 2 * in_stride) : nullptr;
+    int* T_d = (int*)(in_base + 3 * in_stride);
     float* spk_d = c->fbuf("in.spk", (size_t)B * H);
     HIPCHK(hipMemcpyAsync(spk_d, spk, (size_t)B * H * 4, hipMemcpyHostToDevice, c->stream));
 
@@ -699,10 +724,12 @@ void run_encode(zvx_ctx* c, const int32_t* phoneme, const int32_t* puncts, const
     c->stage_begin(ZVX_T_VARIANCE);
     c->tag = "variance";
     HIPCHK(hipMemcpyAsync(c->fbuf("enc.out", nid * H), x, nid * H * 4, hipMemcpyDeviceToDevice, c->stream));
-    float* logd = c->fbuf("va.logd", nid); float* pitch = c->fbuf("va.pitch", nid); float* energy = c->fbuf("va.energy", nid);
-    HIPCHK(hipMemsetAsync(logd, 0, nid * 4, c->stream)); HIPCHK(hipMemsetAsync(pitch, 0, nid * 4, c->stream)); HIPCHK(hipMemsetAsync(energy, 0, nid * 4, c->stream));
-    int* pidx = c->ibuf("va.pitch_idx", nid); int* eidx = c->ibuf("va.energy_idx", nid);
-    HIPCHK(hipMemsetAsync(pidx, 0, nid * 4, c->stream)); HIPCHK(hipMemsetAsync(eidx, 0, nid * 4, c->stream));
+    // the per-phoneme outputs that padding positions must read as zero: one zero-fill for all six
+    size_t va_stride = 0;
+    char* va_base = c->carve("va.zeroed", {"va.logd", "va.pitch", "va.energy", "va.pitch_idx", "va.energy_idx", "va.dur"}, nid * 4, &va_stride);
+    HIPCHK(hipMemsetAsync(va_base, 0, va_stride * 6, c->stream));
+    float* logd = (float*)va_base; float* pitch = (float*)(va_base + va_stride); float* energy = (float*)(va_base + 2 * va_stride);
+    int* pidx = (int*)(va_base + 3 * va_stride); int* eidx = (int*)(va_base + 4 * va_stride);
     // The duration and the pitch predictor read the same x and are independent (fs2.py:663-668): for small batches -- launches that
     // leave most of the chip idle -- the duration predictor runs on a second stream beside the pitch predictor.  Same kernels, same
     // arithmetic; x is only modified (pitch embedding) after both have read it.
@@ -732,8 +759,7 @@ void run_encode(zvx_ctx* c, const int32_t* phoneme, const int32_t* puncts, const
 
     c->stage_begin(ZVX_T_LENREG);
     c->tag = "lenreg";
-    int* dur = c->ibuf("va.dur", nid); int* cum = c->ibuf("va.cum", nid); int* ml = c->ibuf("va.mel_len", B);
-    HIPCHK(hipMemsetAsync(dur, 0, nid * 4, c->stream));
+    int* dur = (int*)(va_base + 5 * va_stride); int* cum = c->ibuf("va.cum", nid); int* ml = c->ibuf("va.mel_len", B);
     launch_durations(dur_in, logd, dur, cum, ml, B, Tmax, T_d, c->stream);
     c->mel_len_host.resize(B);
     HIPCHK(hipMemcpyAsync(c->mel_len_host.data(), ml, B * sizeof(int), hipMemcpyDeviceToHost, c->stream));
