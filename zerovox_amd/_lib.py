@@ -233,7 +233,8 @@ class Context:
             if Lmax <= 0:
                 raise ZvxError(ZVX_E_INVALID, "predicted durations need Lmax_cap (or use encode/decode/vocode)")
         mel_len = np.zeros(B, np.int32)
-        logd = np.zeros((B, Tmax), np.float32)
+        # a queued call (device output, no_sync) must not ask for host outputs: a copy into pageable memory would wait for the stream
+        logd = None if (wav_device_ptr is not None and no_sync) else np.zeros((B, Tmax), np.float32)
         mel = np.zeros((B, max(Lmax, 1), self.n_mels), np.float32) if want_mel else None
         flags = ZVX_PCM16 if pcm16 else 0
         if wav_device_ptr is not None:

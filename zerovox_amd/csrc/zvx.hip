@@ -161,9 +161,40 @@ struct zvx_ctx {
     }
     int* ibuf(const std::string& name, size_t n) { return (int*)buf(name, n * sizeof(int)); }
     float* fbuf(const std::string& name, size_t n) { return (float*)buf(name, n * sizeof(float)); }
+    // Small host -> device copies go through PINNED memory owned by the context.  A copy from pageable memory makes the runtime
+    // wait for the stream before it returns; from pinned memory it is queued like a launch.  With forced durations and a device
+    // output (ZVX_NO_SYNC) a whole zvx_synthesize call then only QUEUES work: the host runs ahead of the GPU by a call or more and
+    // a slow or preempted host thread no longer shows up as GPU idle time.  Two arenas alternate between API calls; an arena is
+    // reused only after the event recorded behind its last copy has passed.
+    struct Arena { char* p = nullptr; size_t cap = 0, cur = 0; hipEvent_t ev = nullptr; bool pending = false; };
+    Arena arena[2];
+    int arena_i = 0;
+    static constexpr size_t ARENA_BYTES = 2u << 20;
+    void arena_begin() {
+        arena_i ^= 1;
+        Arena& a = arena[arena_i];
+        if (a.pending) { HIPCHK(hipEventSynchronize(a.ev)); a.pending = false; }
+        a.cur = 0;
+    }
+    void arena_end() {
+        Arena& a = arena[arena_i];
+        if (!a.cur || !stream) return;
+        if (!a.ev) HIPCHK(hipEventCreateWithFlags(&a.ev, hipEventDisableTiming));
+        HIPCHK(hipEventRecord(a.ev, stream));
+        a.pending = true;
+    }
+    void upload(void* dst, const void* src, size_t bytes) {
+        Arena& a = arena[arena_i];
+        const size_t need = (bytes + 63) & ~(size_t)63;
+        if (!a.p) { HIPCHK(hipHostMalloc((void**)&a.p, ARENA_BYTES, hipHostMallocDefault)); a.cap = ARENA_BYTES; }
+        if (a.cur + need > a.cap) { HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream)); return; }   // large: as before
+        memcpy(a.p + a.cur, src, bytes);
+        HIPCHK(hipMemcpyAsync(dst, a.p + a.cur, bytes, hipMemcpyHostToDevice, stream));
+        a.cur += need;
+    }
     int* upload_ints(const std::string& name, const int* v, size_t n) {
         int* d = ibuf(name, n);
-        HIPCHK(hipMemcpyAsync(d, v, n * sizeof(int), hipMemcpyHostToDevice, stream));
+        upload(d, v, n * sizeof(int));
         return d;
     }
     size_t es() const { return dtype_size(dt); }
@@ -677,23 +708,24 @@ void run_encode(zvx_ctx* c, const int32_t* phoneme, const int32_t* puncts, const
     }
     c->B = B; c->Tmax = Tmax; c->have_features = false; c->have_mel = false;
     const size_t nid = (size_t)B * Tmax;
-    // the integer inputs travel as one upload
+    // the call's small inputs (ids, lengths, forced durations, speaker embeddings) travel as ONE upload
     size_t in_stride = 0;
-    char* in_base = c->carve("in.ints", {"in.phoneme", "in.puncts", "in.duration", "in.T"}, std::max(nid, (size_t)B) * 4, &in_stride);
-    c->in_stage.resize(in_stride * 4 / sizeof(int));
+    char* in_base = c->carve("in.all", {"in.phoneme", "in.puncts", "in.duration", "in.T", "in.spk"},
+                             std::max(std::max(nid, (size_t)B), (size_t)B * H) * 4, &in_stride);
+    c->in_stage.resize(in_stride * 5 / sizeof(int));
     {
         int* hs = c->in_stage.data();
         const size_t st = in_stride / sizeof(int);
         memcpy(hs, phoneme, nid * 4); memcpy(hs + st, puncts, nid * 4);
         if (duration) memcpy(hs + 2 * st, duration, nid * 4);
         memcpy(hs + 3 * st, T, (size_t)B * 4);
-        HIPCHK(hipMemcpyAsync(in_base, hs, in_stride * 4, hipMemcpyHostToDevice, c->stream));
+        memcpy(hs + 4 * st, spk, (size_t)B * H * 4);
+        c->upload(in_base, hs, in_stride * 5);
     }
     int* ph_d = (int*)in_base; int* pu_d = (int*)(in_base + in_stride);
     int* dur_in = duration ? (int*)(in_base + 2 * in_stride) : nullptr;
     int* T_d = (int*)(in_base + 3 * in_stride);
-    float* spk_d = c->fbuf("in.spk", (size_t)B * H);
-    HIPCHK(hipMemcpyAsync(spk_d, spk, (size_t)B * H * 4, hipMemcpyHostToDevice, c->stream));
+    float* spk_d = (float*)(in_base + 4 * in_stride);
 
     c->stage_begin(ZVX_T_ENCODER);
     c->tag = "encoder";
@@ -762,8 +794,17 @@ void run_encode(zvx_ctx* c, const int32_t* phoneme, const int32_t* puncts, const
     int* dur = (int*)(va_base + 5 * va_stride); int* cum = c->ibuf("va.cum", nid); int* ml = c->ibuf("va.mel_len", B);
     launch_durations(dur_in, logd, dur, cum, ml, B, Tmax, T_d, c->stream);
     c->mel_len_host.resize(B);
-    HIPCHK(hipMemcpyAsync(c->mel_len_host.data(), ml, B * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));            // the one data-dependent host sync (model.py:325)
+    if (duration) {
+        // forced durations: the mel lengths are their sums (same clamps as k_durations) -- nothing to wait for
+        for (int b = 0; b < B; b++) {
+            long long sum = 0;
+            for (int t = 0; t < T[b]; t++) sum += std::min(std::max(duration[(size_t)b * Tmax + t], 0), 65536);
+            c->mel_len_host[b] = (int)std::min(sum, 0x7fffffffLL);
+        }
+    } else {
+        HIPCHK(hipMemcpyAsync(c->mel_len_host.data(), ml, B * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));        // predicted durations: the one data-dependent host sync (model.py:325)
+    }
     if (mel_len_out) memcpy(mel_len_out, c->mel_len_host.data(), B * sizeof(int));
     int Lmax = 0; for (int b = 0; b < B; b++) Lmax = std::max(Lmax, c->mel_len_host[b]);
     // checked BEFORE anything is sized by it: a garbage log-duration must not drive an allocation
@@ -1426,6 +1467,8 @@ zvx_status guarded(zvx_ctx* ctx, F&& f) {
     if (!ctx) return ZVX_E_INVALID;
     try {
         HIPCHK(hipSetDevice(ctx->device));
+        ctx->arena_begin();
+        struct End { zvx_ctx* c; ~End() { try { c->arena_end(); } catch (...) {} } } end{ctx};
         f();
         return ZVX_OK;
     } catch (const ZvxError& e) {
@@ -1478,6 +1521,7 @@ void zvx_destroy(zvx_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     zvx_comm_destroy(c);
+    for (int i = 0; i < 2; i++) { if (c->arena[i].p) (void)hipHostFree(c->arena[i].p); if (c->arena[i].ev) (void)hipEventDestroy(c->arena[i].ev); }
     for (int i = 0; i < 2; i++) if (c->voc_aux[i]) { (void)hipStreamSynchronize(c->voc_aux[i]); (void)hipStreamDestroy(c->voc_aux[i]); }
     for (int i = 0; i < 3; i++) if (c->voc_ev[i]) (void)hipEventDestroy(c->voc_ev[i]);
     if (c->aux_stream) { (void)hipStreamSynchronize(c->aux_stream); (void)hipStreamDestroy(c->aux_stream); (void)hipEventDestroy(c->ev_aux[0]); (void)hipEventDestroy(c->ev_aux[1]); }
