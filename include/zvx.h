@@ -112,6 +112,10 @@ zvx_status zvx_vocode_mel(zvx_ctx* ctx, const float* mel, const int32_t* P, int 
 
 /* encode + decode + vocode.  mel_out / log_duration may be NULL.  With predicted durations the caller
  * sizes wav for Lmax_cap frames per utterance; ZVX_E_BUFFER if a prediction exceeds it.
+ * Queued calls: with forced durations, ZVX_DEVICE_OUT | ZVX_NO_SYNC and mel_out == log_duration == NULL the call only
+ * QUEUES work on the context's stream and returns (the host inputs are copied into pinned staging before it returns and may be
+ * reused at once; mel_len is filled from the durations): successive calls keep the GPU fed whatever the host thread's timing.
+ * With predicted durations the call waits once, for the predicted mel lengths.
  * Replaces ZeroVox.inference_ex (model.py:308-347) over B independent utterances. */
 zvx_status zvx_synthesize(zvx_ctx* ctx, const int32_t* phoneme, const int32_t* puncts, const int32_t* duration,
                           const int32_t* T, int B, int Tmax, const float* spk, const int32_t* pad_to,
