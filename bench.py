@@ -452,6 +452,9 @@ def main(argv=None, ctx_factory=default_ctx_factory):
                                "flops_per_launch": dom["flops"] / dom["launches"],
                                "alg_bytes_per_launch": dom["bytes"] / dom["launches"],
                                "alg_GBps": dom["bytes"] / (dom["ms"] * 1e-3) / 1e9}
+            if args.in_flight > 1:
+                res["roofline"]["note"] = ("launch durations measured while the other context's launches share the CUs (two vocoders side by side "
+                                           "stretch each launch): the kernel's own roofline is on the in_flight = 1 line")
             if traffic_note:
                 res["roofline"]["traffic_note"] = traffic_note
             if smi and smi.samples:

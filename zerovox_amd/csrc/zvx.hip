@@ -93,7 +93,7 @@ struct zvx_ctx {
     int rs_prof = 0;                       // zvx_set_int("rs_prof", 1): per-wave cycle counters of the streaming kernels (library built with -DRS_PROFILE)
     int enc_split = 0;                     // bf16 mode: the f32 GEMMs of the phoneme encoder / variance adaptor run as 3-plane bf16 GEMMs
     const void* fft_xs_ready = nullptr;     // fft.xs holds the split planes of this buffer (written by the previous FFT block's last LayerNorm)
-    int norm_fuse_maxb = 2;                // zvx_set_int("norm_fuse_maxb", n): batches of at most n utterances take the one-launch InstanceNorm of the StyleTTS decoder (0: never; A/B)
+    int norm_fuse_maxb = 1 << 20;          // zvx_set_int("norm_fuse_maxb", n): batches of at most n utterances may take the one-launch InstanceNorm of the StyleTTS decoder (0: never; A/B)
     int dec_f16 = 1;                       // zvx_set_int("dec_f16", 0): StyleTTS decoder activations / weights in bf16 instead of IEEE half (A/B)
     int use_attn_f32 = 1;                  // zvx_set_int("attn_f32", 0): the encoder's attention as V^T / score / P.V GEMMs + softmax (A/B)
     int use_flash = 1;                     // zvx_set_int("flash", 0): the decoder's attention as score GEMM + softmax + PV GEMM (A/B)
@@ -885,7 +885,11 @@ void sty_norm(const StyCtx& s, const void* x, int ldx, int C, void* y, int ldy, 
     const std::string keep = s.c->tag;
     s.c->tag = "decoder.norm";
     s.c->timed(0, (double)s.B * s.Lmax * C * s.c->es() * 3.0, [&] {          // statistics pass (read) + normalise pass (read + write)
-        if (s.dt != DT_F32 && s.B <= s.c->norm_fuse_maxb) {       // single requests: one launch (bit-identical)
+        // One launch (statistics, then the same workgroup walks its rows again: bit-identical) where it measures faster
+        // (tools/ab_norm_fuse.py): short utterances at any batch size, and any length once B x C / 64 workgroups fill a fair part
+        // of the chip.  A few workgroups walking many rows twice (B <= 4 at 896 frames) lose to the wide second launch.
+        const bool fuse_pays = s.Lmax <= 512 || (long)s.B * ((C + 63) / 64) >= 64;
+        if (s.dt != DT_F32 && s.B <= s.c->norm_fuse_maxb && fuse_pays) {
             launch_instnorm_fused(x, s.dt, ldx, y, s.dt, ldy, s.B, s.Lmax, s.L_d, C, 1e-5f, s.mean, s.rstd, gamma, beta, g_bs, one_plus, act, 0.2f, s.c->stream);
             return;
         }
