@@ -620,12 +620,15 @@ void launch_zero_tail_rows(float* x, int ldx, int B, int rows_max, const int* ro
 // is unchanged (tap-major, then channel groups), so results are bit-identical to the direct form.
 // Samples in [out_len*out_mul, Nmax) of every row are written as zeros, so the caller's row never depends on what an
 // earlier call left in a reused buffer.  pcm16: the row is int16 PCM, (short)trunc(tanh(.) * 32760) (demo.py:29-35).
-__global__ __launch_bounds__(256) void k_conv_post_tanh(const void* x, int xdt, int ldx, long x_bs, const float* w, float bias, int kt, int C,
+template <int KT, int CC>
+__global__ __launch_bounds__(256) void k_conv_post_tanh(const void* x, int xdt, int ldx, long x_bs, const float* __restrict__ w, float bias, int kt, int C,
                                  void* wav, long wav_bs, int Nmax, int pcm16, const int* in_len, int len_mul, const int* out_len, int out_mul) {
     extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
     const int es = xdt == DT_BF16 ? 2 : 4, rowb = C * es, pitch = rowb + 16, half = (kt - 1) / 2, nrows = 256 + kt - 1;
+    // KT, CC > 0 (HiFi-GAN: 7 taps x 32 channels, bf16): the tap / channel loops unroll and the weights are read with uniform
+    // addresses straight from `w` (scalar loads, SGPR operands) instead of 56 LDS reads per sample; otherwise staged in LDS
     float* wl = (float*)(sm + (size_t)nrows * pitch);
-    for (int i = threadIdx.x; i < kt * C; i += blockDim.x) wl[i] = w[i];
+    if (KT == 0) for (int i = threadIdx.x; i < kt * C; i += blockDim.x) wl[i] = w[i];
     const int b = blockIdx.y;
     const long n0 = (long)blockIdx.x * 256;
     const long nin = (long)in_len[b] * len_mul, nout = (long)out_len[b] * out_mul;
@@ -649,6 +652,25 @@ __global__ __launch_bounds__(256) void k_conv_post_tanh(const void* x, int xdt, 
     const long n = n0 + threadIdx.x;
     if (n >= nout) { if (n < Nmax) put(n, 0.f); return; }
     float acc = bias;
+    if (KT > 0) {
+#pragma unroll
+        for (int k = 0; k < KT; k++) {
+            const long m = n + k - half;
+            if (m < 0 || m >= nin) continue;
+            const unsigned char* row = sm + (threadIdx.x + k) * pitch;
+#pragma unroll
+            for (int c = 0; c < CC; c += 8) {
+                const uint4 t = *(const uint4*)(row + c * 2);
+                const float* ww = w + k * CC + c;
+                acc += __uint_as_float(t.x << 16) * ww[0] + __uint_as_float(t.x & 0xffff0000u) * ww[1]
+                     + __uint_as_float(t.y << 16) * ww[2] + __uint_as_float(t.y & 0xffff0000u) * ww[3]
+                     + __uint_as_float(t.z << 16) * ww[4] + __uint_as_float(t.z & 0xffff0000u) * ww[5]
+                     + __uint_as_float(t.w << 16) * ww[6] + __uint_as_float(t.w & 0xffff0000u) * ww[7];
+            }
+        }
+        put(n, tanhf(acc));
+        return;
+    }
     for (int k = 0; k < kt; k++) {
         const long m = n + k - half;
         if (m < 0 || m >= nin) continue;
@@ -678,8 +700,12 @@ void launch_conv_post_tanh(const void* x, int x_dt, int ldx, long x_bs, const fl
     if (Nmax <= 0) return;
     const size_t es = x_dt == DT_BF16 ? 2 : 4;
     const size_t lds = (size_t)(256 + ktaps - 1) * (C * es + 16) + (size_t)ktaps * C * sizeof(float);
-    hipLaunchKernelGGL(k_conv_post_tanh, dim3((Nmax + 255) / 256, B), dim3(256), lds, s, x, x_dt, ldx, x_bs, w,
-                       bias, ktaps, C, wav, wav_bs, Nmax, pcm16, in_len, len_mul, out_len, out_mul);
+    if (x_dt == DT_BF16 && ktaps == 7 && C == 32)
+        hipLaunchKernelGGL((k_conv_post_tanh<7, 32>), dim3((Nmax + 255) / 256, B), dim3(256), lds, s, x, x_dt, ldx, x_bs, w,
+                           bias, ktaps, C, wav, wav_bs, Nmax, pcm16, in_len, len_mul, out_len, out_mul);
+    else
+        hipLaunchKernelGGL((k_conv_post_tanh<0, 0>), dim3((Nmax + 255) / 256, B), dim3(256), lds, s, x, x_dt, ldx, x_bs, w,
+                           bias, ktaps, C, wav, wav_bs, Nmax, pcm16, in_len, len_mul, out_len, out_mul);
 }
 
 // ---------------------------------------------------------------- speaker encoder pieces
