@@ -820,6 +820,38 @@ def test_rccl_gather_path_on_a_one_rank_communicator():
         ctx.close()
 
 
+def test_queued_calls_own_their_inputs_and_keep_their_order():
+    """zvx_synthesize with forced durations, a device output and ZVX_NO_SYNC only queues work (include/zvx.h): the host inputs are
+    copied into the context's pinned staging before the call returns.  Eight calls with different inputs are queued back to back,
+    each call's host arrays are overwritten with garbage as soon as it returns, and only then is the stream drained: every
+    waveform equals the synchronous call's, and mel_len is filled on return."""
+    ctx = ctx_for("styletts", "v1", "bf16")
+    n, B, T = 8, 3, 24
+    cases, refs = [], []
+    for i in range(n):
+        ph, pu, Tl, spk, dur = synthetic.batch(B, T, 50 + 7 * i, "uniform")
+        Tl = np.array([T, 5 + i, 13], np.int32)
+        for b in range(B): ph[b, Tl[b]:] = 0; pu[b, Tl[b]:] = 0; dur[b, Tl[b]:] = 0
+        cases.append((ph, pu, Tl, spk, dur))
+        refs.append(ctx.synthesize(ph, pu, Tl, spk, dur, None, want_mel=False))
+    N = max(int(r["mel_len"].max()) for r in refs) * 256
+    bufs = [ctx.dev_alloc(B * N * 4) for _ in range(n)]
+    try:
+        for i, (ph, pu, Tl, spk, dur) in enumerate(cases):
+            a = [x.copy() for x in (ph, pu, Tl, spk, dur)]
+            r = ctx.synthesize(a[0], a[1], a[2], a[3], a[4], None, want_mel=False, wav_device_ptr=bufs[i], wav_stride=N, no_sync=True)
+            assert np.array_equal(r["mel_len"], refs[i]["mel_len"]) and r["log_duration"] is None
+            a[0][:] = 1; a[1][:] = 1; a[2][:] = 1; a[3][:] = 1e9; a[4][:] = 30            # the caller's arrays are free again
+        ctx.sync()
+        for i in range(n):
+            got = ctx.dev_to_host(bufs[i], (B, N), np.float32)
+            for b in range(B):
+                k = int(refs[i]["mel_len"][b]) * 256
+                assert np.array_equal(got[b, :k], refs[i]["wav"][b][:k]), (i, b)
+    finally:
+        for p in bufs: ctx.dev_free(p)
+
+
 # ------------------------------------------------------------------------------------------------
 # BASELINE.json configs at their full sizes
 # ------------------------------------------------------------------------------------------------
