@@ -182,7 +182,7 @@ def test_committed_bench_line_follows_the_contract():
     """The bench line committed under profiles/ (produced by `python bench.py` on the GPU box) carries every field the
     driver and the judge read."""
     import json
-    path = os.path.join(ROOT, "profiles", "r01_bench_n1.json")
+    path = os.path.join(ROOT, "profiles", "r03_bench_n1.json")
     if not os.path.exists(path):
         pytest.skip("no committed bench line")
     d = json.loads(open(path).read().strip().splitlines()[-1])

@@ -131,3 +131,15 @@ def test_manifest_hashes():
     for name, meta in man["fixtures"].items():
         data = open(os.path.join(GOLDEN, name + ".npz"), "rb").read()
         assert hashlib.sha256(data).hexdigest() == meta["sha256"], name
+
+
+def test_onednn_backed_oracle_is_the_same_function():
+    """bench.py's cpu_baseline times oracle/onednn_port.py (the oracle with its convolutions evaluated by torch / oneDNN) in a child
+    process: the child checks itself against the NumPy oracle before timing and reports the difference."""
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "oracle", "onednn_port.py"), "5", "styletts", "v1", "4", "1"],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-400:]
+    j = json.loads(out.stdout.strip().splitlines()[-1])
+    assert j["check_max_abs_diff"] < 1e-4 and j["value"] > 0
