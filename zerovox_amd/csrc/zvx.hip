@@ -60,7 +60,8 @@ struct zvx_ctx {
     hipStream_t comm_stream = nullptr;
     hipStream_t voc_aux[2] = {nullptr, nullptr};   // single requests: the non-final pairs of the 2nd / 3rd ResBlock of a vocoder stage run beside the 1st
     hipEvent_t voc_ev[3] = {nullptr, nullptr, nullptr};
-    int voc_overlap_maxb = 4;              // zvx_set_int("voc_overlap_maxb", n): batches of at most n utterances use them (0: never; A/B)
+    int voc_overlap_maxb = 1 << 20;        // zvx_set_int("voc_overlap_maxb", n): batches of at most n utterances use them (0: never; A/B)
+    long voc_overlap_frames = 28672;       // zvx_set_int("voc_overlap_frames", n): ... and only below n mel frames per call (B x Pmax)
     hipStream_t aux_stream = nullptr;      // second compute stream: the duration predictor of a small batch beside the pitch predictor
     hipEvent_t ev_aux[2] = {nullptr, nullptr};
     int va_overlap_maxb = 4;               // zvx_set_int("va_overlap_maxb", n): batches of at most n utterances overlap the two predictors (0: never; A/B)
@@ -1015,7 +1016,9 @@ void run_vocoder(zvx_ctx* c, const float* mel, int ldm, int Lmel_max, const int*
     void* XS = c->buf("voc.XS", maxel * es);     // running sum over the resblocks of a stage, in the activation dtype
     // temporaries of the ResBlocks that run beside the first one (single requests, below).  Taken HERE: a new buffer is zero-filled
     // on the main stream, which the side streams only follow from the stage-input event on
-    const bool side_ok = nk >= 2 && nk <= 3 && B <= c->voc_overlap_maxb && !(c->voc_chunk > 0 && c->voc_chunk < B);
+    // tools/ab_voc_overlap.py: -5 ... -24 % for every batch below the headline's size (most where B leaves a ragged last round of
+    // workgroups: B = 6 / 12), +-1 % at 32 x 896 frames, which therefore keeps the serial schedule
+    const bool side_ok = nk >= 2 && nk <= 3 && B <= c->voc_overlap_maxb && (long)B * Pmax < c->voc_overlap_frames && !(c->voc_chunk > 0 && c->voc_chunk < B);
     void* sideT1[2] = {nullptr, nullptr}; void* sidePP[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
     if (side_ok)
         for (int j = 1; j < nk; j++) {
@@ -1573,6 +1576,7 @@ zvx_status zvx_set_int(zvx_ctx* c, const char* key, int64_t value) {
         else if (std::string(key) == "norm_fuse_maxb") c->norm_fuse_maxb = (int)value;
         else if (std::string(key) == "va_overlap_maxb") c->va_overlap_maxb = (int)value;
         else if (std::string(key) == "voc_overlap_maxb") c->voc_overlap_maxb = (int)value;
+        else if (std::string(key) == "voc_overlap_frames") c->voc_overlap_frames = (long)value;
         else if (std::string(key) == "enc_split") c->enc_split = (c->dt == DT_BF16 && value && c->has("enc.0.wqk.s3")) ? 1 : 0;
         else if (std::string(key) == "rs_prof") c->rs_prof = (int)value;
         else if (std::string(key) == "rs_opt") c->rs_opt = (int)value;
