@@ -13,10 +13,10 @@ rng = np.random.default_rng(2)
 variants = (("round-2 sizing", {"rs_seg_min": -1, "pairstream": 1, "slab_small": 0, "norm_fuse_maxb": 0, "va_overlap_maxb": 0, "voc_overlap_maxb": 0}), ("short resstream segments", {"rs_seg_min": 0, "pairstream": 1, "slab_small": 0}),
             ("+ small conv-slab tiles", {"rs_seg_min": 0, "pairstream": 1, "slab_small": 1}), ("+ 32-channel tiles for one-row-tile launches", {"rs_seg_min": 0, "pairstream": 1, "slab_small": 2}),
             ("+ one-launch InstanceNorm", {"rs_seg_min": 0, "pairstream": 1, "slab_small": 2, "norm_fuse_maxb": 1 << 20}),
-            ("+ duration beside pitch predictor", {"rs_seg_min": 0, "pairstream": 1, "slab_small": 2, "norm_fuse_maxb": 1 << 20, "va_overlap_maxb": 4}),
-            ("+ ResBlocks side by side, B <= 2", {"rs_seg_min": 0, "pairstream": 1, "slab_small": 2, "norm_fuse_maxb": 1 << 20, "va_overlap_maxb": 4, "voc_overlap_maxb": 2}),
-            ("+ ResBlocks side by side (default)", {"rs_seg_min": 0, "pairstream": 1, "slab_small": 2, "norm_fuse_maxb": 1 << 20, "va_overlap_maxb": 4, "voc_overlap_maxb": 1 << 20}),
-            ("+ pair kernel, 256-row segments", {"rs_seg_min": 0, "pairstream": 4, "slab_small": 2, "norm_fuse_maxb": 1 << 20, "va_overlap_maxb": 4, "voc_overlap_maxb": 1 << 20}))
+            ("+ duration beside pitch predictor", {"rs_seg_min": 0, "pairstream": 1, "slab_small": 2, "norm_fuse_maxb": 1 << 20, "va_overlap_maxb": 1 << 20}),
+            ("+ ResBlocks side by side, B <= 2", {"rs_seg_min": 0, "pairstream": 1, "slab_small": 2, "norm_fuse_maxb": 1 << 20, "va_overlap_maxb": 1 << 20, "voc_overlap_maxb": 2}),
+            ("+ ResBlocks side by side (default)", {"rs_seg_min": 0, "pairstream": 1, "slab_small": 2, "norm_fuse_maxb": 1 << 20, "va_overlap_maxb": 1 << 20, "voc_overlap_maxb": 1 << 20}),
+            ("+ pair kernel, 256-row segments", {"rs_seg_min": 0, "pairstream": 4, "slab_small": 2, "norm_fuse_maxb": 1 << 20, "va_overlap_maxb": 1 << 20, "voc_overlap_maxb": 1 << 20}))
 for (B, P) in ((1, 448), (1, 1024), (2, 448), (4, 448)):
     mel = rng.standard_normal((B, P, 80)).astype(np.float32); L = np.full(B, P, np.int32)
     ref = None

@@ -64,7 +64,7 @@ struct zvx_ctx {
     long voc_overlap_frames = 28672;       // zvx_set_int("voc_overlap_frames", n): ... and only below n mel frames per call (B x Pmax)
     hipStream_t aux_stream = nullptr;      // second compute stream: the duration predictor of a small batch beside the pitch predictor
     hipEvent_t ev_aux[2] = {nullptr, nullptr};
-    int va_overlap_maxb = 4;               // zvx_set_int("va_overlap_maxb", n): batches of at most n utterances overlap the two predictors (0: never; A/B)
+    int va_overlap_maxb = 1 << 20;             // zvx_set_int("va_overlap_maxb", n): batches of at most n utterances overlap the two predictors (0: never; A/B)
     ncclComm_t comm = nullptr;
     int rank = 0, world = 1;
     hipEvent_t ev_compute = nullptr;
@@ -763,9 +763,11 @@ void run_encode(zvx_ctx* c, const int32_t* phoneme, const int32_t* puncts, const
     HIPCHK(hipMemsetAsync(va_base, 0, va_stride * 6, c->stream));
     float* logd = (float*)va_base; float* pitch = (float*)(va_base + va_stride); float* energy = (float*)(va_base + 2 * va_stride);
     int* pidx = (int*)(va_base + 3 * va_stride); int* eidx = (int*)(va_base + 4 * va_stride);
-    // The duration and the pitch predictor read the same x and are independent (fs2.py:663-668): for small batches -- launches that
-    // leave most of the chip idle -- the duration predictor runs on a second stream beside the pitch predictor.  Same kernels, same
-    // arithmetic; x is only modified (pitch embedding) after both have read it.
+    // The duration and the pitch predictor read the same x and are independent (fs2.py:663-668): the duration predictor runs on a
+    // second stream beside the pitch predictor.  Their exact-f32 convolutions are chains of dependent matrix instructions on a
+    // fraction of the CUs at any batch size (64 workgroups at B = 32 x 128), so this pays everywhere: the stage 0.43 -> 0.32-0.36 ms
+    // for B = 1 ... 32 (tools/ab_va_overlap.py).  Same kernels, same arithmetic; x is only modified (pitch embedding) after both
+    // have read it.
     if (B <= c->va_overlap_maxb) {
         if (!c->aux_stream) {
             HIPCHK(hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking));
