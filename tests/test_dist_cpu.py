@@ -209,6 +209,35 @@ def test_bench_in_flight_two_contexts_round_robin(capsys):
     assert abs(r["value"] * r["ms_per_step"] * 1e-3 * 4 - total) < 1e-6 * total
 
 
+def test_bench_set_overrides_reach_every_context_and_the_line(capsys):
+    """bench.py --set KEY=INT (repeatable): zvx_set_int on every context before the first step, echoed in config.overrides."""
+    import bench
+    from zerovox_amd import config as zcfg
+    made = []
+
+    class Rec(StubContext):
+        def __init__(self):
+            super().__init__(); self.sets = []
+        def set_int(self, k, v): self.sets.append((k, v))
+
+    def factory(args, local_rank):
+        c = Rec(); c._first = 0
+        made.append(c)
+        return c, (zcfg.medium_modelcfg("styletts"), None, None, None)
+
+    old = {k: os.environ.pop(k, None) for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    try:
+        rc = bench.main(["--in-flight", "2", "--steps", "2", "--warmup", "1", "--batch", "2", "--phonemes", "8", "--profile", "0", "--no-cpu-baseline",
+                         "--set", "voc_overlap_maxb=0", "--set", "norm_fuse_maxb=7"], ctx_factory=factory)
+    finally:
+        os.environ.update({k: v for k, v in old.items() if v is not None})
+    assert rc == 0 and len(made) == 2
+    for c in made:
+        assert ("voc_overlap_maxb", 0) in c.sets and ("norm_fuse_maxb", 7) in c.sets
+    r = json.loads([l for l in capsys.readouterr().out.splitlines() if l.strip()][-1])
+    assert r["config"]["overrides"] == {"voc_overlap_maxb": 0, "norm_fuse_maxb": 7}
+
+
 def test_bench_under_torchrun_with_stub_context():
     """The driver's own launch line (python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
     --master-port P bench.py --gpus N ...): env parsing, the TCPStore rendezvous against the elastic agent's store, one JSON line."""
