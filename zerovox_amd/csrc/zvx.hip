@@ -170,19 +170,20 @@ struct zvx_ctx {
     struct Arena { char* p = nullptr; size_t cap = 0, cur = 0; hipEvent_t ev = nullptr; bool pending = false; };
     Arena arena[2];
     int arena_i = 0;
+    int api_depth = 0;
     static constexpr size_t ARENA_BYTES = 2u << 20;
     void arena_begin() {
-        arena_i ^= 1;
         Arena& a = arena[arena_i];
         if (a.pending) { HIPCHK(hipEventSynchronize(a.ev)); a.pending = false; }
         a.cur = 0;
     }
-    void arena_end() {
-        Arena& a = arena[arena_i];
+    void arena_end() {                      // only a call that uploaded something rotates the arenas: a gather or a query between two
+        Arena& a = arena[arena_i];          // synthesis calls must not send them both to the same arena (the second would wait for the first)
         if (!a.cur || !stream) return;
         if (!a.ev) HIPCHK(hipEventCreateWithFlags(&a.ev, hipEventDisableTiming));
         HIPCHK(hipEventRecord(a.ev, stream));
         a.pending = true;
+        arena_i ^= 1;
     }
     void upload(void* dst, const void* src, size_t bytes) {
         Arena& a = arena[arena_i];
@@ -1476,8 +1477,9 @@ zvx_status guarded(zvx_ctx* ctx, F&& f) {
     if (!ctx) return ZVX_E_INVALID;
     try {
         HIPCHK(hipSetDevice(ctx->device));
-        ctx->arena_begin();
-        struct End { zvx_ctx* c; ~End() { try { c->arena_end(); } catch (...) {} } } end{ctx};
+        const bool outer = ctx->api_depth++ == 0;               // (an entry point that calls another one keeps the outer call's arena)
+        struct End { zvx_ctx* c; ~End() { try { if (--c->api_depth == 0) c->arena_end(); } catch (...) {} } } end{ctx};
+        if (outer) ctx->arena_begin();
         f();
         return ZVX_OK;
     } catch (const ZvxError& e) {
