@@ -1,7 +1,7 @@
 #!/bin/bash
 # Runs on the GPU box (via gpurun): bench lines + rocprofv3 kernel trace + PMC passes of the SAME command at the SAME sources.
 # Results land in gpurun_out/prof_<tag>/ ; copy them into profiles/ (tools/install_profiles.sh <tag>) and commit.
-#   usage: tools/refresh_profiles.sh <tag> [quick]
+#   usage: tools/refresh_profiles.sh <tag> [quick|extra]     (extra = PMC passes for the secondary workloads only: other decoder / vocoders, single requests)
 set -u
 TAG=${1:-r03}
 QUICK=${2:-}
@@ -30,6 +30,20 @@ profile_workload() {   # <name> <bench options...>
   cp $OUT/$TJ $ROOT/profiles/$TJ          # the bench line below quotes it (same sources, same workload)
 }
 
+if [ "$QUICK" = "extra" ]; then
+  profile_workload fs2dec --decoder fastspeech2
+  python $ROOT/bench.py --decoder fastspeech2 --no-cpu-baseline > $OUT/bench_fs2dec.json 2> $OUT/bench_fs2dec.err
+  profile_workload v2 --vocoder v2
+  python $ROOT/bench.py --vocoder v2 --no-cpu-baseline > $OUT/bench_v2.json 2> $OUT/bench_v2.err
+  profile_workload v3 --vocoder v3
+  python $ROOT/bench.py --vocoder v3 --no-cpu-baseline > $OUT/bench_v3.json 2> $OUT/bench_v3.err
+  profile_workload b1_t64 --batch 1 --phonemes 64
+  python $ROOT/bench.py --batch 1 --phonemes 64 --no-cpu-baseline > $OUT/bench_b1_t64.json 2> $OUT/bench_b1_t64.err
+  profile_workload cfg4_b1 --config 4 --batch 1
+  python $ROOT/bench.py --config 4 --batch 1 --no-cpu-baseline > $OUT/bench_cfg4_b1.json 2> $OUT/bench_cfg4_b1.err
+  ls -la $OUT
+  exit 0
+fi
 profile_workload bench_n1
 python $ROOT/bench.py > $OUT/bench_n1.json 2> $OUT/bench_n1.err
 python $ROOT/bench.py --exact-encoder --no-cpu-baseline > $OUT/bench_n1_exact_encoder.json 2> $OUT/bench_n1_exact_encoder.err
