@@ -609,14 +609,20 @@ __global__ __launch_bounds__(256, MINW) void convslab_kernel(const GemmArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: SGPR arithmetic, scalar branches
     const int wr = wave % WM, wc = wave / WM;
     const int ntn = (a.N + BN - 1) / BN;
-    int wg;
-    {
+    int wg, b;
+    if (a.xcd_flat) {
+        // workgroups reach the XCDs round-robin in LINEAR order (x fastest, then y): remap over the whole grid, so that each XCD walks a
+        // contiguous range of (utterance, time tile, channel tile) whatever gridDim.x is modulo 8
+        const int nx = gridDim.x, nwg = nx * gridDim.y, id = blockIdx.y * nx + blockIdx.x, q = nwg >> 3, r = nwg & 7, xcd = id & 7;
+        const int w = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
+        b = w / nx; wg = w - b * nx;
+    } else {
         const int nwg = gridDim.x, id = blockIdx.x, q = nwg >> 3, r = nwg & 7, xcd = id & 7;
         wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
+        b = blockIdx.y;
     }
     const int nt = wg % ntn, mt = wg / ntn;
     const int m0 = mt * BM, n0 = nt * BN;
-    const int b = blockIdx.y;
     const int out_len = a.out_len ? a.out_len[b] : a.M;
     const int in_len = a.in_len ? a.in_len[b] : a.in_len_static;
     if (m0 >= out_len || m0 >= a.M) return;
@@ -1514,7 +1520,11 @@ static int epi_mode_of(const GemmArgs& a) {
     return -1;
 }
 
+static int g_slab_flat = 1;                                       // zvx_set_int("slab_flat", v): 1 = tile -> XCD remap over batch x tiles (decoder convs -2 %, bit-identical; tools/ab_slab_flat.sh)
+void gemm_set_slab_flat(int v) { g_slab_flat = v; }
+
 static int launch_convslab(GemmArgs a, hipStream_t stream) {
+    a.xcd_flat = g_slab_flat;
     int hl = 0, hr = 0;
     for (int i = 0; i < a.ntaps; i++) { hl = a.dv[i] < -hl ? -a.dv[i] : hl; hr = a.dv[i] > hr ? a.dv[i] : hr; }
     a.halo_l = hl; a.halo_r = hr;

@@ -1586,6 +1586,7 @@ zvx_status zvx_set_int(zvx_ctx* c, const char* key, int64_t value) {
         else if (std::string(key) == "rs_opt") c->rs_opt = (int)value;
         else if (std::string(key) == "rs_seg_min") c->rs_seg_min = (int)value;
         else if (std::string(key) == "slab_small") gemm_set_slab_small((int)value);
+        else if (std::string(key) == "slab_flat") gemm_set_slab_flat((int)value);
         else if (std::string(key) == "max_frames") { if (value < 1 || value > (1 << 24)) fail(ZVX_E_INVALID, "max_frames out of range"); c->max_frames = (int)value; }
         else fail(ZVX_E_INVALID, "unknown option '%s'", key);
     });

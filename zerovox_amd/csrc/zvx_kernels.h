@@ -52,6 +52,7 @@ struct GemmArgs {
     // convolution over the FLATTENED map (tap offset du * win + dv): input row g is valid iff 0 <= g < flat_rows and
     // (g % flat_win) < in_len[z] (the columns of an utterance's true width); every output row of the map is written
     int flat_win, flat_rows;
+    int xcd_flat;                                                  // conv-slab: remap over the WHOLE grid (batch x tiles), not per utterance (zvx_set_int "slab_flat")
     int out_split3;            // f32 result written as bf16 split planes [hi | hi | lo] (row = 3 N, ldo elements apart): the input of the next 3-plane GEMM
     // epilogue: v = alpha*acc + bias; v += res; v += accum; [accum = v]; v *= out_scale; v = act(v);
     //           v = v*post_scale[n] + post_shift[n]; out = (T)v
@@ -73,6 +74,7 @@ struct GemmArgs {
 int launch_gemm(const GemmArgs& a, hipStream_t stream);
 // arm (or disarm with nullptrs) a pair of events that the NEXT launch_gemm / launch_resfuse dispatch carries as its own
 // start / stop timestamps (no marker packets on the stream)
+void gemm_set_slab_flat(int v);                                   // 1: conv-slab tile -> XCD remap over batch x tiles (every channel tile of a time tile on one XCD for any tile count)
 void gemm_set_slab_small(int v);                                  // 0: conv-slab launches keep 256-row tiles for single requests (A/B)
 void gemm_profile_events(hipEvent_t start, hipEvent_t stop);
 // the kernel variant launch_gemm / launch_resfuse would pick for these arguments (nothing is dispatched)
