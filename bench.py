@@ -32,7 +32,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s
 MFMA_PEAK = {"bf16": 2500.0, "f32": 157.3}   # dense TFLOP/s (MI355X_MICROARCH.md)
 F32_STAGES = ("variance",)                    # exact-f32 MFMA in both precision modes (its outputs are the discrete decisions)
-SPLIT_STAGES = ("encoder",)                   # bf16 mode: f32-class results from 3 bf16 products per multiply
+SPLIT_STAGES = ("encoder",)                   # 16-bit mode: f32-class results from 3 half-precision products per multiply
 
 
 def src_sha16():
@@ -188,14 +188,22 @@ def default_ctx_factory(args, local_rank):
     return _lib.Context(manifest, blob, local_rank), (cfg, sd, hcfg, hsd)
 
 
-def cpu_baseline(config, model, T, pad_to, decoder="styletts", vocoder="v1"):
-    """The NumPy oracle (a port of the reference's PyTorch CPU path) on a BOUNDED sample of the workload, timed on this box's
-    host cores (about 10-30 s).  Checker / baseline only -- never on the product path."""
+def cpu_baseline(config, model, T, pad_to, decoder="styletts", vocoder="v1", numpy_leg=False):
+    """The oracle (a port of the reference's PyTorch CPU path) on a BOUNDED sample of the workload, timed on this box's host cores.
+    Default: the oracle with its convolution primitives evaluated by torch / oneDNN in a child process (~10 s; the library the
+    reference itself runs on a CPU).  numpy_leg (--cpu-numpy): also the plain NumPy / BLAS oracle (~30 s more), which is what
+    stands alone when torch is missing on the box.  Checker / baseline only -- never on the product path."""
+    cores = min(16, os.cpu_count() or 1)            # OpenBLAS / oneDNN stop scaling on these skinny conv GEMMs beyond ~16 threads
+    unit = "clips/s" if config == 5 else "samples/s"
+    res = _cpu_baseline_onednn(config, T, decoder, vocoder, cores, unit)
+    if "value" in res and not numpy_leg:
+        if config == 2:
+            res.update(_reference_context())
+        return res
     from oracle import zvx_oracle as O
     from zerovox_amd import synthetic
     from threadpoolctl import threadpool_limits
     cfg, sd, hcfg, hsd = model
-    cores = min(16, os.cpu_count() or 1)            # OpenBLAS stops scaling on these skinny conv GEMMs beyond ~16 threads
     with threadpool_limits(limits=cores):
         O.hifigan_generator(np.zeros((80, 8), np.float32), hsd, hcfg)      # BLAS thread-pool warm-up
         t0 = time.time()
@@ -212,11 +220,26 @@ def cpu_baseline(config, model, T, pad_to, decoder="styletts", vocoder="v1"):
                 O.resnet_se34v2(m, sd, cfg)
             n, unit, what = 4, "clips/s", "4 clips of the workload (258-frame mels)"
         dt = time.time() - t0
-    res = {"value": n / dt, "unit": unit, "cores": int(cores), "kind": "port",
-           "sample": f"{what} through oracle/zvx_oracle.py (NumPy/BLAS fp32) in {dt:.1f} s"}
-    # The same oracle with its three convolution primitives evaluated by torch / oneDNN -- the library the reference itself runs on a
-    # CPU -- in a child process (this process holds the HIP runtime of libzvx; torch brings its own).  That is the figure comparable
-    # to the reference's CPU path, so it is the headline `value`; the plain NumPy timing stays beside it.
+    npres = {"value": n / dt, "sample": f"{what} through oracle/zvx_oracle.py (NumPy/BLAS fp32) in {dt:.1f} s"}
+    if "value" in res:
+        res["numpy_oracle"] = npres
+    else:                                               # no torch on the box, or the child failed: the NumPy timing stands
+        res = {"value": npres["value"], "unit": unit, "cores": int(cores), "kind": "port", "sample": npres["sample"], **res}
+    if config == 2:
+        res.update(_reference_context())
+    return res
+
+
+def _reference_context():
+    # context, not measured here: the reference's own PyTorch / oneDNN CPU path in the survey container
+    return {"reference_torch_cpu_samples_per_s": 189000,
+            "reference_torch_cpu_note": "gooofy/zerovox inference_ex on 8 cores of the survey container (BASELINE.md section 3); the oneDNN-backed port is the comparable figure, the plain NumPy oracle (--cpu-numpy) is ~12x slower than that path"}
+
+
+def _cpu_baseline_onednn(config, T, decoder, vocoder, cores, unit):
+    """The oracle with its three convolution primitives evaluated by torch / oneDNN -- the library the reference itself runs on a CPU --
+    in a child process (this process holds the HIP runtime of libzvx; torch brings its own).  The child first checks the port against
+    the plain NumPy oracle on a small case."""
     import subprocess
     units = {2: 3, 4: 3, 5: 40}[config]
     try:
@@ -224,18 +247,12 @@ def cpu_baseline(config, model, T, pad_to, decoder="styletts", vocoder="v1"):
                               decoder, vocoder, str(cores), str(units), str(T)],
                              capture_output=True, text=True, timeout=600, env={**os.environ, "HIP_VISIBLE_DEVICES": "", "CUDA_VISIBLE_DEVICES": ""})
         j = json.loads(out.stdout.strip().splitlines()[-1])
-        res = {"value": j["value"], "unit": unit, "cores": int(cores), "kind": "port",
-               "sample": (f"{j['what']} through oracle/zvx_oracle.py with conv1d / conv_transpose1d / conv2d evaluated by torch {j['torch']} "
-                          f"(oneDNN, {j['threads']} threads; checked against the NumPy oracle first: max |diff| {j['check_max_abs_diff']:.1e}) "
-                          f"in {j['seconds']:.1f} s"),
-               "numpy_oracle": {"value": n / dt, "sample": res["sample"]}}
-    except Exception as e:                              # no torch on the box, or the child failed: the NumPy timing stands
-        res["onednn_port_error"] = f"{type(e).__name__}: {e}"[:300]
-    if config == 2:
-        # context, not measured here: the reference's own PyTorch / oneDNN CPU path in the survey container
-        res["reference_torch_cpu_samples_per_s"] = 189000
-        res["reference_torch_cpu_note"] = "gooofy/zerovox inference_ex on 8 cores of the survey container (BASELINE.md section 3); the oneDNN-backed port above is the comparable figure, the plain NumPy oracle is ~25x slower than that path"
-    return res
+        return {"value": j["value"], "unit": unit, "cores": int(cores), "kind": "port",
+                "sample": (f"{j['what']} through oracle/zvx_oracle.py with conv1d / conv_transpose1d / conv2d evaluated by torch {j['torch']} "
+                           f"(oneDNN, {j['threads']} threads; checked against the NumPy oracle first: max |diff| {j['check_max_abs_diff']:.1e}) "
+                           f"in {j['seconds']:.1f} s")}
+    except Exception as e:
+        return {"onednn_port_error": f"{type(e).__name__}: {e}"[:300]}
 
 
 def main(argv=None, ctx_factory=default_ctx_factory):
@@ -251,9 +268,10 @@ def main(argv=None, ctx_factory=default_ctx_factory):
     ap.add_argument("--precision", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--pcm16", action="store_true", help="int16 PCM waveform rows (halves the gather payload)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--exact-encoder", action="store_true", help="bf16 mode: phoneme encoder on the exact-f32 MFMA instead of 3-plane bf16 split products (bucket ids / durations bit-equal to the f32 path)")
+    ap.add_argument("--cpu-numpy", action="store_true", help="cpu_baseline: also time the plain NumPy / BLAS oracle (~30 s more; it always runs when the oneDNN-backed port cannot)")
+    ap.add_argument("--exact-encoder", action="store_true", help="bf16 mode: phoneme encoder on the exact-f32 MFMA instead of 3-plane split products on IEEE-half planes (A/B: both are f32-class)")
     ap.add_argument("--host-out", action="store_true", help="config 2: deliver every step's waveform to host memory (D2H copy inside the timed region), as the reference's tts_ex does")
-    ap.add_argument("--in-flight", type=int, default=1, help="config 2, one GPU: steps alternate over this many contexts (each its own stream): batch i+1's latency-paced encoder / decoder run under batch i's vocoder")
+    ap.add_argument("--in-flight", type=int, default=1, help="config 2, one GPU: steps alternate over this many contexts (A/B of round 3; since round 4 ONE context overlaps batch i+1's front end with batch i's vocoder by itself: zvx_set_int front_overlap)")
     ap.add_argument("--set", action="append", default=[], metavar="KEY=INT", help="zvx_set_int(KEY, INT) on every context before the first step (A/B of a runtime switch; echoed in config.overrides)")
     ap.add_argument("--profile", type=int, default=2, help="0 none, 1 stage events, 2 + per-launch events on the dominant kernel")
     args = ap.parse_args(argv)
@@ -285,6 +303,12 @@ def main(argv=None, ctx_factory=default_ctx_factory):
     else:
         ctx.comm_init(None, 0, 1)
 
+    rccl_info = None
+    if world > 1 and hasattr(ctx, "comm_info"):
+        try:
+            rccl_info = ctx.comm_info()              # collective: every rank calls it
+        except Exception as e:
+            rccl_info = {"error": f"{type(e).__name__}: {e}"[:200]}
     T = args.phonemes
     more_ctx = []                                    # --in-flight: (context, [wav buffers]) beyond the first
     ss = 2 if args.pcm16 else 4
@@ -330,9 +354,12 @@ def main(argv=None, ctx_factory=default_ctx_factory):
                     + (f", RCCL waveform gather ({'int16' if args.pcm16 else 'f32'}) to rank 0 each step" if world > 1 else ""))
         cfg_extra = {"global_batch": B * world, "phonemes": T, "frames": L, "samples_per_utt": N, "decoder": args.decoder,
                      "vocoder": args.vocoder, "pad_to": int(pad_to[0]), "wav_dtype": "int16" if args.pcm16 else "f32",
-                     "encoder_arithmetic": ("exact f32 MFMA" if (args.exact_encoder or args.precision == "f32") else
-                                            "3-plane bf16 split products (f32-class: 5e-5 on the encoder output; --exact-encoder for bit-equal discrete decisions)"),
+                     "encoder_arithmetic": ("exact f32 MFMA" if (args.exact_encoder or args.precision == "f32" or overrides.get("enc_split") == 0) else
+                                            ("3-plane split products on bf16 planes (rounds 2-3 A/B: 5e-5 on the encoder output)" if overrides.get("enc_split") == 1 else
+                                             "3-plane split products on IEEE-half planes (hi.wh + hi.wl + lo.wh, every operand carried to 2^-24: f32-class, discrete decisions held to the f32 mode's 1e-3 margin)")),
                      "in_flight": max(1, args.in_flight),
+                     "front_overlap": ("off" if overrides.get("front_overlap") == 0 else
+                                       "one context, two streams: the encoder / variance adaptor / mel decoder of step i+1 are queued on the context's front stream and run under the vocoder of step i (every step is a whole batch, all complete at the closing fence; bit-identical to the serial schedule)"),
                      "decoder_arithmetic": ("f32" if args.precision == "f32" else
                                             "IEEE half weights + activations on the f16 MFMA (log-mel within 2e-2 of the f32 reference); vocoder: bf16"),
                      "wav_delivery": "host (synchronous D2H copy of every step's waveform inside the timed region)" if args.host_out else
@@ -433,6 +460,8 @@ def main(argv=None, ctx_factory=default_ctx_factory):
             "config": {"workload": workload, **cfg_extra, **({"overrides": overrides} if overrides else {})},
             "stage_ms_last_step": stage_ms, "output_ok": ok, "src_sha16": src_sha16(),
         }
+        if rccl_info is not None:
+            res["rccl"] = rccl_info                   # ranks the communicator itself counts, RCCL version, every rank's device
         if unit == "samples/s":
             audio_s = total / sr
             res["rtf_ref_audio_s_per_s"] = audio_s / elapsed
@@ -469,6 +498,13 @@ def main(argv=None, ctx_factory=default_ctx_factory):
                                "flops_per_launch": dom["flops"] / dom["launches"],
                                "alg_bytes_per_launch": dom["bytes"] / dom["launches"],
                                "alg_GBps": dom["bytes"] / (dom["ms"] * 1e-3) / 1e9}
+            ser = next((k for k in kstats_all if k["name"] == dom["name"] and k["launches"]), None)
+            if ser:
+                # the same kernel in the ONE untimed, fully instrumented step that ran alone on the chip (nothing of another step beside it)
+                ser_tf = ser["flops"] / (ser["ms"] * 1e-3) / 1e12
+                res["roofline"]["alone"] = {"achieved": ser_tf, "frac": ser_tf / peak, "launches": ser["launches"], "avg_launch_ms": ser["ms"] / ser["launches"],
+                                            "note": "per-launch events of the untimed instrumented step (serial: no other step's front end on the chip); "
+                                                    "`achieved` / `frac` above are the timed region's, where the next step's encoder / decoder share the CUs"}
             if args.in_flight > 1:
                 res["roofline"]["note"] = ("launch durations measured while the other context's launches share the CUs (two vocoders side by side "
                                            "stretch each launch): the kernel's own roofline is on the in_flight = 1 line")
@@ -495,11 +531,11 @@ def main(argv=None, ctx_factory=default_ctx_factory):
                 row = {"stage": t["name"], "launches": t["launches"], "ms": round(t["ms"], 4), "TFLOPs": round(tf, 2),
                        "alg_GBps": round(gb, 1), "frac_mfma": round(tf / pk, 4), "frac_hbm": round(gb / HBM_PEAK_GBS, 4), "mfma_peak": pk}
                 if args.precision == "bf16" and t["name"] in SPLIT_STAGES:
-                    row["note"] = "algorithmic (f32-equivalent) FLOPs; issued on the bf16 MFMA as ~3x that (hi.wh + hi.wl + lo.wh)"
+                    row["note"] = "algorithmic (f32-equivalent) FLOPs; issued on the f16 MFMA as ~3x that (hi.wh + hi.wl + lo.wh)"
                 per_stage.append(row)
             res["roofline_per_stage"] = per_stage
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(args.config, model, T, 896 if args.config == 2 else 0, args.decoder, args.vocoder)
+            res["cpu_baseline"] = cpu_baseline(args.config, model, T, 896 if args.config == 2 else 0, args.decoder, args.vocoder, numpy_leg=args.cpu_numpy)
         flush_c_stdio()
         print(json.dumps(res), flush=True)
     fence()

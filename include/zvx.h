@@ -8,7 +8,8 @@
  * Conventions
  *   - every function returns a zvx_status (0 = ok); zvx_last_error() returns the message of the last
  *     failure on that context (or of zvx_create when ctx is NULL);
- *   - one context per device, NOT thread-safe (like the reference object), no globals;
+ *   - one context per device, NOT thread-safe (like the reference object); no mutable process-wide state: every
+ *     switch of zvx_set_int lives in its context, several contexts may be driven from several threads;
  *   - buffers are caller-allocated.  Host pointers by default; outputs flagged ZVX_DEVICE_OUT are
  *     device pointers on the context's device (used for the RCCL waveform gather);
  *   - batches are padded row-major: [B][Tmax] ids, [B][Lmax][80] mels, wav rows of `wav_stride` floats;
@@ -146,6 +147,11 @@ zvx_status zvx_comm_gather(zvx_ctx* ctx, const void* local, size_t bytes, void* 
 zvx_status zvx_comm_barrier(zvx_ctx* ctx);
 /* *value = max over ranks (bench.py: MAX-over-ranks elapsed time) */
 zvx_status zvx_comm_max_f64(zvx_ctx* ctx, double* value);
+/* Collective (every rank calls it): who is in the job as the communicator itself reports it -- out[0] = world, out[1] =
+ * ncclCommCount, out[2] = ncclGetVersion code, out[3] = ranks that contributed to an all-reduce SUM of ones, out[4 + r] = PCI
+ * address ((domain << 16) | (bus << 8) | (device << 3) | function) of rank r's device.  n_out >= 4 + world.  bench.py puts it
+ * into the N > 1 JSON line ("rccl": {...}). */
+zvx_status zvx_comm_info(zvx_ctx* ctx, int64_t* out, int n_out);
 void       zvx_comm_destroy(zvx_ctx* ctx);
 
 /* Device buffers for ZVX_DEVICE_OUT outputs / zvx_comm_gather without any other GPU runtime in the process. */
@@ -154,7 +160,7 @@ zvx_status zvx_dev_free(zvx_ctx* ctx, void* p);
 zvx_status zvx_dev_from_host(zvx_ctx* ctx, void* dst_dev, const void* src_host, size_t bytes);
 zvx_status zvx_dev_to_host(zvx_ctx* ctx, void* dst_host, const void* src_dev, size_t bytes);
 
-/* drains the compute AND the communication stream */
+/* drains every stream of the context (compute, front end, communication) */
 zvx_status zvx_sync(zvx_ctx* ctx);
 zvx_status zvx_stage_times(zvx_ctx* ctx, float ms[ZVX_T_COUNT]);
 

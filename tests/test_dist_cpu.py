@@ -117,6 +117,15 @@ class StubContext:
         if self.world > 1:
             dist.barrier()
 
+    def comm_info(self):
+        # what zvx_comm_info reports, with gloo as the transport: a SUM of ones and a MAX over per-rank device slots
+        ones = torch.tensor([1.0], dtype=torch.float64); slots = torch.zeros(self.world, dtype=torch.float64)
+        slots[self.rank] = 0x0500 + self.rank + 1
+        if self.world > 1:
+            dist.all_reduce(ones, op=dist.ReduceOp.SUM); dist.all_reduce(slots, op=dist.ReduceOp.MAX)
+        return {"world": self.world, "comm_count": self.world, "version_code": 0, "version": "stub", "ranks_seen": int(ones.item()),
+                "device_pci": [f"stub:{int(v) - 1:04x}" for v in slots.tolist()]}
+
     def comm_max(self, v):
         if self.world == 1:
             return v
@@ -178,6 +187,8 @@ def test_bench_control_flow_world2_with_stub_context():
     total = 2 * 4 * r["config"]["samples_per_utt"] * 3
     assert abs(r["value"] * r["ms_per_step"] * 1e-3 * 3 - total) < 1e-6 * total
     assert r["higher_is_better"] is True and r["vs_baseline"] is None
+    # the N > 1 line says who the communicator saw (zvx_comm_info): both ranks, each with its own device
+    assert r["rccl"]["ranks_seen"] == 2 and r["rccl"]["comm_count"] == 2 and len(set(r["rccl"]["device_pci"])) == 2
 
 
 def test_bench_in_flight_two_contexts_round_robin(capsys):

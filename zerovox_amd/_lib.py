@@ -19,7 +19,7 @@ ZVX_T_COUNT = 8
 EXPORTS = ("zvx_create", "zvx_destroy", "zvx_last_error", "zvx_get_int", "zvx_set_int", "zvx_spkemb", "zvx_melspec", "zvx_encode",
            "zvx_decode", "zvx_decode_features", "zvx_vocode", "zvx_vocode_mel", "zvx_synthesize", "zvx_fetch",
            "zvx_sync", "zvx_stage_times", "zvx_kernel_stats", "zvx_tag_stats", "zvx_reset_stats",
-           "zvx_comm_unique_id", "zvx_comm_init", "zvx_comm_gather", "zvx_comm_barrier", "zvx_comm_max_f64", "zvx_comm_destroy",
+           "zvx_comm_unique_id", "zvx_comm_init", "zvx_comm_gather", "zvx_comm_barrier", "zvx_comm_max_f64", "zvx_comm_info", "zvx_comm_destroy",
            "zvx_dev_alloc", "zvx_dev_free", "zvx_dev_from_host", "zvx_dev_to_host", "zvx_spkemb_ex")
 ZVX_COMM_ID_BYTES = 128
 
@@ -76,6 +76,7 @@ def load():
     lib.zvx_comm_gather.argtypes = [vp, vp, C.c_size_t, vp, C.c_int, C.c_int]
     lib.zvx_comm_barrier.argtypes = [vp]
     lib.zvx_comm_max_f64.argtypes = [vp, C.POINTER(C.c_double)]
+    lib.zvx_comm_info.argtypes = [vp, C.POINTER(C.c_int64), C.c_int]
     lib.zvx_comm_destroy.argtypes = [vp]
     lib.zvx_comm_destroy.restype = None
     lib.zvx_dev_alloc.argtypes = [vp, C.c_size_t, C.POINTER(vp)]
@@ -217,8 +218,10 @@ class Context:
         return wav
 
     def synthesize(self, phoneme, puncts, T, spk, duration=None, pad_to=None, want_mel=True, Lmax_cap=0,
-                   wav_device_ptr=None, wav_stride=None, no_sync=False, pcm16=False):
-        """Batched phoneme -> waveform.  Returns dict(wav [B][N] (None if device output), mel_len, mel, log_duration)."""
+                   wav_device_ptr=None, wav_stride=None, no_sync=False, pcm16=False, mel_device_ptr=None):
+        """Batched phoneme -> waveform.  Returns dict(wav [B][N] (None if device output), mel_len, mel, log_duration).
+        With a device waveform (wav_device_ptr) the mel, if wanted, is a device buffer too (ZVX_DEVICE_OUT covers both outputs):
+        mel_device_ptr -> [B][Lmax][n_mels] f32 with Lmax = the longest utterance's forced-duration sum (or Lmax_cap)."""
         phoneme = _i32(phoneme)
         B, Tmax = phoneme.shape
         puncts = _i32(puncts, (B, Tmax))
@@ -235,17 +238,22 @@ class Context:
         mel_len = np.zeros(B, np.int32)
         # a queued call (device output, no_sync) must not ask for host outputs: a copy into pageable memory would wait for the stream
         logd = None if (wav_device_ptr is not None and no_sync) else np.zeros((B, Tmax), np.float32)
-        mel = np.zeros((B, max(Lmax, 1), self.n_mels), np.float32) if want_mel else None
+        mel = np.zeros((B, max(Lmax, 1), self.n_mels), np.float32) if (want_mel and wav_device_ptr is None) else None
+        mptr = _ptr(mel)
         flags = ZVX_PCM16 if pcm16 else 0
         if wav_device_ptr is not None:
             wav, wptr, stride = None, C.c_void_p(int(wav_device_ptr)), int(wav_stride)
             flags |= ZVX_DEVICE_OUT | (ZVX_NO_SYNC if no_sync else 0)
+            if want_mel:
+                if mel_device_ptr is None:
+                    raise ZvxError(ZVX_E_INVALID, "a device waveform output takes a device mel output (mel_device_ptr) or want_mel=False")
+                mptr = C.c_void_p(int(mel_device_ptr))
         else:
             stride = max(Lmax * self.hop, 1)
             wav = np.zeros((B, stride), np.int16 if pcm16 else np.float32)
             wptr = _ptr(wav)
         self._chk(self._lib.zvx_synthesize(self._h, _ptr(phoneme), _ptr(puncts), _ptr(dur), _ptr(T), B, Tmax, _ptr(spk),
-                                           _ptr(pt), Lmax, wptr, stride, _ptr(mel_len), _ptr(mel), max(Lmax, 1),
+                                           _ptr(pt), Lmax, wptr, stride, _ptr(mel_len), mptr, max(Lmax, 1),
                                            _ptr(logd), flags))
         return dict(wav=wav, mel_len=mel_len, mel=mel, log_duration=logd)
 
@@ -331,6 +339,18 @@ class Context:
 
     def comm_barrier(self):
         self._chk(self._lib.zvx_comm_barrier(self._h))
+
+    def comm_info(self) -> dict:
+        """Collective: what the communicator itself reports (ranks, RCCL version) and every rank's device PCI address."""
+        n = 4 + self.world
+        out = (C.c_int64 * n)()
+        self._chk(self._lib.zvx_comm_info(self._h, out, n))
+        ver = int(out[2])
+        pci = [int(out[4 + r]) for r in range(self.world)]
+        return {"world": int(out[0]), "comm_count": int(out[1]), "version_code": ver,
+                "version": (f"{ver // 10000}.{(ver // 100) % 100}.{ver % 100}" if ver > 0 else None),
+                "ranks_seen": int(out[3]),
+                "device_pci": [(f"{p >> 16:04x}:{(p >> 8) & 0xff:02x}:{(p >> 3) & 0x1f:02x}.{p & 7}" if p >= 0 else None) for p in pci]}
 
     def comm_max(self, value: float) -> float:
         v = C.c_double(float(value))

@@ -223,7 +223,7 @@ bool launch_flash_attention(const FlashArgs& a, hipStream_t stream, bool dry_run
     constexpr int D = 264, KS = (D + 15) / 16, DP = KS * 16, DO = (D + 31) / 32 * 32;
     const size_t lds = 2 * ((size_t)FA_BK * (DP * 2 + 16) + (size_t)DO * (FA_BK * 2 + 16));
     const dim3 grid((a.L + FA_BQ - 1) / FA_BQ, a.nbatch * a.nheads), block(256);
-    static bool attr_done = false;
+    static std::atomic<bool> attr_done{false};
     if (!attr_done) {
         (void)hipFuncSetAttribute((const void*)flash_attn_kernel<264, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         (void)hipFuncSetAttribute((const void*)flash_attn_kernel<264, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -428,9 +428,16 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(const AttnF32Args a) {
             if (q < a.L) {
                 const float val = q < len ? acc[e] * As[r] : 0.f;
                 op[(long)q * a.ldo + col] = val;
-                if (a.planes) {                                                     // [hi | hi | lo] bf16 planes for the output projection's split-product GEMM
-                    const unsigned short hi = __builtin_bit_cast(unsigned short, (__bf16)val);
-                    const unsigned short lo = __builtin_bit_cast(unsigned short, (__bf16)(val - __uint_as_float((unsigned)hi << 16)));
+                if (a.planes) {                                                     // [hi | hi | lo] 16-bit planes for the output projection's split-product GEMM
+                    unsigned short hi, lo;
+                    if (a.planes_f16) {                                             // IEEE-half planes: lo scaled by 2^11 (ops.hip: split2h)
+                        const _Float16 hh = (_Float16)__builtin_amdgcn_fmed3f(val, -65504.f, 65504.f);
+                        hi = __builtin_bit_cast(unsigned short, hh);
+                        lo = __builtin_bit_cast(unsigned short, (_Float16)__builtin_amdgcn_fmed3f((val - (float)hh) * 2048.f, -65504.f, 65504.f));
+                    } else {
+                        hi = __builtin_bit_cast(unsigned short, (__bf16)val);
+                        lo = __builtin_bit_cast(unsigned short, (__bf16)(val - __uint_as_float((unsigned)hi << 16)));
+                    }
                     unsigned short* const pp = a.planes + ((long)b * a.L + q) * 3 * a.planes_C + h * D + col;
                     pp[0] = hi; pp[a.planes_C] = hi; pp[2 * a.planes_C] = lo;
                 }
@@ -449,7 +456,7 @@ bool launch_attention_f32(const AttnF32Args& a, hipStream_t stream, bool dry_run
     constexpr int D = 264, KP = (D - 128) + 4;
     const size_t lds = sizeof(float) * ((size_t)AF_BQ * (D + 4) + (size_t)AF_BK * KP + (size_t)AF_BQ * (AF_BK + 4) + 32);
     auto kfn = attn_f32_kernel<264>;
-    static bool attr_done = false;
+    static std::atomic<bool> attr_done{false};
     if (!attr_done) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_done = true; }
     const dim3 grid((a.L + AF_BQ - 1) / AF_BQ, a.nbatch * a.nheads), block(256);
     if (g_fa_ev_start) hipExtLaunchKernelGGL(kfn, grid, block, lds, stream, g_fa_ev_start, g_fa_ev_stop, 0, a);

@@ -473,14 +473,20 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs& a, f32x16 (&acc)[T
                     else if (ok[p]) *(u32x4*)((unsigned short*)a.out + ooff + (long)r * a.ldo + n) = o;
                 } else if (ok[p]) {
                     if (!CT && a.out_split3) {
-                        // bf16 split planes [hi | hi | lo] of the f32 result (ops.hip: split2), the operand layout of the next 3-plane GEMM
+                        // 16-bit split planes [hi | hi | lo] of the f32 result (ops.hip: split2 / split2h), the operand layout of the next 3-plane GEMM
                         unsigned short* op = (unsigned short*)a.out + ooff + (long)r * a.ldo + n;
                         u32x4 hv, lv;
 #pragma unroll
                         for (int e = 0; e < 4; e++) {
-                            const unsigned hp = pack_bf16x2(t[e].x, t[e].y);
-                            const f32x2 rem = t[e] - unpack_bf16x2(hp);
-                            hv[e] = hp; lv[e] = pack_bf16x2(rem.x, rem.y);
+                            if (a.out_split3 == 2) {                               // IEEE-half planes: lo scaled by 2^11 (ops.hip: split2h)
+                                const unsigned hp = pack_f16x2(t[e].x, t[e].y);
+                                const f32x2 rem = (t[e] - unpack_f16x2(hp)) * 2048.f;
+                                hv[e] = hp; lv[e] = pack_f16x2(rem.x, rem.y);
+                            } else {
+                                const unsigned hp = pack_bf16x2(t[e].x, t[e].y);
+                                const f32x2 rem = t[e] - unpack_bf16x2(hp);
+                                hv[e] = hp; lv[e] = pack_bf16x2(rem.x, rem.y);
+                            }
                         }
                         *(u32x4*)op = hv; *(u32x4*)(op + a.N) = hv; *(u32x4*)(op + 2 * a.N) = lv;
                     } else {
@@ -917,7 +923,7 @@ static bool launch_convreg_c(const GemmArgs& a, hipStream_t stream) {
     if (a.flat_win) {                                     // 3 x 3 over a flattened map: halo = flat_win + 1 rows either side
         if (a.ntaps != 9 || a.halo_l + a.halo_r > 544 || lds > 160 * 1024) return false;
         auto kfn = convreg_kernel<C, 9, BM, WM, WN, MINW, 544>;
-        static bool attr_done = false;
+        static std::atomic<bool> attr_done{false};
         if (!attr_done) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_done = true; }
         ZVX_LAUNCH(kfn, grid, dim3(256), lds, stream, a);
         return true;
@@ -1379,8 +1385,7 @@ static bool launch_resfuse_persist_c(const GemmArgs& a, hipStream_t stream) {
     constexpr int BM1 = 32 * TM * (4 / (C >= 32 ? C / 32 : 1));
     const int h2 = (a.ntaps - 1) / 2, bmo = BM1 - 2 * h2;
     const int ntm = (a.M + bmo - 1) / bmo, ntiles = ntm * a.nbatch;
-    static int ncu = 0;
-    if (!ncu) { int dev = 0; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) ncu = 256; }
+    const int ncu = num_cus();
     dim3 grid(ntiles < ncu ? ntiles : ncu);
     for (int t = 0; t < a.ntaps; t++)                      // the kernel derives the taps from (kernel size, dilation)
         if (a.dv[t] != t - h2 || a.dv1[t] != (t - h2) * (a.dv1[1] - a.dv1[0])) return false;
@@ -1487,8 +1492,6 @@ static const Variant kVariants[] = {
 const char* gemm_variant_name(int id) { return kVariants[id].name; }
 int gemm_num_variants() { return (int)(sizeof(kVariants) / sizeof(kVariants[0])); }
 
-static int g_slab_small = 2;                                      // zvx_set_int("slab_small", v): single-request tile choice: 0 none, 1 small row tiles, 2 + 32-channel tiles for one-row-tile launches (A/B)
-void gemm_set_slab_small(int v) { g_slab_small = v; }
 
 template <int BM, int BN, int WM, int WN, int MINW, int R, int EPI = -1>
 static void launch_slab_variant(const GemmArgs& a, dim3 grid, size_t lds, hipStream_t stream) {
@@ -1520,11 +1523,11 @@ static int epi_mode_of(const GemmArgs& a) {
     return -1;
 }
 
-static int g_slab_flat = 1;                                       // zvx_set_int("slab_flat", v): 1 = tile -> XCD remap over batch x tiles (decoder convs -2 %, bit-identical; tools/ab_slab_flat.sh)
-void gemm_set_slab_flat(int v) { g_slab_flat = v; }
-
+// a.xcd_flat (zvx_set_int "slab_flat", default 1): tile -> XCD remap over batch x tiles (decoder convs -2 %, bit-identical; tools/ab_slab_flat.sh)
+// a.slab_small (zvx_set_int "slab_small", default 2): single-request tile choice: 0 none, 1 small row tiles, 2 + 32-channel tiles for one-row-tile launches
+// Both are the CONTEXT's switches (zvx_ctx::gemm fills them): no process-wide state.
 static int launch_convslab(GemmArgs a, hipStream_t stream) {
-    a.xcd_flat = g_slab_flat;
+    const int g_slab_small = a.slab_small;                        // (name kept from when this was a process-wide static)
     int hl = 0, hr = 0;
     for (int i = 0; i < a.ntaps; i++) { hl = a.dv[i] < -hl ? -a.dv[i] : hl; hr = a.dv[i] > hr ? a.dv[i] : hr; }
     a.halo_l = hl; a.halo_r = hr;
@@ -1552,8 +1555,7 @@ static int launch_convslab(GemmArgs a, hipStream_t stream) {
         if (best_cost < 0 || cost < best_cost - 1e-9) { best_cost = cost; best = i; }
     }
     static const int bms[4] = {128, 256, 256, 256};
-    static int ncu = 0;
-    if (!ncu) { int dev = 0; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) ncu = 256; }
+    const int ncu = num_cus();
     // single requests (a launch whose 256-row tiles would occupy a fraction of the CUs): 64- / 128-row tiles, 128 channels wide.  The
     // K loop of a tile is the same whatever its shape, so results do not depend on this choice.
     // a launch of ONE row tile and a handful of 128-channel tiles (a single request's encoder GEMMs): the workgroups stream their

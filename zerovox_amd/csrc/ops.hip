@@ -73,10 +73,13 @@ void launch_cast(const void* in, int in_dt, void* out, int out_dt, size_t n, hip
     hipLaunchKernelGGL(k_cast, dim3(blocks), dim3(256), 0, s, in, in_dt, out, out_dt, n);
 }
 // ---------------------------------------------------------------- 16-bit transpose  [b][rows][ld_in] -> [b][C][ld_out]
-__global__ __launch_bounds__(256) void k_transpose16(const unsigned short* in, int ld_in, unsigned short* out, int ld_out, int rows, int C) {
+__global__ __launch_bounds__(256) void k_transpose16(const unsigned short* in, int ld_in, unsigned short* out, int ld_out, int rows_max, int C, const int* len) {
     __shared__ unsigned short tile[64][66];
     const int b = blockIdx.z, r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
-    const unsigned short* ip = in + (long)b * rows * ld_in;
+    // rows past the utterance's own length are never written by the producing GEMM (it masks by out_len): they read as zeros here,
+    // whatever an earlier call (or another precision's use of the shared buffer) left there -- 0 * stale NaN = NaN in P.V otherwise
+    const int rows = len ? min(len[b], rows_max) : rows_max;
+    const unsigned short* ip = in + (long)b * rows_max * ld_in;
     unsigned short* op = out + (long)b * C * ld_out;
     for (int i = threadIdx.x; i < 64 * 64; i += 256) {
         const int r = i >> 6, c = i & 63;
@@ -88,51 +91,83 @@ __global__ __launch_bounds__(256) void k_transpose16(const unsigned short* in, i
         if (c0 + c < C && r0 + r < ld_out) op[(long)(c0 + c) * ld_out + r0 + r] = (r0 + r < rows) ? tile[r][c] : (unsigned short)0;
     }
 }
-void launch_transpose16(const void* in, int ld_in, void* out, int ld_out, int B, int rows, int C, hipStream_t s) {
+void launch_transpose16(const void* in, int ld_in, void* out, int ld_out, int B, int rows, int C, hipStream_t s, const int* len) {
     if (rows <= 0) return;
-    hipLaunchKernelGGL(k_transpose16, dim3((C + 63) / 64, (ld_out + 63) / 64, B), dim3(256), 0, s, (const unsigned short*)in, ld_in, (unsigned short*)out, ld_out, rows, C);
+    hipLaunchKernelGGL(k_transpose16, dim3((C + 63) / 64, (ld_out + 63) / 64, B), dim3(256), 0, s, (const unsigned short*)in, ld_in, (unsigned short*)out, ld_out, rows, C, len);
 }
 
 void launch_f32_to_bf16(const float* in, bf16_t* out, size_t n, hipStream_t s) { launch_cast(in, DT_F32, out, DT_BF16, n, s); }
 
-// ---------------------------------------------------------------- bf16 split planes of an f32 tensor
-// f32-class GEMMs on the bf16 MFMA: x = hi + lo (+ 2^-17 x), w = wh + wl likewise, and
-//     x.w ~= hi.wh + hi.wl + lo.wh     (the dropped lo.wl term is 2^-18 relative)
-// is ONE bf16 GEMM over a K axis of three planes: activations [hi | hi | lo] against weights [wh | wl | wh], accumulated in
+// ---------------------------------------------------------------- 16-bit split planes of an f32 tensor
+// f32-class GEMMs on the 16-bit MFMA: x = hi + lo, w = wh + wl, and
+//     x.w ~= hi.wh + hi.wl + lo.wh
+// is ONE 16-bit GEMM over a K axis of three planes: activations [hi | hi | lo] against weights [wh | wl | wh], accumulated in
 // f32 by the MFMA.  k_split3 writes the activation planes (rows past an utterance's length as zeros), k_split3_w the weights.
+//   bf16 planes (f16 = 0, the round-2/3 path, kept as an A/B): 8-bit significands, hi + lo carries 16 bits, the dropped lo.wl
+//     term is 2^-18 relative -- 5e-5 on the encoder output.
+//   IEEE-half planes (f16 = 1, default): 11-bit significands, hi + lo carries 22 bits + sign (2^-24 relative: an f32 half-ulp),
+//     the dropped term is 2^-24.  Half has 5 exponent bits, so the planes are SCALED by powers of two to stay normal:
+//       activations [xh | xh | xl * 2^11]           (xl = x - xh is 2^-12 |x| at most; x itself sits behind a LayerNorm)
+//       weights     [wh | wl | w * 2^-11] * 2^s     (s per tensor: max |w| 2^s in [2^14, 2^15); the epilogue multiplies by 2^-s)
+//     every product pair shares the scale 2^s: xh.wh, xh.wl, (xl 2^11).(w 2^(s-11)).
 __device__ __forceinline__ void split2(float v, unsigned short& hi, unsigned short& lo) {
     hi = tobf(v);
     lo = tobf(v - __uint_as_float(((unsigned)hi) << 16));
 }
-__global__ __launch_bounds__(256) void k_split3(const float* x, int ldx, unsigned short* out, int rows_max, const int* rows, int C) {
+__device__ __forceinline__ void split2h(float v, unsigned short& hi, unsigned short& lo) {
+    const _Float16 h = (_Float16)clamp_h(v);
+    hi = __builtin_bit_cast(unsigned short, h);
+    lo = __builtin_bit_cast(unsigned short, (_Float16)clamp_h((v - (float)h) * 2048.f));
+}
+__device__ __forceinline__ void split2x(float v, int f16, unsigned short& hi, unsigned short& lo) { if (f16) split2h(v, hi, lo); else split2(v, hi, lo); }
+__global__ __launch_bounds__(256) void k_split3(const float* x, int ldx, unsigned short* out, int rows_max, const int* rows, int C, int f16) {
     const int b = blockIdx.y, r = blockIdx.x;
     const bool live = r < (rows ? rows[b] : rows_max);
     const float* xr = x + ((long)b * rows_max + r) * ldx;
     unsigned short* o = out + ((long)b * rows_max + r) * 3 * C;
     for (int c = threadIdx.x * 4; c < C; c += blockDim.x * 4) {                 // C % 4 == 0
         unsigned short h[4], l[4];
-        if (live) { const float4 v = *(const float4*)(xr + c); split2(v.x, h[0], l[0]); split2(v.y, h[1], l[1]); split2(v.z, h[2], l[2]); split2(v.w, h[3], l[3]); }
+        if (live) { const float4 v = *(const float4*)(xr + c); split2x(v.x, f16, h[0], l[0]); split2x(v.y, f16, h[1], l[1]); split2x(v.z, f16, h[2], l[2]); split2x(v.w, f16, h[3], l[3]); }
         else { for (int e = 0; e < 4; e++) h[e] = l[e] = 0; }
         const uint2 hv = make_uint2(h[0] | ((unsigned)h[1] << 16), h[2] | ((unsigned)h[3] << 16));
         const uint2 lv = make_uint2(l[0] | ((unsigned)l[1] << 16), l[2] | ((unsigned)l[3] << 16));
         *(uint2*)(o + c) = hv; *(uint2*)(o + C + c) = hv; *(uint2*)(o + 2 * C + c) = lv;
     }
 }
-void launch_split3(const float* x, int ldx, void* out, int B, int rows_max, const int* rows, int C, hipStream_t s) {
+void launch_split3(const float* x, int ldx, void* out, int B, int rows_max, const int* rows, int C, hipStream_t s, int f16) {
     if (rows_max <= 0) return;
-    hipLaunchKernelGGL(k_split3, dim3(rows_max, B), dim3(C >= 1024 ? 256 : 128), 0, s, x, ldx, (unsigned short*)out, rows_max, rows, C);
+    hipLaunchKernelGGL(k_split3, dim3(rows_max, B), dim3(C >= 1024 ? 256 : 128), 0, s, x, ldx, (unsigned short*)out, rows_max, rows, C, f16);
 }
-__global__ void k_split3_w(const float* w, unsigned short* out, long nrows, int K) {
+__global__ void k_split3_w(const float* w, unsigned short* out, long nrows, int K, int f16, float scale) {
     const long r = blockIdx.x;
     if (r >= nrows) return;
     for (int k = threadIdx.x; k < K; k += blockDim.x) {
-        unsigned short h, l;
-        split2(w[r * K + k], h, l);
-        out[r * 3 * K + k] = h; out[r * 3 * K + K + k] = l; out[r * 3 * K + 2 * K + k] = h;
+        unsigned short h, l, h3;
+        if (f16) {
+            const float v = w[r * K + k] * scale;                                // scale = 2^s: exact
+            const _Float16 wh = (_Float16)clamp_h(v);
+            h = __builtin_bit_cast(unsigned short, wh);
+            l = __builtin_bit_cast(unsigned short, (_Float16)(v - (float)wh));
+            h3 = __builtin_bit_cast(unsigned short, (_Float16)clamp_h(v * (1.0f / 2048.f)));
+        } else { split2(w[r * K + k], h, l); h3 = h; }
+        out[r * 3 * K + k] = h; out[r * 3 * K + K + k] = l; out[r * 3 * K + 2 * K + k] = h3;
     }
 }
-void launch_split3_weights(const float* w, void* out, long nrows, int K, hipStream_t s) {
-    hipLaunchKernelGGL(k_split3_w, dim3((unsigned)nrows), dim3(256), 0, s, w, (unsigned short*)out, nrows, K);
+void launch_split3_weights(const float* w, void* out, long nrows, int K, hipStream_t s, int f16, float scale) {
+    hipLaunchKernelGGL(k_split3_w, dim3((unsigned)nrows), dim3(256), 0, s, w, (unsigned short*)out, nrows, K, f16, scale);
+}
+// max |x| over n floats (load-time: the per-tensor scale of the half-precision weight planes); out must be zeroed
+__global__ void k_absmax(const float* x, size_t n, unsigned* out) {
+    float m = 0.f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) m = fmaxf(m, fabsf(x[i]));
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) atomicMax(out, __float_as_uint(m));           // non-negative floats order like their bit patterns
+}
+void launch_absmax(const float* x, size_t n, float* out, hipStream_t s) {
+    (void)hipMemsetAsync(out, 0, 4, s);
+    if (!n) return;
+    int blocks = (int)((n + 255) / 256); if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(k_absmax, dim3(blocks), dim3(256), 0, s, x, n, (unsigned*)out);
 }
 
 // ---------------------------------------------------------------- embedding + positional encoding
@@ -156,13 +191,13 @@ void launch_embed(const int* phoneme, const int* puncts, const float* emb, int e
 // ---------------------------------------------------------------- LayerNorm / SCLN, one wave per row
 __global__ void k_layernorm(const void* x, int xdt, int ldx, void* y, int ydt, int ldy, int rows_max, const int* rows,
                             int C, int mode, float eps, const float* gamma, const float* beta, const float* bg,
-                            long bg_bs, const float* post_add, unsigned short* planes) {
+                            long bg_bs, const float* post_add, unsigned short* planes, int planes_f16) {
     const int b = blockIdx.y;
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const int nr = rows ? rows[b] : rows_max;
     if (r >= nr) {
-        // planes: the [hi | hi | lo] bf16 split of the result for the next split-product GEMM (what k_split3 would write), zeros past the utterance
+        // planes: the [hi | hi | lo] 16-bit split of the result for the next split-product GEMM (what k_split3 would write), zeros past the utterance
         if (planes && r < rows_max) { unsigned short* o = planes + ((long)b * rows_max + r) * 3 * C; for (int c = lane; c < 3 * C; c += 64) o[c] = 0; }
         return;
     }
@@ -185,7 +220,7 @@ __global__ void k_layernorm(const void* x, int xdt, int ldx, void* y, int ydt, i
         st(y, ydt, yo + c, v);
         if (planes) {
             unsigned short hi, lo;
-            split2(v, hi, lo);
+            split2x(v, planes_f16, hi, lo);
             unsigned short* o = planes + ((long)b * rows_max + r) * 3 * C;
             o[c] = hi; o[C + c] = hi; o[2 * C + c] = lo;
         }
@@ -193,9 +228,9 @@ __global__ void k_layernorm(const void* x, int xdt, int ldx, void* y, int ydt, i
 }
 void launch_layernorm(const void* x, int x_dt, int ldx, void* y, int y_dt, int ldy, int B, int rows_max,
                       const int* rows, int C, int mode, float eps, const float* gamma, const float* beta,
-                      const float* bg, long bg_bs, const float* post_add, hipStream_t s, void* split_planes) {
+                      const float* bg, long bg_bs, const float* post_add, hipStream_t s, void* split_planes, int planes_f16) {
     hipLaunchKernelGGL(k_layernorm, dim3((rows_max + 3) / 4, B), dim3(256), 0, s, x, x_dt, ldx, y, y_dt, ldy, rows_max,
-                       rows, C, mode, eps, gamma, beta, bg, bg_bs, post_add, (unsigned short*)split_planes);
+                       rows, C, mode, eps, gamma, beta, bg, bg_bs, post_add, (unsigned short*)split_planes, planes_f16);
 }
 
 // ---------------------------------------------------------------- row softmax with key-length mask

@@ -440,11 +440,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     else ps_role<1, NT, AM, HAS_OUT>(a, lds, lane, wave - 4);
 }
 
-static int g_ps_ncu = 0;
-static int ps_ncu() {
-    if (!g_ps_ncu) { int dev = 0; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&g_ps_ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || g_ps_ncu <= 0) g_ps_ncu = 256; }
-    return g_ps_ncu;
-}
+static int ps_ncu() { return num_cus(); }
 
 bool launch_pairstream(PairArgs a, hipStream_t stream, bool dry_run, hipEvent_t ev_start, hipEvent_t ev_stop) {
     if (a.C != 128 || a.ldx != a.C || a.dil < 1 || !a.W1 || !a.W2 || !a.b1 || !a.b2) return false;
@@ -474,7 +470,7 @@ bool launch_pairstream(PairArgs a, hipStream_t stream, bool dry_run, hipEvent_t 
     const int nsegs = a.nseg * a.nbatch;
     const dim3 grid(nsegs < nwg ? nsegs : nwg), block(512);
 #define PS_GO(NT_, AM_, HO_) do { auto kfn = pairstream128_kernel<NT_, AM_, HO_>; \
-        static bool attr_done = false; \
+        static std::atomic<bool> attr_done{false}; \
         if (!attr_done) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_done = true; } \
         if (ev_start) hipExtLaunchKernelGGL(kfn, grid, block, lds, stream, ev_start, ev_stop, 0, a); \
         else hipLaunchKernelGGL(kfn, grid, block, lds, stream, a); return true; } while (0)

@@ -470,11 +470,7 @@ __global__ __launch_bounds__(128 * NPAIR * (C / 32) * RSPLIT) void resstream_ker
 // ------------------------------------------------------------------------------------------------
 // launcher
 // ------------------------------------------------------------------------------------------------
-static int g_ncu = 0;
-static int ncu() {
-    if (!g_ncu) { int dev = 0; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&g_ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || g_ncu <= 0) g_ncu = 256; }
-    return g_ncu;
-}
+static int ncu() { return num_cus(); }
 
 template <int C, int NT, int NPAIR, int RSPLIT, int DP>
 static bool launch_rs(StreamArgs& a, hipStream_t stream, bool dry_run) {
@@ -512,7 +508,7 @@ static bool launch_rs(StreamArgs& a, hipStream_t stream, bool dry_run) {
     const dim3 grid(nsegs < nwg ? nsegs : nwg), block(64 * NR * WPR);
     const int am = a.accum ? a.accum_mode : 0;
 #define RS_GO(AM_, HO_) do { auto kfn = resstream_kernel<C, NT, NPAIR, RSPLIT, AM_, HO_, DP>; \
-        static bool attr_done = false; \
+        static std::atomic<bool> attr_done{false}; \
         if (!attr_done) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_done = true; } \
         if (g_rs_ev_start) hipExtLaunchKernelGGL(kfn, grid, block, lds, stream, g_rs_ev_start, g_rs_ev_stop, 0, a); \
         else hipLaunchKernelGGL(kfn, grid, block, lds, stream, a); return true; } while (0)

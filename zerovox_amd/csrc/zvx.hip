@@ -8,6 +8,7 @@
 
 #include <dlfcn.h>
 #include <math.h>
+#include <cmath>
 #include <rccl/rccl.h>          // types and prototypes only: the library is dlopen'ed by zvx_comm_* (single-GPU use never loads it)
 #include <stdarg.h>
 #include <stdio.h>
@@ -44,6 +45,7 @@ struct Tensor {
     void* dev = nullptr;
     int dtype = DT_F32;
     const float* host = nullptr;
+    float alpha = 1.f;                       // split-plane weights in IEEE half: the planes carry w * 2^s, alpha = 2^-s (applied by the GEMM epilogue)
     int dim(int i) const { return dims.at(i); }
 };
 
@@ -62,6 +64,17 @@ struct zvx_ctx {
     hipEvent_t voc_ev[3] = {nullptr, nullptr, nullptr};
     int voc_overlap_maxb = 1 << 20;        // zvx_set_int("voc_overlap_maxb", n): batches of at most n utterances use them (0: never; A/B)
     long voc_overlap_frames = 28672;       // zvx_set_int("voc_overlap_frames", n): ... and only below n mel frames per call (B x Pmax)
+    // Front end of call i+1 under the vocoder of call i (zvx_synthesize): encoder / variance adaptor / length regulator / mel decoder are
+    // issued on front_stream, the vocoder on `stream`.  The two meet in ONE buffer, "mel": the vocoder waits for ev_front_done, the
+    // next call's front end waits for ev_mel_free (recorded behind the vocoder's first kernel, which copies the mel into its padded
+    // input).  A host that queues calls (ZVX_DEVICE_OUT | ZVX_NO_SYNC) gets the latency-paced front end (5-28 % of the matrix roof)
+    // hidden under the previous call's vocoder; a host that waits for every call sees the serial schedule.  Results are bit-identical
+    // (same kernels on the same data).  zvx_set_int("front_overlap", 0): everything on `stream` (A/B).
+    hipStream_t front_stream = nullptr;
+    hipEvent_t ev_front_done = nullptr, ev_mel_free = nullptr, ev_main_join = nullptr;
+    int front_overlap = 1;
+    bool mel_free_pending = false;         // ev_mel_free is recorded and the front stream has not waited for it yet
+    bool front_dirty_main = true;          // front-end buffers were touched on `stream` (zvx_encode / zvx_decode ...) since the front stream last joined it
     hipStream_t aux_stream = nullptr;      // second compute stream: the duration predictor of a small batch beside the pitch predictor
     hipEvent_t ev_aux[2] = {nullptr, nullptr};
     int va_overlap_maxb = 1 << 20;             // zvx_set_int("va_overlap_maxb", n): batches of at most n utterances overlap the two predictors (0: never; A/B)
@@ -92,7 +105,8 @@ struct zvx_ctx {
     int profile = 0;
     int profile_only = -1;                 // >= 0: per-launch events only for this kernel variant (keeps the timed region lean)
     int rs_prof = 0;                       // zvx_set_int("rs_prof", 1): per-wave cycle counters of the streaming kernels (library built with -DRS_PROFILE)
-    int enc_split = 0;                     // bf16 mode: the f32 GEMMs of the phoneme encoder / variance adaptor run as 3-plane bf16 GEMMs
+    int enc_split = 0;                     // 16-bit mode: the f32 GEMMs of the phoneme encoder run as 3-plane 16-bit GEMMs: 2 = IEEE-half planes (default: 2^-24-class, f32
+                                           // results), 1 = bf16 planes (rounds 2-3: 5e-5 on the encoder output; A/B), 0 = the exact-f32 MFMA
     const void* fft_xs_ready = nullptr;     // fft.xs holds the split planes of this buffer (written by the previous FFT block's last LayerNorm)
     int norm_fuse_maxb = 1 << 20;          // zvx_set_int("norm_fuse_maxb", n): batches of at most n utterances may take the one-launch InstanceNorm of the StyleTTS decoder (0: never; A/B)
     int dec_f16 = 1;                       // zvx_set_int("dec_f16", 0): StyleTTS decoder activations / weights in bf16 instead of IEEE half (A/B)
@@ -102,6 +116,7 @@ struct zvx_ctx {
     int use_resstream = 1;                 // zvx_set_int("resstream", 0): ResBlocks of the narrow stages as per-pair launches (A/B, bit-equal)
     int rs_seg_min = 0;                    // zvx_set_int("rs_seg_min", -1): streaming ResBlock segments never shorter than 2048 rows (A/B of the single-request sizing)
     int rs_opt = 3;                        // zvx_set_int("rs_opt", v): StreamArgs.opt of the streaming ResBlock kernels (bit 0: staggered wave priorities)
+    int slab_small = 2, slab_flat = 1;     // zvx_set_int("slab_small" / "slab_flat", v): conv-slab tile choice for single requests / whole-grid XCD remap (A/B; per context)
     int use_pairstream = 1;                // zvx_set_int("pairstream", v): C = 128 ResBlock pairs on pairstream.hip: 1 = every k (default; jobs under ~200 k rows run the bit-identical two-launch path), 3 = every k and every job size (tests), 4 = like 3 with 256-row segments for small jobs, 2 = k >= 7 only (k = 3 on the register-resident resfuse kernel, which adds the running sum after rounding to bf16), 0 = none, -1 = no fused kernel at all for C = 128 (two conv-slab launches per pair: the bit-equality reference)
     int shape_log = 0;                     // zvx_set_int("shape_log", 1): one stderr line per timed launch (profile 2)
     int max_frames = 1 << 18;              // hard cap on a predicted mel length (guards the allocation, fs2.py:678-681 has none)
@@ -189,7 +204,13 @@ struct zvx_ctx {
         Arena& a = arena[arena_i];
         const size_t need = (bytes + 63) & ~(size_t)63;
         if (!a.p) { HIPCHK(hipHostMalloc((void**)&a.p, ARENA_BYTES, hipHostMallocDefault)); a.cap = ARENA_BYTES; }
-        if (a.cur + need > a.cap) { HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream)); return; }   // large: as before
+        if (a.cur + need > a.cap) {
+            // larger than what is left of the arena: a plain copy, COMPLETED before this returns (the caller's / the context's staging
+            // memory may be reused right after the call; the runtime's own staging of pageable copies is not a contract to lean on)
+            HIPCHK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, stream));
+            HIPCHK(hipStreamSynchronize(stream));
+            return;
+        }
         memcpy(a.p + a.cur, src, bytes);
         HIPCHK(hipMemcpyAsync(dst, a.p + a.cur, bytes, hipMemcpyHostToDevice, stream));
         a.cur += need;
@@ -213,6 +234,7 @@ struct zvx_ctx {
     void gemm(GemmArgs& a) {
         if (a.flops <= 0) a.flops = 2.0 * (double)a.M * a.nbatch * a.nheads * (double)a.N * (double)a.K * a.ntaps;
         if (!a.Wp && a.dtype != DT_F32) { auto it = packed.find(a.W); if (it != packed.end()) a.Wp = it->second; }
+        a.slab_small = slab_small; a.xcd_flat = slab_flat;
         GemmEvent ev{};
         const bool prof = profile >= 2 && (profile_only < 0 || gemm_variant_of(a) == profile_only);
         if (prof) { ev.a = new_event(); ev.b = new_event(); gemm_profile_events(ev.a, ev.b); }
@@ -282,9 +304,31 @@ struct zvx_ctx {
             if (stage_used[s]) { float ms = 0.f; HIPCHK(hipEventElapsedTime(&ms, stage_ev[s][0], stage_ev[s][1])); stage_ms[s] = ms; stage_used[s] = false; }
     }
     void sync() {
+        if (front_stream) HIPCHK(hipStreamSynchronize(front_stream));
         HIPCHK(hipStreamSynchronize(stream));
         if (comm_stream) HIPCHK(hipStreamSynchronize(comm_stream));
         if (profile) resolve_events();
+    }
+    // error path of an API call: whatever it queued on a side stream before it threw is drained, so that the next call's main-stream
+    // work cannot race with it (the joins that normally order the streams were never issued)
+    void quiesce_side_streams() noexcept {
+        if (front_stream) (void)hipStreamSynchronize(front_stream);
+        if (aux_stream) (void)hipStreamSynchronize(aux_stream);
+        for (int i = 0; i < 2; i++) if (voc_aux[i]) (void)hipStreamSynchronize(voc_aux[i]);
+        front_dirty_main = true; mel_free_pending = false;
+    }
+    int front_prio = 1;                    // zvx_set_int("front_prio", v): priority of the front stream: 1 = highest the device offers, -1 = lowest, 0 = default
+    void front_setup() {
+        if (front_stream) return;
+        if (front_prio) {
+            int least = 0, greatest = 0;                                     // (numerically: greatest priority = the smaller value)
+            HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+            HIPCHK(hipStreamCreateWithPriority(&front_stream, hipStreamNonBlocking, front_prio > 0 ? greatest : least));
+        } else
+        HIPCHK(hipStreamCreateWithFlags(&front_stream, hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&ev_front_done, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&ev_mel_free, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&ev_main_join, hipEventDisableTiming));
     }
 };
 
@@ -333,6 +377,57 @@ void parse_manifest(zvx_ctx* c, const char* manifest, const void* weights, size_
         }
     }
     if (first) fail(ZVX_E_MANIFEST, "manifest: empty");
+}
+
+// phoneme encoder (kept in f32 because it feeds discrete decisions): in the 16-bit mode its static-weight GEMMs run on the 16-bit
+// MFMA as 3-plane split products (ops.hip: k_split3), f32-class accuracy at ~5x the f32 MFMA rate.
+// Weights [taps][N][K] f32 -> 16-bit [taps][N][wh | wl | wh], fragment-packed like every other slab-kernel weight.  f16: IEEE-half
+// planes scaled by 2^s per tensor (".s3h", Tensor.alpha = 2^-s), else bf16 planes (".s3").  Built from the f32 copies on the
+// device, at load for the default mode and on the first zvx_set_int("enc_split", other mode).
+void build_split_weights(zvx_ctx* c, bool f16) {
+    const char* sfx = f16 ? ".s3h" : ".s3";
+    if (c->has(std::string("enc.0.wqk") + sfx)) return;
+    std::vector<std::pair<std::string, Tensor>> add;
+    size_t stotal = 0;
+    for (auto& kv : c->tensors) {
+        const Tensor& t = kv.second;
+        const bool mine = kv.first.rfind("enc.", 0) == 0;      // the variance predictors stay on the exact-f32 MFMA: N = 256 gives the
+                                                                 // slab tiling too few workgroups to win, and their outputs are the decisions
+        if (!mine || t.kind != 'f' || t.dtype != DT_F32 || t.dims.size() != 3 || (3 * t.dim(2)) % 16 || t.dim(1) % 8) continue;
+        Tensor s3 = t;
+        s3.kind = 's'; s3.dtype = f16 ? DT_F16 : DT_BF16; s3.dims = {t.dim(0), t.dim(1), 3 * t.dim(2)}; s3.numel = t.numel * 3; s3.host = nullptr;
+        stotal += ((s3.numel * 2 + 255) & ~(size_t)255) + ((packed_weight_elems(s3.dim(0), s3.dim(1), s3.dim(2)) * 2 + 255) & ~(size_t)255);
+        add.emplace_back(kv.first + sfx, s3);
+    }
+    char* sarena = stotal ? (char*)c->buf(f16 ? "weights_split_h" : "weights_split", stotal) : nullptr;
+    float* mx_d = f16 ? c->fbuf("weights_split_absmax", 64) : nullptr;
+    size_t soff = 0;
+    for (auto& kv : add) {
+        Tensor& s3 = kv.second;
+        const Tensor& src = c->tensors[kv.first.substr(0, kv.first.size() - strlen(sfx))];
+        float scale = 1.f;
+        if (f16) {
+            // s: max |w| 2^s in [2^14, 2^15) -- the hi plane uses the top of half's range, wl = w 2^s - wh stays normal down to
+            // |w| ~ 2^-9 max |w| and the third plane (w 2^(s-11)) down to 2^-17 max |w|; below that the planes lose bits of an
+            // element whose contribution is already < 2^-24 of the row's largest
+            float mx = 0.f;
+            launch_absmax((const float*)src.dev, src.numel, mx_d, c->stream);
+            HIPCHK(hipMemcpyAsync(&mx, mx_d, 4, hipMemcpyDeviceToHost, c->stream));
+            HIPCHK(hipStreamSynchronize(c->stream));
+            if (!(mx > 0.f) || !std::isfinite(mx)) mx = 1.f;
+            int e = 0; (void)frexpf(mx, &e);                 // mx = m 2^e, m in [0.5, 1)
+            int sh = 15 - e; sh = std::max(-24, std::min(sh, 40));
+            scale = ldexpf(1.f, sh);
+            s3.alpha = ldexpf(1.f, -sh);
+        }
+        s3.dev = sarena + soff; soff += (s3.numel * 2 + 255) & ~(size_t)255;
+        launch_split3_weights((const float*)src.dev, s3.dev, (long)src.dim(0) * src.dim(1), src.dim(2), c->stream, f16 ? 1 : 0, scale);
+        void* pk = sarena + soff; soff += (packed_weight_elems(s3.dim(0), s3.dim(1), s3.dim(2)) * 2 + 255) & ~(size_t)255;
+        launch_pack_weights(s3.dev, s3.dim(0), s3.dim(1), s3.dim(2), pk, c->stream);
+        c->packed[s3.dev] = pk;
+        c->tensors[kv.first] = s3;
+    }
+    HIPCHK(hipStreamSynchronize(c->stream));
 }
 
 void upload_weights(zvx_ctx* c) {
@@ -422,35 +517,7 @@ void upload_weights(zvx_ctx* c) {
         }
         for (auto& kv : add) c->tensors[kv.first] = kv.second;
     }
-    // phoneme encoder (kept in f32 because it feeds discrete decisions): in bf16 mode its static-weight
-    // GEMMs run on the bf16 MFMA as 3-plane split products (ops.hip: k_split3), f32-class accuracy at ~5x the f32 MFMA rate.
-    // Weights [taps][N][K] -> bf16 [taps][N][wh | wl | wh], fragment-packed like every other slab-kernel weight.
-    if (c->enc_split) {
-        std::vector<std::pair<std::string, Tensor>> add;
-        size_t stotal = 0;
-        for (auto& kv : c->tensors) {
-            const Tensor& t = kv.second;
-            const bool mine = kv.first.rfind("enc.", 0) == 0;      // the variance predictors stay on the exact-f32 MFMA: N = 256 gives the
-                                                                     // slab tiling too few workgroups to win, and their outputs are the decisions
-            if (!mine || t.kind != 'f' || t.dims.size() != 3 || (3 * t.dim(2)) % 16 || t.dim(1) % 8) continue;
-            Tensor s3 = t;
-            s3.kind = 's'; s3.dtype = DT_BF16; s3.dims = {t.dim(0), t.dim(1), 3 * t.dim(2)}; s3.numel = t.numel * 3; s3.host = nullptr;
-            stotal += ((s3.numel * 2 + 255) & ~(size_t)255) + ((packed_weight_elems(s3.dim(0), s3.dim(1), s3.dim(2)) * 2 + 255) & ~(size_t)255);
-            add.emplace_back(kv.first + ".s3", s3);
-        }
-        char* sarena = stotal ? (char*)c->buf("weights_split", stotal) : nullptr;
-        size_t soff = 0;
-        for (auto& kv : add) {
-            Tensor& s3 = kv.second;
-            const Tensor& src = c->tensors[kv.first.substr(0, kv.first.size() - 3)];
-            s3.dev = sarena + soff; soff += (s3.numel * 2 + 255) & ~(size_t)255;
-            launch_split3_weights((const float*)src.dev, s3.dev, (long)src.dim(0) * src.dim(1), src.dim(2), c->stream);
-            void* pk = sarena + soff; soff += (packed_weight_elems(s3.dim(0), s3.dim(1), s3.dim(2)) * 2 + 255) & ~(size_t)255;
-            launch_pack_weights(s3.dev, s3.dim(0), s3.dim(1), s3.dim(2), pk, c->stream);
-            c->packed[s3.dev] = pk;
-            c->tensors[kv.first] = s3;
-        }
-    }
+    if (c->enc_split) build_split_weights(c, c->enc_split == 2);
     HIPCHK(hipStreamSynchronize(c->stream));
     DevBuf& st = c->bufs["weights_staging"];
     HIPCHK(hipFree(st.base)); st.base = nullptr; st.p = nullptr; st.cap = 0;
@@ -461,7 +528,7 @@ void read_config(zvx_ctx* c) {
     if (it == c->cfg.end()) fail(ZVX_E_MANIFEST, "manifest: missing cfg 'precision'");
     if (it->second == "bf16") c->dt = DT_BF16; else if (it->second == "f32") c->dt = DT_F32;
     else fail(ZVX_E_MANIFEST, "manifest: unknown precision '%s'", it->second.c_str());
-    c->enc_split = c->dt == DT_BF16 ? (c->cfg.count("enc_split") ? c->cfg_int("enc_split") : 1) : 0;
+    c->enc_split = c->dt == DT_BF16 ? (c->cfg.count("enc_split") ? std::max(0, std::min(2, c->cfg_int("enc_split"))) : 2) : 0;
     c->H = c->cfg_int("hidden"); c->emb_dim = c->cfg_int("emb_dim"); c->punct_dim = c->cfg_int("punct_dim");
     c->n_phone_rows = c->cfg_int("n_phone_rows"); c->n_punct_rows = c->cfg_int("n_punct_rows");
     c->max_txt_len = c->cfg_int("max_txt_len"); c->max_mel_len = c->cfg_int("max_mel_len");
@@ -511,12 +578,15 @@ void fft_block(zvx_ctx* c, void* x, int dt, int B, int Lmax, const int* len_dev,
 
     // f32 blocks (phoneme encoder) in bf16 mode: the static-weight GEMMs take bf16 split planes [hi | hi | lo] of their f32 input
     // against [wh | wl | wh] weights (K = 3 x the logical K): f32-class results from the bf16 MFMA
-    const bool split = dt == DT_F32 && c->enc_split && c->has(w.p + ".wqk.s3");
+    const bool sp16 = c->enc_split == 2;                                          // IEEE-half planes (f32-class to 2^-24) / bf16 planes (2^-17)
+    const char* const s3 = sp16 ? ".s3h" : ".s3";
+    const bool split = dt == DT_F32 && c->enc_split && c->has(w.p + ".wqk" + s3);
     void* xs = split ? c->buf("fft.xs", (size_t)B * Lmax * 3 * H * 2) : nullptr;
-    auto split_of = [&](const float* src, int C, void* dst) { launch_split3(src, C, dst, B, Lmax, len_dev, C, c->stream); };
+    auto split_of = [&](const float* src, int C, void* dst) { launch_split3(src, C, dst, B, Lmax, len_dev, C, c->stream, sp16); };
     auto as_split = [&](GemmArgs& a, const void* planes, int C, const std::string& wname) {      // operand swap: same GEMM, 3-plane K axis
-        const Tensor& ws = c->t(wname + ".s3");
-        a.dtype = DT_BF16; a.X = planes; a.x_bs = (long)Lmax * 3 * C; a.ldx = 3 * C; a.K = 3 * C;
+        const Tensor& ws = c->t(wname + s3);
+        a.dtype = sp16 ? DT_F16 : DT_BF16; a.X = planes; a.x_bs = (long)Lmax * 3 * C; a.ldx = 3 * C; a.K = 3 * C;
+        a.alpha = ws.alpha;                                                                        // half planes carry w 2^s
         a.W = ws.dev; a.ldw = 3 * C; a.w_ts = (long)ws.dim(1) * 3 * C;
         a.flops = 2.0 * (double)a.M * a.nbatch * a.N * C * a.ntaps;                                 // algorithmic (f32) work, not the 3x issued
     };
@@ -542,7 +612,7 @@ void fft_block(zvx_ctx* c, void* x, int dt, int B, int Lmax, const int* len_dev,
         a.out = qkv; a.o_bs = (long)Lmax * 3 * H; a.ldo = 3 * H;
         c->gemm(a);
         af.qkv = qkv;
-        if (split) { af.planes = (unsigned short*)xs; af.planes_C = H; }           // o as split planes for the output projection
+        if (split) { af.planes = (unsigned short*)xs; af.planes_C = H; af.planes_f16 = sp16; }   // o as split planes for the output projection
         c->timed(4.0 * B * nheads * (double)Lmax * Lmax * d, (double)B * Lmax * 4.0 * H * 4, [&] { launch_attention_f32(af, c->stream, false); });
     } else {
     if (split) split_of((const float*)x, H, xs);
@@ -563,7 +633,7 @@ void fft_block(zvx_ctx* c, void* x, int dt, int B, int Lmax, const int* len_dev,
         a.bias = c->pf(w.p + ".bv"); a.bias_mode = 1;
         a.out = vrow; a.o_bs = (long)Lmax * H; a.ldo = H;
         c->gemm(a);
-        c->timed(0, (double)B * Lmax * H * 4.0, [&] { launch_transpose16(vrow, H, vt, Lp, B, Lmax, H, c->stream); });
+        c->timed(0, (double)B * Lmax * H * 4.0, [&] { launch_transpose16(vrow, H, vt, Lp, B, Lmax, H, c->stream, len_dev); });   // V^T columns >= len[b]: zeros (stale rows of the shared FFN buffer)
     } else
     {   // V^T[h*d + j][l] = Wv x^T + b  (stored transposed so that P.V is K-contiguous)   fs2.py:145
         GemmArgs a = gemm_base(dt);
@@ -625,7 +695,7 @@ void fft_block(zvx_ctx* c, void* x, int dt, int B, int Lmax, const int* len_dev,
     const double ln_bytes = (double)B * Lmax * H * (4.0 + es);
     c->timed(0, ln_bytes, [&] {
         if (w.scln) launch_layernorm(y, DT_F32, H, x, dt, H, B, Lmax, len_dev, H, 1, 1e-8f, nullptr, nullptr, w.bg, w.bg_bs, nullptr, c->stream);
-        else launch_layernorm(y, DT_F32, H, x, dt, H, B, Lmax, len_dev, H, 0, 1e-5f, c->pf(w.p + ".ln1_g"), c->pf(w.p + ".ln1_b"), nullptr, 0, nullptr, c->stream, split ? xs : nullptr);
+        else launch_layernorm(y, DT_F32, H, x, dt, H, B, Lmax, len_dev, H, 0, 1e-5f, c->pf(w.p + ".ln1_g"), c->pf(w.p + ".ln1_b"), nullptr, 0, nullptr, c->stream, split ? xs : nullptr, sp16);
     });
     {   // h = relu(conv_k9(x))                                         fs2.py:198-200
         GemmArgs a = gemm_base(dt);
@@ -638,7 +708,7 @@ void fft_block(zvx_ctx* c, void* x, int dt, int B, int Lmax, const int* len_dev,
         if (split) {
             if (w.scln) split_of((const float*)x, H, xs);                           // (SCLN blocks are never f32 + split today; kept correct)
             as_split(a, xs, H, w.p + ".w1");
-            a.out_dtype = DT_F32; a.out_split3 = 1; a.out = hs; a.o_bs = (long)Lmax * 3 * F; a.ldo = 3 * F;   // h straight into the planes of the k = 1 convolution
+            a.out_dtype = DT_F32; a.out_split3 = sp16 ? 2 : 1; a.out = hs; a.o_bs = (long)Lmax * 3 * F; a.ldo = 3 * F;   // h straight into the planes of the k = 1 convolution
         }
         c->gemm(a);
     }
@@ -655,7 +725,7 @@ void fft_block(zvx_ctx* c, void* x, int dt, int B, int Lmax, const int* len_dev,
     }
     c->timed(0, ln_bytes, [&] {
         if (w.scln) launch_layernorm(y, DT_F32, H, x, dt, H, B, Lmax, len_dev, H, 1, 1e-8f, nullptr, nullptr, w.bg + 2 * H, w.bg_bs, w.post_add, c->stream);
-        else launch_layernorm(y, DT_F32, H, x, dt, H, B, Lmax, len_dev, H, 0, 1e-5f, c->pf(w.p + ".ln2_g"), c->pf(w.p + ".ln2_b"), nullptr, 0, w.post_add, c->stream, split ? xs : nullptr);
+        else launch_layernorm(y, DT_F32, H, x, dt, H, B, Lmax, len_dev, H, 0, 1e-5f, c->pf(w.p + ".ln2_g"), c->pf(w.p + ".ln2_b"), nullptr, 0, w.post_add, c->stream, split ? xs : nullptr, sp16);
     });
     if (split && !w.scln) c->fft_xs_ready = x;                                       // the next block on the same buffer finds its input planes in fft.xs
 }
@@ -697,6 +767,7 @@ void run_encode(zvx_ctx* c, const int32_t* phoneme, const int32_t* puncts, const
                 int B, int Tmax, const float* spk, int32_t* mel_len_out, int Lmax_cap) {
     const int H = c->H;
     c->have_features = false; c->have_mel = false;
+    if (c->stream != c->front_stream) c->front_dirty_main = true;
     if (B <= 0 || Tmax <= 0) fail(ZVX_E_INVALID, "B and Tmax must be positive");
     if (c->vp_k != 3) fail(ZVX_E_UNSUPPORTED, "vp_kernel_size != 3 changes the sequence length (fs2.py:543 padding=1)");
     c->T_host.assign(T, T + B);
@@ -976,6 +1047,7 @@ void decoder_styletts(zvx_ctx* c, const float* feats, const float* spk_d, const 
 }
 
 void run_decode(zvx_ctx* c, const float* feats, const float* spk_d, const int* L_d, int B, int Lmax) {
+    if (c->stream != c->front_stream) c->front_dirty_main = true;
     c->stage_begin(ZVX_T_DECODER);
     c->tag = "decoder";
     float* mel = c->fbuf("mel", (size_t)B * std::max(Lmax, 1) * c->n_mels);
@@ -1031,6 +1103,10 @@ void run_vocoder(zvx_ctx* c, const float* mel, int ldm, int Lmel_max, const int*
 
     c->tag = "voc.pre";
     launch_mel_pad(mel, DT_F32, ldm, Lmel_max, mel_len_d, vin, dt, nm, Pmax, P_d, B, nm, c->stream);     // model.py:331-335
+    if (c->front_stream && c->stream != c->front_stream) {   // the mel buffer is free again: a queued call's decoder (front stream) may overwrite it
+        HIPCHK(hipEventRecord(c->ev_mel_free, c->stream));
+        c->mel_free_pending = true;
+    }
     {   // conv_pre, stored as leaky_relu(x, 0.1) (its only consumer, hifigan.py:115-117)
         GemmArgs a = gemm_base(dt);
         a.X = vin; a.x_bs = (long)Pmax * nm; a.ldx = nm; a.W = c->t("voc.pre_w").dev; a.ldw = nm; a.w_ts = (long)c->voc_c0 * nm;
@@ -1484,9 +1560,11 @@ zvx_status guarded(zvx_ctx* ctx, F&& f) {
         return ZVX_OK;
     } catch (const ZvxError& e) {
         ctx->err = e.what();
+        ctx->quiesce_side_streams();
         return e.code;
     } catch (const std::exception& e) {
         ctx->err = e.what();
+        ctx->quiesce_side_streams();
         return ZVX_E_INVALID;
     }
 }
@@ -1530,12 +1608,17 @@ zvx_status zvx_create(const char* manifest, const void* weights, size_t nbytes, 
 void zvx_destroy(zvx_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
+    if (c->front_stream) (void)hipStreamSynchronize(c->front_stream);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     zvx_comm_destroy(c);
     for (int i = 0; i < 2; i++) { if (c->arena[i].p) (void)hipHostFree(c->arena[i].p); if (c->arena[i].ev) (void)hipEventDestroy(c->arena[i].ev); }
     for (int i = 0; i < 2; i++) if (c->voc_aux[i]) { (void)hipStreamSynchronize(c->voc_aux[i]); (void)hipStreamDestroy(c->voc_aux[i]); }
     for (int i = 0; i < 3; i++) if (c->voc_ev[i]) (void)hipEventDestroy(c->voc_ev[i]);
     if (c->aux_stream) { (void)hipStreamSynchronize(c->aux_stream); (void)hipStreamDestroy(c->aux_stream); (void)hipEventDestroy(c->ev_aux[0]); (void)hipEventDestroy(c->ev_aux[1]); }
+    if (c->front_stream) {
+        (void)hipStreamSynchronize(c->front_stream); (void)hipStreamDestroy(c->front_stream);
+        (void)hipEventDestroy(c->ev_front_done); (void)hipEventDestroy(c->ev_mel_free); (void)hipEventDestroy(c->ev_main_join);
+    }
     for (auto& kv : c->bufs) if (kv.second.base) (void)hipFree(kv.second.base);
     for (auto e : c->event_pool) (void)hipEventDestroy(e);
     if (c->stream) {
@@ -1581,12 +1664,24 @@ zvx_status zvx_set_int(zvx_ctx* c, const char* key, int64_t value) {
         else if (std::string(key) == "va_overlap_maxb") c->va_overlap_maxb = (int)value;
         else if (std::string(key) == "voc_overlap_maxb") c->voc_overlap_maxb = (int)value;
         else if (std::string(key) == "voc_overlap_frames") c->voc_overlap_frames = (long)value;
-        else if (std::string(key) == "enc_split") c->enc_split = (c->dt == DT_BF16 && value && c->has("enc.0.wqk.s3")) ? 1 : 0;
+        else if (std::string(key) == "enc_split") {
+            if (value < 0 || value > 2) fail(ZVX_E_INVALID, "enc_split: 0 (exact f32), 1 (bf16 planes) or 2 (half planes)");
+            c->enc_split = c->dt == DT_BF16 ? (int)value : 0;
+            if (c->enc_split) { c->sync(); build_split_weights(c, c->enc_split == 2); }
+        }
+        else if (std::string(key) == "front_overlap") { c->sync(); c->front_overlap = (int)value; c->front_dirty_main = true; }
+        else if (std::string(key) == "front_prio") {
+            c->sync(); c->front_prio = (int)value; c->front_dirty_main = true; c->mel_free_pending = false;
+            if (c->front_stream) {                                           // re-created with the new priority on the next zvx_synthesize
+                (void)hipStreamDestroy(c->front_stream); c->front_stream = nullptr;
+                (void)hipEventDestroy(c->ev_front_done); (void)hipEventDestroy(c->ev_mel_free); (void)hipEventDestroy(c->ev_main_join);
+            }
+        }
         else if (std::string(key) == "rs_prof") c->rs_prof = (int)value;
         else if (std::string(key) == "rs_opt") c->rs_opt = (int)value;
         else if (std::string(key) == "rs_seg_min") c->rs_seg_min = (int)value;
-        else if (std::string(key) == "slab_small") gemm_set_slab_small((int)value);
-        else if (std::string(key) == "slab_flat") gemm_set_slab_flat((int)value);
+        else if (std::string(key) == "slab_small") c->slab_small = (int)value;
+        else if (std::string(key) == "slab_flat") c->slab_flat = (int)value;
         else if (std::string(key) == "max_frames") { if (value < 1 || value > (1 << 24)) fail(ZVX_E_INVALID, "max_frames out of range"); c->max_frames = (int)value; }
         else fail(ZVX_E_INVALID, "unknown option '%s'", key);
     });
@@ -1681,11 +1776,34 @@ zvx_status zvx_synthesize(zvx_ctx* c, const int32_t* phoneme, const int32_t* pun
                           int32_t* mel_len, float* mel_out, int Lstride, float* log_duration, int flags) {
     return guarded(c, [&] {
         if (!phoneme || !puncts || !T || !spk || !wav) fail(ZVX_E_INVALID, "zvx_synthesize: NULL input");
-        run_encode(c, phoneme, puncts, duration, T, B, Tmax, spk, mel_len, Lmax_cap);
-        if (log_duration) HIPCHK(hipMemcpyAsync(log_duration, c->fbuf("va.logd", 0), (size_t)B * Tmax * 4, hipMemcpyDeviceToHost, c->stream));
-        int* L_d = c->upload_ints("dec.L", c->mel_len_host.data(), B);
-        run_decode(c, c->fbuf("features", 0), c->fbuf("in.spk", 0), L_d, B, c->Lmax);
-        if (mel_out && c->Lmax > 0) copy_out_rows(c, c->fbuf("mel", 0), c->Lmax, c->n_mels, mel_out, Lstride, B, flags & ZVX_DEVICE_OUT);
+        auto front_end = [&] {
+            run_encode(c, phoneme, puncts, duration, T, B, Tmax, spk, mel_len, Lmax_cap);
+            if (log_duration) HIPCHK(hipMemcpyAsync(log_duration, c->fbuf("va.logd", 0), (size_t)B * Tmax * 4, hipMemcpyDeviceToHost, c->stream));
+            int* L_d = c->upload_ints("dec.L", c->mel_len_host.data(), B);
+            run_decode(c, c->fbuf("features", 0), c->fbuf("in.spk", 0), L_d, B, c->Lmax);
+            if (mel_out && c->Lmax > 0) copy_out_rows(c, c->fbuf("mel", 0), c->Lmax, c->n_mels, mel_out, Lstride, B, flags & ZVX_DEVICE_OUT);
+        };
+        if (c->front_overlap) {
+            // the front end on its own stream (see zvx_ctx::front_stream): ordered behind (1) whatever other entry points did to the
+            // front-end buffers on the main stream, (2) the previous vocoder's read of the mel buffer -- and NOT behind that vocoder
+            c->front_setup();
+            hipStream_t const main_stream = c->stream;
+            if (c->front_dirty_main) {
+                HIPCHK(hipEventRecord(c->ev_main_join, main_stream));
+                HIPCHK(hipStreamWaitEvent(c->front_stream, c->ev_main_join, 0));
+                c->front_dirty_main = false; c->mel_free_pending = false;       // (the join covers the mel read too)
+            }
+            if (c->mel_free_pending) { HIPCHK(hipStreamWaitEvent(c->front_stream, c->ev_mel_free, 0)); c->mel_free_pending = false; }
+            {
+                struct Swap { zvx_ctx* c; hipStream_t keep; ~Swap() { c->stream = keep; } } sw{c, main_stream};   // restored on every path out
+                c->stream = c->front_stream;
+                front_end();
+                HIPCHK(hipEventRecord(c->ev_front_done, c->front_stream));
+            }
+            HIPCHK(hipStreamWaitEvent(main_stream, c->ev_front_done, 0));
+        } else {
+            front_end();
+        }
         do_vocode(c, pad_to, wav, wav_stride, flags);
     });
 }
@@ -1743,6 +1861,8 @@ struct Rccl {
     decltype(&ncclGroupEnd) GroupEnd = nullptr;
     decltype(&ncclAllReduce) AllReduce = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    decltype(&ncclCommCount) CommCount = nullptr;            // optional (zvx_comm_info)
+    decltype(&ncclGetVersion) GetVersion = nullptr;
 };
 Rccl& rccl() {
     static Rccl r;
@@ -1753,6 +1873,8 @@ Rccl& rccl() {
     ZVX_SYM(GetUniqueId); ZVX_SYM(CommInitRank); ZVX_SYM(CommDestroy); ZVX_SYM(Send); ZVX_SYM(Recv); ZVX_SYM(GroupStart); ZVX_SYM(GroupEnd);
     ZVX_SYM(AllReduce); ZVX_SYM(GetErrorString);
 #undef ZVX_SYM
+    r.CommCount = (decltype(r.CommCount))dlsym(r.h, "ncclCommCount");
+    r.GetVersion = (decltype(r.GetVersion))dlsym(r.h, "ncclGetVersion");
     return r;
 }
 #define NCCLCHK(x) do { ncclResult_t r_ = (x); if (r_ != ncclSuccess) fail(ZVX_E_HIP, "%s failed: %s (%s:%d)", #x, rccl().GetErrorString(r_), __FILE__, __LINE__); } while (0)
@@ -1830,6 +1952,45 @@ zvx_status zvx_comm_max_f64(zvx_ctx* c, double* value) {
         NCCLCHK(rccl().AllReduce(d, d, 1, ncclFloat64, ncclMax, c->comm, c->comm_stream));
         HIPCHK(hipMemcpyAsync(value, d, sizeof(double), hipMemcpyDeviceToHost, c->comm_stream));
         HIPCHK(hipStreamSynchronize(c->comm_stream));
+    });
+}
+
+// Who is in the job, as seen by the communicator itself (bench.py puts it into the N > 1 JSON line so that the first multi-GPU
+// run is self-diagnosing): out[0] = world of this context, out[1] = ncclCommCount, out[2] = ncclGetVersion code,
+// out[3] = number of ranks that contributed to an all-reduce SUM of ones (a live data-path check), out[4 + r] = PCI address of
+// rank r's device ((domain << 16) | (bus << 8) | (device << 3) | function), gathered with an all-reduce MAX over per-rank slots.
+// Collective: every rank calls it.  Without a communicator (world 1, no id) only this rank's entries are filled.
+zvx_status zvx_comm_info(zvx_ctx* c, int64_t* out, int n_out) {
+    return guarded(c, [&] {
+        if (!c->comm_stream || !out) fail(ZVX_E_STATE, "zvx_comm_info: call zvx_comm_init first");
+        const int W = c->world;
+        if (n_out < 4 + W) fail(ZVX_E_BUFFER, "zvx_comm_info: need %d entries", 4 + W);
+        c->sync();
+        for (int i = 0; i < n_out; i++) out[i] = -1;
+        out[0] = W;
+        char bus[64] = {0};
+        long pci = -1;
+        if (hipDeviceGetPCIBusId(bus, sizeof bus, c->device) == hipSuccess) {
+            unsigned dom = 0, b = 0, d = 0, f = 0;
+            if (sscanf(bus, "%x:%x:%x.%x", &dom, &b, &d, &f) >= 3) pci = ((long)dom << 16) | ((long)b << 8) | ((long)d << 3) | f;
+        }
+        std::vector<double> v((size_t)W + 1, 0.0);
+        v[0] = 1.0; v[1 + c->rank] = (double)(pci + 1);          // + 1: an address of 0 still reads as "present"
+        if (c->comm) {
+            Rccl& r = rccl();
+            int n = -1, ver = -1;
+            if (r.CommCount) NCCLCHK(r.CommCount(c->comm, &n));
+            if (r.GetVersion) NCCLCHK(r.GetVersion(&ver));
+            out[1] = n; out[2] = ver;
+            double* d = (double*)c->buf("comm.info", (size_t)(W + 1) * 8);
+            HIPCHK(hipMemcpyAsync(d, v.data(), (size_t)(W + 1) * 8, hipMemcpyHostToDevice, c->comm_stream));
+            NCCLCHK(r.AllReduce(d, d, 1, ncclFloat64, ncclSum, c->comm, c->comm_stream));
+            NCCLCHK(r.AllReduce(d + 1, d + 1, W, ncclFloat64, ncclMax, c->comm, c->comm_stream));
+            HIPCHK(hipMemcpyAsync(v.data(), d, (size_t)(W + 1) * 8, hipMemcpyDeviceToHost, c->comm_stream));
+            HIPCHK(hipStreamSynchronize(c->comm_stream));
+        }
+        out[3] = (int64_t)(v[0] + 0.5);
+        for (int r = 0; r < W; r++) out[4 + r] = (int64_t)v[1 + r] - 1;
     });
 }
 

@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 
 namespace zvx {
 
@@ -11,6 +12,12 @@ typedef unsigned short bf16_t;   // raw bf16 bits
 enum DType { DT_F32 = 0, DT_BF16 = 1, DT_F16 = 2 };   // DT_F16: IEEE half activations + weights of the StyleTTS decoder (11-bit significand: 8x
                                                         // smaller rounding error than bf16 at the same MFMA rate; every value there is O(1) behind a norm)
 static inline size_t dtype_size(int dt) { return dt == DT_F32 ? 4 : 2; }
+// compute units of the current device, read once (a function-local static: initialisation is thread-safe -- several contexts may be
+// driven from several host threads)
+inline int num_cus() {
+    static const int n = [] { int dev = 0, v = 0; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256; return v; }();
+    return n;
+}
 
 enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_LRELU = 2, ACT_TANH = 3 };
 
@@ -52,8 +59,9 @@ struct GemmArgs {
     // convolution over the FLATTENED map (tap offset du * win + dv): input row g is valid iff 0 <= g < flat_rows and
     // (g % flat_win) < in_len[z] (the columns of an utterance's true width); every output row of the map is written
     int flat_win, flat_rows;
-    int xcd_flat;                                                  // conv-slab: remap over the WHOLE grid (batch x tiles), not per utterance (zvx_set_int "slab_flat")
-    int out_split3;            // f32 result written as bf16 split planes [hi | hi | lo] (row = 3 N, ldo elements apart): the input of the next 3-plane GEMM
+    int xcd_flat;                                                  // conv-slab: remap over the WHOLE grid (batch x tiles), not per utterance (zvx_set_int "slab_flat"; the context's switch)
+    int slab_small;                                                // conv-slab tile choice for single requests (zvx_set_int "slab_small"; the context's switch): 0 none, 1 small row tiles, 2 + 32-channel tiles
+    int out_split3;            // f32 result written as 16-bit split planes [hi | hi | lo] (row = 3 N, ldo elements apart): the input of the next 3-plane GEMM; 1 = bf16, 2 = IEEE half (lo x 2^11)
     // epilogue: v = alpha*acc + bias; v += res; v += accum; [accum = v]; v *= out_scale; v = act(v);
     //           v = v*post_scale[n] + post_shift[n]; out = (T)v
     float alpha;
@@ -74,8 +82,6 @@ struct GemmArgs {
 int launch_gemm(const GemmArgs& a, hipStream_t stream);
 // arm (or disarm with nullptrs) a pair of events that the NEXT launch_gemm / launch_resfuse dispatch carries as its own
 // start / stop timestamps (no marker packets on the stream)
-void gemm_set_slab_flat(int v);                                   // 1: conv-slab tile -> XCD remap over batch x tiles (every channel tile of a time tile on one XCD for any tile count)
-void gemm_set_slab_small(int v);                                  // 0: conv-slab launches keep 256-row tiles for single requests (A/B)
 void gemm_profile_events(hipEvent_t start, hipEvent_t stop);
 // the kernel variant launch_gemm / launch_resfuse would pick for these arguments (nothing is dispatched)
 int gemm_variant_of(const GemmArgs& a);
@@ -152,7 +158,8 @@ bool launch_flash_attention(const FlashArgs& a, hipStream_t stream, bool dry_run
 struct AttnF32Args {
     const float* qkv; long bs; int ld; int q_off, k_off, v_off;   // [b][L][ld] f32
     float* out; long o_bs; int ldo;                               // [b][L][ldo] f32, head h at column h*D
-    unsigned short* planes; int planes_C;                         // optional: the result also as bf16 split planes [hi | hi | lo], rows of 3 planes_C
+    unsigned short* planes; int planes_C;                         // optional: the result also as 16-bit split planes [hi | hi | lo], rows of 3 planes_C
+    int planes_f16;                                               // planes in IEEE half (lo scaled by 2^11) instead of bf16
     const int* len; int L, D, nheads, nbatch;
     float scale;
 };
@@ -166,14 +173,16 @@ void flash_profile_events(hipEvent_t start, hipEvent_t stop);
 // single requests: InstanceNorm statistics + affine + activation of a 16-bit tensor in ONE launch (bit-identical to the two-kernel path)
 void launch_instnorm_fused(const void* x, int x_dt, int ldx, void* y, int y_dt, int ldy, int B, int Lmax, const int* L, int C, float eps,
                            float* mean, float* rstd, const float* gamma, const float* beta, long g_bs, int one_plus, int act, float slope, hipStream_t s);
-void launch_transpose16(const void* in, int ld_in, void* out, int ld_out, int B, int rows, int C, hipStream_t s);
+void launch_transpose16(const void* in, int ld_in, void* out, int ld_out, int B, int rows, int C, hipStream_t s, const int* len = nullptr);   // rows >= len[b] read as zeros
 void launch_f32_to_bf16(const float* in, bf16_t* out, size_t n, hipStream_t s);
 void launch_cast(const void* in, int in_dt, void* out, int out_dt, size_t n, hipStream_t s);
 
-// f32 -> three bf16 planes [hi | hi | lo] per row (out [b][rows_max][3C]; rows >= rows[b] -> zeros) and weights
-// [nrows][K] -> [nrows][hi | lo | hi]: an f32-class GEMM as one bf16 GEMM over 3K (see ops.hip)
-void launch_split3(const float* x, int ldx, void* out, int B, int rows_max, const int* rows, int C, hipStream_t s);
-void launch_split3_weights(const float* w, void* out, long nrows, int K, hipStream_t s);
+// f32 -> three 16-bit planes [hi | hi | lo] per row (out [b][rows_max][3C]; rows >= rows[b] -> zeros) and weights
+// [nrows][K] -> [nrows][hi | lo | hi]: an f32-class GEMM as one 16-bit GEMM over 3K (see ops.hip).  f16 = 0: bf16 planes;
+// f16 = 1: IEEE-half planes, lo scaled by 2^11, weights scaled by `scale` (a power of two; third plane w * scale * 2^-11)
+void launch_split3(const float* x, int ldx, void* out, int B, int rows_max, const int* rows, int C, hipStream_t s, int f16 = 0);
+void launch_split3_weights(const float* w, void* out, long nrows, int K, hipStream_t s, int f16 = 0, float scale = 1.f);
+void launch_absmax(const float* x, size_t n, float* out /* device, 4 bytes */, hipStream_t s);
 
 // encoder front: out[b][t][:] = cat(emb[ph], pemb[pu]) + pe[t]      (fs2.py:372-392)
 void launch_embed(const int* phoneme, const int* puncts, const float* emb, int emb_dim, const float* pemb,
@@ -185,7 +194,7 @@ void launch_embed(const int* phoneme, const int* puncts, const float* emb, int e
 // post_add [B][C] (may be NULL) is added after the affine (the style-embedding add, fs2.py:740-741).
 void launch_layernorm(const void* x, int x_dt, int ldx, void* y, int y_dt, int ldy, int B, int rows_max,
                       const int* rows, int C, int mode, float eps, const float* gamma, const float* beta,
-                      const float* bg, long bg_bs, const float* post_add, hipStream_t s, void* split_planes = nullptr);
+                      const float* bg, long bg_bs, const float* post_add, hipStream_t s, void* split_planes = nullptr, int planes_f16 = 0);
 
 // scores [z][L][lds] f32 -> P (dtype) [z][L][ldp]: softmax over n < len[b]; zero-fill [len, roundup8(len))
 void launch_softmax_rows(const float* scores, int lds, void* P, int p_dt, int ldp, int nbatch, int nheads,

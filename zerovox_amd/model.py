@@ -101,7 +101,8 @@ class ZeroVox:
         manifest, blob = pack.pack_model(modelcfg, tts_sd, meldec_cfg, meldec_sd, precision)
         self._packed, self._device = (manifest, blob), parse_device(infer_device)
         self._ctx = _lib.Context(manifest, blob, self._device)
-        self._more_ctx = []                             # further contexts of the same model (synthesize_batches)
+        self._more_ctx = []                             # further contexts of the same model (synthesize_batches; release_contexts() frees them)
+        self._streaming = False                         # a synthesize_batches generator is live: self._ctx belongs to its worker threads
         self._min_mel_len = 689                         # model.py:254 -- stateful, see inference_ex
         self.hidden = self._ctx.hidden
 
@@ -177,9 +178,36 @@ class ZeroVox:
         from collections import deque
         from concurrent.futures import ThreadPoolExecutor
         n = max(1, int(in_flight))
+        if self._streaming:
+            raise RuntimeError("a synthesize_batches generator of this model is still active: its contexts are in use "
+                               "(exhaust or close() it first; a context is not re-entrant, include/zvx.h)")
         while len(self._more_ctx) < n - 1:
             self._more_ctx.append(_lib.Context(self._packed[0], self._packed[1], self._device))
         ctxs = [self._ctx] + self._more_ctx[:n - 1]
+        self._streaming = True
+        try:
+            yield from self._run_batches(ctxs, batches, n, want_mel)
+        finally:
+            self._streaming = False
+
+    def release_contexts(self):
+        """Free the extra contexts synthesize_batches created (weights + work buffers, ~0.5 GB each); the next call re-creates them."""
+        if self._streaming:
+            raise RuntimeError("a synthesize_batches generator is still active")
+        for c in self._more_ctx:
+            c.close()
+        self._more_ctx = []
+
+    def close(self):
+        """Release every context of the model (device memory, streams).  The object is unusable afterwards."""
+        self.release_contexts()
+        if self._ctx is not None:
+            self._ctx.close()
+            self._ctx = None
+
+    def _run_batches(self, ctxs, batches, n, want_mel):
+        from collections import deque
+        from concurrent.futures import ThreadPoolExecutor
 
         def run(c, kw):
             B = np.asarray(kw["phoneme"]).shape[0]
@@ -203,4 +231,6 @@ class ZeroVox:
         B = np.asarray(phoneme).shape[0]
         if pad_to is None:
             pad_to = np.full(B, 689, np.int32)
+        if self._streaming:
+            raise RuntimeError("synthesize_batch while a synthesize_batches generator is active: the context is not re-entrant")
         return self._ctx.synthesize(phoneme, puncts, T, style_embed, duration, pad_to, want_mel, Lmax_cap)
