@@ -407,6 +407,32 @@ def test_fs2_half_decoder_after_the_exact_f32_encoder_on_ragged_batches_stays_fi
         ctx.set_int("enc_split", 2)
 
 
+def test_batch_flattened_decoder_convolutions_equal_per_utterance_launches():
+    """The StyleTTS decoder's buffers keep one padding row per utterance so that its k = 3 / 1x1 convolutions run over the whole
+    batch as ONE row axis (GemmArgs::bflat: row tiles cross utterance boundaries, rows past an utterance's length are staged as
+    zeros).  Against the per-utterance launches (`dec_flat 0`): bit-identical mel and waveform for ragged batches whose utterances
+    end inside, at and just past tile boundaries, in half and in bf16; an utterance alone (never flattened) equals its batch row."""
+    ctx = ctx_for("styletts", "tiny", "bf16")
+    rng = np.random.default_rng(31)
+    try:
+        for f16 in (1, 0):
+            ctx.set_int("dec_f16", f16)
+            for Ls in ([255, 256, 257, 130, 511], [896, 129, 640, 385], [300] * 7):
+                B, Lmax = len(Ls), max(Ls)
+                feats = np.zeros((B, Lmax, 528), np.float32)
+                for b, L in enumerate(Ls):
+                    feats[b, :L] = rng.standard_normal((L, 528)).astype(np.float32)
+                spk = rng.standard_normal((B, 528)).astype(np.float32); spk /= np.linalg.norm(spk, axis=1, keepdims=True)
+                Ln = np.array(Ls, np.int32)
+                ctx.set_int("dec_flat", 0); ref = ctx.decode_features(feats, Ln, spk).copy()
+                ctx.set_int("dec_flat", 1); got = ctx.decode_features(feats, Ln, spk).copy()
+                assert np.isfinite(got).all() and np.array_equal(got, ref), (f16, Ls)
+                solo = ctx.decode_features(feats[1:2, :Ls[1]], Ln[1:2], spk[1:2])
+                assert np.array_equal(solo[0], got[1, :Ls[1]]), (f16, Ls)
+    finally:
+        ctx.set_int("dec_flat", 1); ctx.set_int("dec_f16", 1)
+
+
 def test_streaming_pair_kernel_on_a_ragged_batch_against_the_oracle():
     """pairstream.hip forced for every job size (`pairstream 3`) on a ragged HiFi-GAN V1 batch, DIRECTLY against the oracle's
     batch-1 generator calls (the bit-equality test below ties it to the two-launch path; this one does not lean on that chain)."""

@@ -629,18 +629,31 @@ __global__ __launch_bounds__(256, MINW) void convslab_kernel(const GemmArgs a) {
     }
     const int nt = wg % ntn, mt = wg / ntn;
     const int m0 = mt * BM, n0 = nt * BN;
-    const int out_len = a.out_len ? a.out_len[b] : a.M;
-    const int in_len = a.in_len ? a.in_len[b] : a.in_len_static;
+    const bool bflat = a.bflat != 0;                      // batch-flattened launch: b == 0, a.M = all rows, lengths looked up per row
+    const int out_len = bflat ? a.M : (a.out_len ? a.out_len[b] : a.M);
+    const int in_len = bflat ? 0 : (a.in_len ? a.in_len[b] : a.in_len_static);
     if (m0 >= out_len || m0 >= a.M) return;
+    if (bflat) {                                          // a tile that lies wholly in one utterance's padding rows: nothing to write
+        const int b0 = m0 / a.bflat, t0 = m0 - b0 * a.bflat;
+        if (t0 >= a.out_len[b0] && t0 + BM <= a.bflat) return;
+    }
 
     const int HL = a.halo_l, SR = BM + a.halo_l + a.halo_r;
     const int nkc = (a.K + SLAB_KC - 1) / SLAB_KC, n16 = a.K >> 4, ntaps = a.ntaps;
     const unsigned short* Xp = (const unsigned short*)a.X + (long)b * a.x_bs;
     // flattened 2-D maps (MAXH > 64 instantiations): in_len is the utterance's valid WIDTH; which of this thread's slab rows are
-    // valid positions of the map is the same for every K-chunk -> one bit per staging iteration
-    const int in_rows = (MAXH > 64 && a.flat_win) ? a.flat_rows : in_len;
+    // valid positions of the map is the same for every K-chunk -> one bit per staging iteration.  Batch-flattened 1-D launches
+    // use the same bit: row g is position g % bflat of utterance g / bflat, valid below THAT utterance's length.
+    const int in_rows = ((MAXH > 64 || bflat) && a.flat_win) ? a.flat_rows : in_len;
     unsigned rowmask = 0xffffffffu;
-    if (MAXH > 64 && a.flat_win) {
+    if (bflat) {
+        rowmask = 0;
+#pragma unroll
+        for (int it = 0; it < NIT; it++) {
+            const int g = m0 - HL + ((tid + it * 256) >> 3);
+            if (g >= 0 && g < in_rows) { const int bb = g / a.bflat; if (g - bb * a.bflat < a.in_len[bb]) rowmask |= 1u << it; }
+        }
+    } else if (MAXH > 64 && a.flat_win) {
         rowmask = 0;
 #pragma unroll
         for (int it = 0; it < NIT; it++) {
@@ -690,6 +703,10 @@ __global__ __launch_bounds__(256, MINW) void convslab_kernel(const GemmArgs a) {
         const int t32 = (n0 >> 5) + wc * TN + i;
         wq[i] = (const unsigned char*)a.Wp + (long)(t32 < nt32_total ? t32 : 0) * gtotal * 1024;
     }
+    // A wave whose channels all lie past N (N = 528 is 4.125 tiles of 128: two of the last tile's four waves) multiplies nothing:
+    // its k16 count is zero (!FULLK variants -- every N that is not a multiple of the tile width comes with such a K here).  The
+    // chip is power-limited: MFMAs on zeros are time.
+    const bool wave_dead = __builtin_amdgcn_readfirstlane((int)(n0 + wc * TN * 32 >= a.N)) != 0;
     const unsigned lane16 = lane * 16;
     u32x4 wreg[WREG ? WD : 1][TN] = {};                              // 4-step ring: slot = k16 index within the tap
     auto wload = [&](int gs, int slot) {                            // slot is a literal at every call site
@@ -740,7 +757,7 @@ __global__ __launch_bounds__(256, MINW) void convslab_kernel(const GemmArgs a) {
         }
         __syncthreads();                          // (drains this wave's DMAs too: the chunk's first D steps are in the ring)
         int nk16 = 4;
-        if (!FULLK) { nk16 = n16 - kc * 4; if (nk16 > 4) nk16 = 4; }
+        if (!FULLK) { nk16 = n16 - kc * 4; if (nk16 > 4) nk16 = 4; if (wave_dead) nk16 = 0; }
 
         // LDS reads of the main loop are inline asm: hipcc would otherwise drain every pending LDS-DMA (vmcnt(0))
         // in front of each ds_read.  Fragments of step s+1 are read while the MFMAs of step s run (sets A/B).
@@ -1527,11 +1544,20 @@ static int epi_mode_of(const GemmArgs& a) {
 // a.slab_small (zvx_set_int "slab_small", default 2): single-request tile choice: 0 none, 1 small row tiles, 2 + 32-channel tiles for one-row-tile launches
 // Both are the CONTEXT's switches (zvx_ctx::gemm fills them): no process-wide state.
 static int launch_convslab(GemmArgs a, hipStream_t stream) {
+    if (a.bflat) {
+        // batch-flattened: one row axis over all utterances (see GemmArgs::bflat); anything it does not cover runs per utterance
+        int h = 0;
+        for (int i = 0; i < a.ntaps; i++) { const int d = a.dv[i] < 0 ? -a.dv[i] : a.dv[i]; if (d > h) h = d; }
+        const bool ok = a.in_len && a.out_len && a.nbatch > 1 && a.bflat >= a.M + h && a.x_bs == (long)a.bflat * a.ldx && (!a.out || a.o_bs == (long)a.bflat * a.ldo) &&
+                        (!a.res_mode || a.r_bs == (long)a.bflat * a.ldr) && !a.accum_mode && a.bias_mode != 2 && !a.flat_win && a.M > 128 && a.N >= 128 &&
+                        (long)a.nbatch * a.bflat < (1l << 30);
+        if (!ok) a.bflat = 0;                               // (decided below, once the tile shape is known)
+    }
     const int g_slab_small = a.slab_small;                        // (name kept from when this was a process-wide static)
     int hl = 0, hr = 0;
     for (int i = 0; i < a.ntaps; i++) { hl = a.dv[i] < -hl ? -a.dv[i] : hl; hr = a.dv[i] > hr ? a.dv[i] : hr; }
     a.halo_l = hl; a.halo_r = hr;
-    if (a.flat_win) {
+    if (a.flat_win && !a.bflat) {
         // stride-1 3 x 3 convolution over flattened [H][W] maps (ResNetSE34V2.py:74-76): weights in registers for C = 32 / 64, the
         // 256 x 128 register-ring tile with a 160-row halo budget for C = 128 / 256
         if (a.N == a.K && a.N == 32 && launch_convreg_c<32, 384, 4, 1, 2>(a, stream)) return 14;      // 384 rows: 2.35x halo over-read instead of 3x, two workgroups per CU still fit
@@ -1562,6 +1588,7 @@ static int launch_convslab(GemmArgs a, hipStream_t stream) {
     // weights at the ~11 B/clk a CU sustains from HBM / Infinity Cache, so the launch is paced by how many CUs take part --
     // 32-channel tiles put four times as many on the weight stream
     if (g_slab_small >= 2 && a.M <= 64 && a.nbatch * ((a.N + 127) / 128) * 4 <= ncu && a.N >= 64 && hl + hr <= 64) {
+        a.bflat = 0;
         dim3 g32((a.N + 31) / 32, a.nbatch);
         const size_t lds32 = (((size_t)(256 + hl + hr) * SLAB_PITCH + 1023) & ~(size_t)1023) + (size_t)8 * 1024;
         launch_slab_variant<256, 32, 4, 1, 2, 8>(a, g32, lds32, stream);
@@ -1570,6 +1597,7 @@ static int launch_convslab(GemmArgs a, hipStream_t stream) {
     if (g_slab_small && a.M > 128 && a.N >= 128 && hl + hr <= 64) {
         const long wg256 = (long)((a.N + 127) / 128) * ((a.M + 255) / 256) * a.nbatch;
         if (wg256 * 2 <= ncu) {
+            a.bflat = 0;
             const bool r64 = wg256 * 4 <= ncu;
             const int bm = r64 ? 64 : 128;
             dim3 gs(((a.N + 127) / 128) * ((a.M + bm - 1) / bm), a.nbatch);
@@ -1584,6 +1612,7 @@ static int launch_convslab(GemmArgs a, hipStream_t stream) {
     // short utterances (the phoneme encoder: M <= 128 rows each): 256-row tiles would be half empty.  128-row tiles, 128 or 256
     // channels wide, whichever puts more workgroups on the chip while it is not yet full
     if (a.M <= 128 && a.N >= 128) {
+        a.bflat = 0;
         const int wide = ((a.N + 255) / 256) * a.nbatch;
         const bool narrow = wide < 2 * ncu;
         const int bn = narrow ? 128 : 256;
@@ -1610,6 +1639,15 @@ static int launch_convslab(GemmArgs a, hipStream_t stream) {
     const int ring_slots = wreg ? 0 : (best == 0 ? 4 : 8);
     const int bn = bns[best], bm = bms[best];
     const int ntn = (a.N + bn - 1) / bn;
+    if (a.bflat) {
+        // flatten when that takes a round of workgroups off the launch (two per CU are resident): 32 x 896 frames x 1056 channels are
+        // 1152 tiles per utterance (every utterance ends in a half-empty tile) against 1017 flattened -- 3 rounds against 2; where the
+        // count of rounds stays, the per-utterance launch (whose partial tiles stage and store less) is kept
+        const long slots = 2L * ncu;
+        const long wg_utt = (long)ntn * ((a.M + bm - 1) / bm) * a.nbatch, wg_flat = (long)ntn * (((long)a.nbatch * a.bflat + bm - 1) / bm);
+        if ((wg_flat + slots - 1) / slots < (wg_utt + slots - 1) / slots) { a.flat_win = a.bflat; a.flat_rows = a.nbatch * a.bflat; a.M = a.flat_rows; a.nbatch = 1; }
+        else a.bflat = 0;
+    }
     const int ntm = (a.M + bm - 1) / bm;
     dim3 grid(ntn * ntm, a.nbatch);
     const int tn = (bn >= 128) ? 2 : 1;

@@ -333,17 +333,17 @@ void launch_length_regulate(const float* x, int ldx, const int* cum, const int* 
     hipLaunchKernelGGL(k_length_regulate, dim3((Lmax + 3) / 4, B), dim3(256), 0, s, x, ldx, cum, T, mel_len, feats, Tmax, Lmax, C);
 }
 
-__global__ void k_add_pe_cast(const float* x, const float* pe, void* y, int ydt, int ldy, int Lmax, const int* L, int C) {
+__global__ void k_add_pe_cast(const float* x, const float* pe, void* y, int ydt, int ldy, int Lmax, const int* L, int C, int out_rows) {
     const int b = blockIdx.y, l = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (l >= L[b]) return;
     const float* row = x + ((long)b * Lmax + l) * C;
-    const long yo = ((long)b * Lmax + l) * ldy;
+    const long yo = ((long)b * out_rows + l) * ldy;
     for (int c = lane; c < C; c += 64) st(y, ydt, yo + c, row[c] + (pe ? pe[(long)l * C + c] : 0.f));
 }
 void launch_add_pe_cast(const float* x, const float* pe, void* y, int y_dt, int ldy, int B, int Lmax,
-                        const int* L, int C, hipStream_t s) {
+                        const int* L, int C, hipStream_t s, int out_rows_max) {
     if (Lmax <= 0) return;
-    hipLaunchKernelGGL(k_add_pe_cast, dim3((Lmax + 3) / 4, B), dim3(256), 0, s, x, pe, y, y_dt, ldy, Lmax, L, C);
+    hipLaunchKernelGGL(k_add_pe_cast, dim3((Lmax + 3) / 4, B), dim3(256), 0, s, x, pe, y, y_dt, ldy, Lmax, L, C, out_rows_max > 0 ? out_rows_max : Lmax);
 }
 
 // ---------------------------------------------------------------- per-(utterance, channel) statistics over valid rows

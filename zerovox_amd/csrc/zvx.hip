@@ -109,6 +109,7 @@ struct zvx_ctx {
                                            // results), 1 = bf16 planes (rounds 2-3: 5e-5 on the encoder output; A/B), 0 = the exact-f32 MFMA
     const void* fft_xs_ready = nullptr;     // fft.xs holds the split planes of this buffer (written by the previous FFT block's last LayerNorm)
     int norm_fuse_maxb = 1 << 20;          // zvx_set_int("norm_fuse_maxb", n): batches of at most n utterances may take the one-launch InstanceNorm of the StyleTTS decoder (0: never; A/B)
+    int dec_flat = 1;                      // zvx_set_int("dec_flat", 0): the StyleTTS decoder's convolutions per utterance instead of batch-flattened (A/B, bit-identical)
     int dec_f16 = 1;                       // zvx_set_int("dec_f16", 0): StyleTTS decoder activations / weights in bf16 instead of IEEE half (A/B)
     int use_attn_f32 = 1;                  // zvx_set_int("attn_f32", 0): the encoder's attention as V^T / score / P.V GEMMs + softmax (A/B)
     int use_flash = 1;                     // zvx_set_int("flash", 0): the decoder's attention as score GEMM + softmax + PV GEMM (A/B)
@@ -938,7 +939,10 @@ void decoder_fs2(zvx_ctx* c, const float* feats, const float* spk_d, const int* 
     c->gemm(a);
 }
 
-struct StyCtx { zvx_ctx* c; int B, Lmax; const int* L_d; float* mean; float* rstd; int dt; };   // dt: the decoder's activation dtype (bf16 / f16 / f32)
+// Lmax: rows per utterance of every buffer of the decoder = longest utterance + one padding row (never a valid position), so that
+// its k = 3 / 1x1 convolutions may run BATCH-FLATTENED (GemmArgs::bflat): row tiles cross utterance boundaries, no utterance ends in
+// a half-empty tile.  Lrows: the longest utterance.  dt: the decoder's activation dtype (bf16 / f16 / f32)
+struct StyCtx { zvx_ctx* c; int B, Lmax; const int* L_d; float* mean; float* rstd; int dt; int Lrows; int flat; const void* mel; };
 
 void sty_conv(const StyCtx& s, const std::string& wname, const void* x, int ldx, int Cin, void* out, int ldo, int out_dt,
               int Cout, const void* res, int ldr, float out_scale) {
@@ -946,12 +950,14 @@ void sty_conv(const StyCtx& s, const std::string& wname, const void* x, int ldx,
     const Tensor& w = c->t(s.dt == DT_F16 ? wname + ".h16" : wname);
     GemmArgs a = gemm_base(s.dt);
     a.X = x; a.x_bs = (long)s.Lmax * ldx; a.ldx = ldx; a.W = w.dev; a.ldw = Cin; a.w_ts = (long)Cout * Cin;
-    a.M = s.Lmax; a.N = Cout; a.K = Cin; a.nbatch = s.B; a.in_len = s.L_d; a.out_len = s.L_d;
+    a.M = s.Lrows; a.N = Cout; a.K = Cin; a.nbatch = s.B; a.in_len = s.L_d; a.out_len = s.L_d;
+    const bool to_mel = out == s.mel;                              // the mel projection writes the caller-visible [B][Lrows][n_mels] layout: per utterance
+    a.bflat = (s.flat && !to_mel) ? s.Lmax : 0;
     set_taps_1d(a, w.dim(0), 1);
     if (c->has(wname + "_b")) { a.bias = c->pf(wname + "_b"); a.bias_mode = 1; }
     if (res) { a.res = res; a.r_bs = (long)s.Lmax * ldr; a.ldr = ldr; a.res_mode = 1; a.res_dtype = s.dt; }
     a.out_scale = out_scale;
-    a.out = out; a.o_bs = (long)s.Lmax * ldo; a.ldo = ldo; a.out_dtype = out_dt;
+    a.out = out; a.o_bs = (long)(to_mel ? s.Lrows : s.Lmax) * ldo; a.ldo = ldo; a.out_dtype = out_dt;
     c->gemm(a);
 }
 // y = lrelu_0.2(affine(IN(x)))  (InstanceNorm over each utterance's true length only)
@@ -975,19 +981,20 @@ void sty_norm(const StyCtx& s, const void* x, int ldx, int C, void* y, int ldy, 
     s.c->tag = keep;
 }
 
-void decoder_styletts(zvx_ctx* c, const float* feats, const float* spk_d, const int* L_d, int B, int Lmax, float* mel) {
+void decoder_styletts(zvx_ctx* c, const float* feats, const float* spk_d, const int* L_d, int B, int Lrows, float* mel) {
     const int H = c->H, H2 = 2 * H, R = c->res_dim, CW = H2 + R;
     const int dt = (c->dt == DT_BF16 && c->dec_f16 && c->has("sty.out.h16")) ? DT_F16 : c->dt;      // 16-bit mode: IEEE half unless switched off
+    const int Lmax = Lrows + 1;                           // row stride of every buffer below (see StyCtx)
     const size_t es = dtype_size(dt), rows = (size_t)B * Lmax;
     const float inv_sqrt2 = (float)(1.0 / sqrt(2.0));
-    StyCtx s{c, B, Lmax, L_d, c->fbuf("sty.mean", (size_t)B * CW), c->fbuf("sty.rstd", (size_t)B * CW), dt};
+    StyCtx s{c, B, Lmax, L_d, c->fbuf("sty.mean", (size_t)B * CW), c->fbuf("sty.rstd", (size_t)B * CW), dt, Lrows, c->dec_flat, mel};
     void* e = c->buf("sty.e", rows * H * es);
     void* t0 = c->buf("sty.t0", rows * CW * es);
     void* t1 = c->buf("sty.t1", rows * H2 * es);
     void* r = c->buf("sty.r", rows * H2 * es);
     void* catA = c->buf("sty.catA", rows * CW * es);
     void* catB = c->buf("sty.catB", rows * CW * es);
-    launch_add_pe_cast(feats, nullptr, e, dt, H, B, Lmax, L_d, H, c->stream);
+    launch_add_pe_cast(feats, nullptr, e, dt, H, B, Lrows, L_d, H, c->stream, Lmax);
 
     // AdaIN affine vectors for all 10 norms: h = fc(s)          styletts.py:89-91
     const Tensor& aw = c->t("sty.adain_w");
@@ -1660,6 +1667,7 @@ zvx_status zvx_set_int(zvx_ctx* c, const char* key, int64_t value) {
         else if (std::string(key) == "flash") c->use_flash = (int)value;
         else if (std::string(key) == "attn_f32") c->use_attn_f32 = (int)value;
         else if (std::string(key) == "dec_f16") c->dec_f16 = (int)value;
+        else if (std::string(key) == "dec_flat") c->dec_flat = (int)value;
         else if (std::string(key) == "norm_fuse_maxb") c->norm_fuse_maxb = (int)value;
         else if (std::string(key) == "va_overlap_maxb") c->va_overlap_maxb = (int)value;
         else if (std::string(key) == "voc_overlap_maxb") c->voc_overlap_maxb = (int)value;

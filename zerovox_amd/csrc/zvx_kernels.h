@@ -59,6 +59,13 @@ struct GemmArgs {
     // convolution over the FLATTENED map (tap offset du * win + dv): input row g is valid iff 0 <= g < flat_rows and
     // (g % flat_win) < in_len[z] (the columns of an utterance's true width); every output row of the map is written
     int flat_win, flat_rows;
+    // Batch-flattened 1-D convolution (conv-slab kernel only; a HINT: every other kernel ignores it and runs the per-utterance
+    // launch the other fields describe).  The nbatch utterances lie `bflat` rows apart in X, out and res (x_bs = bflat * ldx,
+    // o_bs = bflat * ldo, r_bs = bflat * ldr) with bflat >= M + max |tap offset|, so the batch is ONE row axis of nbatch * bflat
+    // rows: row tiles run across utterance boundaries (no half-empty last tile per utterance: 896 frames are 3.5 tiles of 256),
+    // rows g with (g % bflat) >= in_len[g / bflat] are staged as zeros.  EVERY row of the flattened axis is written (rows past an
+    // utterance's length receive finite-or-not junk): every consumer of such a tensor masks by the utterance lengths on the way in.
+    int bflat;
     int xcd_flat;                                                  // conv-slab: remap over the WHOLE grid (batch x tiles), not per utterance (zvx_set_int "slab_flat"; the context's switch)
     int slab_small;                                                // conv-slab tile choice for single requests (zvx_set_int "slab_small"; the context's switch): 0 none, 1 small row tiles, 2 + 32-channel tiles
     int out_split3;            // f32 result written as 16-bit split planes [hi | hi | lo] (row = 3 N, ldo elements apart): the input of the next 3-plane GEMM; 1 = bf16, 2 = IEEE half (lo x 2^11)
@@ -217,9 +224,9 @@ void launch_durations(const int* forced, const float* logd, int* dur, int* cum, 
 // into a second output of dtype dt (decoder input): dec[b][l][:] = feats + pe[l]
 void launch_length_regulate(const float* x, int ldx, const int* cum, const int* T, const int* mel_len,
                             float* feats, int B, int Tmax, int Lmax, int C, hipStream_t s);
-// y[b][l][c] = (T)(x[b][l][c] + (pe ? pe[l][c] : 0))
+// y[b][l][c] = (T)(x[b][l][c] + (pe ? pe[l][c] : 0));  out_rows_max > 0: y's utterances lie that many rows apart (x's: Lmax)
 void launch_add_pe_cast(const float* x, const float* pe, void* y, int y_dt, int ldy, int B, int Lmax,
-                        const int* L, int C, hipStream_t s);
+                        const int* L, int C, hipStream_t s, int out_rows_max = 0);
 
 // InstanceNorm statistics over time for x [b][Lmax][ldx] channels [c0, c0+C): mean/rstd [B][C] (biased, eps)
 void launch_instnorm_stats(const void* x, int x_dt, int ldx, int B, int Lmax, const int* L, int C, float eps,
