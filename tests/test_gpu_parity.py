@@ -429,8 +429,14 @@ def test_batch_flattened_decoder_convolutions_equal_per_utterance_launches():
                 assert np.isfinite(got).all() and np.array_equal(got, ref), (f16, Ls)
                 solo = ctx.decode_features(feats[1:2, :Ls[1]], Ln[1:2], spk[1:2])
                 assert np.array_equal(solo[0], got[1, :Ls[1]]), (f16, Ls)
+                # the 1x1 shortcut of a residual block inside its last k = 3 convolution (a second source of the K loop) against the two
+                # launches: the fused form keeps conv2's result in the f32 accumulator instead of rounding it to 16 bits in between
+                ctx.set_int("dec_sc_fuse", 0); two = ctx.decode_features(feats, Ln, spk).copy(); ctx.set_int("dec_sc_fuse", 1)
+                d = max(float(np.abs(two[b, :L] - got[b, :L]).max()) for b, L in enumerate(Ls))
+                _errlog("sc-fuse", f"f16={f16}", d)
+                assert d <= (1.5e-2 if f16 else 6e-2), (f16, Ls, d)          # measured 6.5e-3 (half): one 11-bit rounding of an O(10) tensor, carried through three more blocks
     finally:
-        ctx.set_int("dec_flat", 1); ctx.set_int("dec_f16", 1)
+        ctx.set_int("dec_flat", 1); ctx.set_int("dec_f16", 1); ctx.set_int("dec_sc_fuse", 1)
 
 
 def test_streaming_pair_kernel_on_a_ragged_batch_against_the_oracle():

@@ -604,6 +604,13 @@ void launch_pack_weights(const void* w_bf16, int ntaps, int N, int K, void* out,
                        (unsigned short*)out, nkc, total);
 }
 
+void launch_pack_pair(const void* packedA, int ntapsA, int KA, const void* packedB, int ntapsB, int KB, int N, void* out, hipStream_t s) {
+    const size_t nt = (N + 31) / 32;
+    const size_t szA = (size_t)((KA + SLAB_KC - 1) / SLAB_KC) * ntapsA * 4 * 1024, szB = (size_t)((KB + SLAB_KC - 1) / SLAB_KC) * ntapsB * 4 * 1024;
+    (void)hipMemcpy2DAsync(out, szA + szB, packedA, szA, szA, nt, hipMemcpyDeviceToDevice, s);
+    (void)hipMemcpy2DAsync((char*)out + szA, szA + szB, packedB, szB, szB, nt, hipMemcpyDeviceToDevice, s);
+}
+
 // F16: the operands are IEEE half (v_mfma_f32_32x32x16_f16, same rate), the StyleTTS decoder's launches; everything else is bf16
 template <int BM, int BN, int WM, int WN, bool FULLK, int MINW, int R, int EPI = -1, int MAXH = 64, bool F16 = false>
 __global__ __launch_bounds__(256, MINW) void convslab_kernel(const GemmArgs a) {
@@ -641,6 +648,9 @@ __global__ __launch_bounds__(256, MINW) void convslab_kernel(const GemmArgs a) {
     const int HL = a.halo_l, SR = BM + a.halo_l + a.halo_r;
     const int nkc = (a.K + SLAB_KC - 1) / SLAB_KC, n16 = a.K >> 4, ntaps = a.ntaps;
     const unsigned short* Xp = (const unsigned short*)a.X + (long)b * a.x_bs;
+    // second source (GemmArgs::X2; !FULLK variants): nkc2 more chunks of ONE tap (row offset 0) behind the nkc chunks of X
+    const int nkc2 = (!FULLK && a.K2 > 0) ? (a.K2 + SLAB_KC - 1) / SLAB_KC : 0, n16_2 = a.K2 >> 4;
+    const unsigned short* Xp2 = (const unsigned short*)a.X2 + (long)b * a.x2_bs;
     // flattened 2-D maps (MAXH > 64 instantiations): in_len is the utterance's valid WIDTH; which of this thread's slab rows are
     // valid positions of the map is the same for every K-chunk -> one bit per staging iteration.  Batch-flattened 1-D launches
     // use the same bit: row g is position g % bflat of utterance g / bflat, valid below THAT utterance's length.
@@ -684,7 +694,7 @@ __global__ __launch_bounds__(256, MINW) void convslab_kernel(const GemmArgs a) {
     constexpr bool WREG = R == 0;
     constexpr int F = BN / 32, CNT = F >= 4 ? F / 4 : 1, WD = 4, D = WREG ? WD : R - 1, WAITN = WREG ? (WD - 1) * TN : (D - 2) * CNT;
     const int nt32_total = (a.N + 31) >> 5;
-    const int nsteps = a.ntaps * 4, gtotal = nkc * nsteps;
+    const int nsteps = a.ntaps * 4, gtotal = nkc * nsteps + nkc2 * 4;
     const uint4* wsrc[CNT];
 #pragma unroll
     for (int j = 0; j < CNT; j++) {
@@ -731,7 +741,10 @@ __global__ __launch_bounds__(256, MINW) void convslab_kernel(const GemmArgs a) {
         for (int s0 = 0; s0 < D; s0++) dma(s0);
     }
 
-    for (int kc = 0; kc < nkc; kc++) {
+    for (int kc = 0; kc < nkc + nkc2; kc++) {
+        const bool src2 = !FULLK && kc >= nkc;                       // wave-uniform
+        const unsigned short* const Xs = src2 ? Xp2 : Xp;
+        const int ldxs = src2 ? a.ldx2 : a.ldx, Ks = src2 ? a.K2 : a.K, kbase = (src2 ? kc - nkc : kc) * SLAB_KC;
         // ---- stage the slab: rows [m0-HL, m0+BM+HR) x 64 channels of chunk kc (FCH iterations of loads in flight, then their stores) ----
         {
             constexpr int FCH = NIT > 10 ? (NIT + 1) / 2 : NIT;      // wide-halo instantiations: two rounds (register budget)
@@ -743,9 +756,9 @@ __global__ __launch_bounds__(256, MINW) void convslab_kernel(const GemmArgs a) {
                     const int it = h0 + i;
                     const int c = tid + it * 256;
                     const int row = c >> 3, q = c & 7;
-                    const int g = m0 - HL + row, k = kc * SLAB_KC + q * 8;
+                    const int g = m0 - HL + row, k = kbase + q * 8;
                     sv[i] = make_uint4(0, 0, 0, 0);
-                    if (it < NIT && c < SR * 8 && g >= 0 && g < in_rows && k < a.K && ((rowmask >> it) & 1)) sv[i] = *(const uint4*)(Xp + (long)g * a.ldx + k);
+                    if (it < NIT && c < SR * 8 && g >= 0 && g < in_rows && k < Ks && ((rowmask >> it) & 1)) sv[i] = *(const uint4*)(Xs + (long)g * ldxs + k);
                 }
                 if (kc && h0 == 0) __syncthreads();   // (after the refill loads are in flight) every wave is done with chunk kc-1's slab
 #pragma unroll
@@ -757,13 +770,14 @@ __global__ __launch_bounds__(256, MINW) void convslab_kernel(const GemmArgs a) {
         }
         __syncthreads();                          // (drains this wave's DMAs too: the chunk's first D steps are in the ring)
         int nk16 = 4;
-        if (!FULLK) { nk16 = n16 - kc * 4; if (nk16 > 4) nk16 = 4; if (wave_dead) nk16 = 0; }
+        if (!FULLK) { nk16 = src2 ? n16_2 - (kc - nkc) * 4 : n16 - kc * 4; if (nk16 > 4) nk16 = 4; if (wave_dead) nk16 = 0; }
+        const int ntaps_kc = src2 ? 1 : ntaps;
 
         // LDS reads of the main loop are inline asm: hipcc would otherwise drain every pending LDS-DMA (vmcnt(0))
         // in front of each ds_read.  Fragments of step s+1 are read while the MFMAs of step s run (sets A/B).
         uint4 xA[TM], wA[TN], xB[TM], wB[TN];
         const unsigned ring_rd = lds_base + (unsigned)(size_t)(ring - slab) + lane * 16 + wc * TN * 1024;
-        const int gs0 = kc * nsteps;
+        const int gs0 = src2 ? nkc * nsteps + (kc - nkc) * 4 : kc * nsteps;
         auto rd = [&](uint4 (&xf)[TM], uint4 (&wf)[TN], int gs, unsigned rowoff, int kk) {
             if (!WREG) {
                 const unsigned wa = ring_rd + (gs & ((WREG ? 1 : R) - 1)) * (F * 1024);
@@ -794,12 +808,12 @@ __global__ __launch_bounds__(256, MINW) void convslab_kernel(const GemmArgs a) {
                                                                        __builtin_bit_cast(bf16x8, xf[j]), acc[i][j], 0, 0, 0);
         };
         auto rowoff_of = [&](int tap) {
-            const int d = __builtin_amdgcn_readlane(dvreg, tap < ntaps ? tap : ntaps - 1);
+            const int d = src2 ? 0 : __builtin_amdgcn_readlane(dvreg, tap < ntaps ? tap : ntaps - 1);
             return (unsigned)((xrow0 + d) * SLAB_PITCH + koff);
         };
         unsigned rowoff = rowoff_of(0);
         rd(xA, wA, gs0, rowoff, 0);
-        for (int tap = 0; tap < ntaps; tap++) {
+        for (int tap = 0; tap < ntaps_kc; tap++) {
             const unsigned rowoff_next = rowoff_of(tap + 1);
 #pragma unroll
             for (int kk = 0; kk < 4; kk++) {
@@ -1512,14 +1526,15 @@ int gemm_num_variants() { return (int)(sizeof(kVariants) / sizeof(kVariants[0]))
 
 template <int BM, int BN, int WM, int WN, int MINW, int R, int EPI = -1>
 static void launch_slab_variant(const GemmArgs& a, dim3 grid, size_t lds, hipStream_t stream) {
+    const bool fullk = a.K % SLAB_KC == 0 && a.K2 == 0;            // (a second source rides the partial-chunk variants: its K2 is any multiple of 16)
     if constexpr (EPI == -1 || EPI == ZVX_EPI(0, 0, 1)) {
         if (a.dtype == DT_F16) {                                   // half operands: the run-time epilogue and the "bias + activation -> 16 bit" one (the decoders' launches)
-            if (a.K % SLAB_KC == 0) ZVX_LAUNCH((convslab_kernel<BM, BN, WM, WN, true, MINW, R, EPI, 64, true>), grid, dim3(256), lds, stream, a);
+            if (fullk) ZVX_LAUNCH((convslab_kernel<BM, BN, WM, WN, true, MINW, R, EPI, 64, true>), grid, dim3(256), lds, stream, a);
             else ZVX_LAUNCH((convslab_kernel<BM, BN, WM, WN, false, MINW, R, EPI, 64, true>), grid, dim3(256), lds, stream, a);
             return;
         }
     }
-    if (a.K % SLAB_KC == 0) ZVX_LAUNCH((convslab_kernel<BM, BN, WM, WN, true, MINW, R, EPI>), grid, dim3(256), lds, stream, a);
+    if (fullk) ZVX_LAUNCH((convslab_kernel<BM, BN, WM, WN, true, MINW, R, EPI>), grid, dim3(256), lds, stream, a);
     else ZVX_LAUNCH((convslab_kernel<BM, BN, WM, WN, false, MINW, R, EPI>), grid, dim3(256), lds, stream, a);
 }
 
@@ -1544,6 +1559,9 @@ static int epi_mode_of(const GemmArgs& a) {
 // a.slab_small (zvx_set_int "slab_small", default 2): single-request tile choice: 0 none, 1 small row tiles, 2 + 32-channel tiles for one-row-tile launches
 // Both are the CONTEXT's switches (zvx_ctx::gemm fills them): no process-wide state.
 static int launch_convslab(GemmArgs a, hipStream_t stream) {
+    if (a.K2) {
+        if (!a.X2 || a.K2 % 16 || a.ldx2 % 8 || a.flat_win || (a.bflat && a.x2_bs != (long)a.bflat * a.ldx2)) return -5;
+    }
     if (a.bflat) {
         // batch-flattened: one row axis over all utterances (see GemmArgs::bflat); anything it does not cover runs per utterance
         int h = 0;
@@ -1553,7 +1571,7 @@ static int launch_convslab(GemmArgs a, hipStream_t stream) {
                         (long)a.nbatch * a.bflat < (1l << 30);
         if (!ok) a.bflat = 0;                               // (decided below, once the tile shape is known)
     }
-    const int g_slab_small = a.slab_small;                        // (name kept from when this was a process-wide static)
+    const int g_slab_small = a.slab_small & 7;                       // (name kept from when this was a process-wide static)
     int hl = 0, hr = 0;
     for (int i = 0; i < a.ntaps; i++) { hl = a.dv[i] < -hl ? -a.dv[i] : hl; hr = a.dv[i] > hr ? a.dv[i] : hr; }
     a.halo_l = hl; a.halo_r = hr;
@@ -1633,7 +1651,17 @@ static int launch_convslab(GemmArgs a, hipStream_t stream) {
     }
     // 1x1 convs (StyleTTS decoder) have no tap reuse of the slab: the wider channel tile halves the re-reads of the input
     // rows, and 128-row tiles divide the decoder's 896 frames exactly
-    if (a.ntaps == 1 && a.N >= 512) best = 0;
+    // ... unless the 256 x 128 tiling (batch-flattened where the caller allows it) takes a whole round of workgroups off the launch:
+    // 32 x 896 frames x 1056 channels are 1125 tiles of 128 x 256 (3 rounds on 512 slots) and 1017 of 256 x 128 (2 rounds): 0.152 -> 0.136 ms
+    if (a.ntaps == 1 && a.N >= 512) {
+        const long slots = 2L * ncu;
+        auto rounds = [&](int bm_, int bn_) {
+            const long ntn_ = (a.N + bn_ - 1) / bn_, utt = ntn_ * ((a.M + bm_ - 1) / bm_) * a.nbatch;
+            const long flat = a.bflat ? ntn_ * (((long)a.nbatch * a.bflat + bm_ - 1) / bm_) : utt;
+            return ((flat < utt ? flat : utt) + slots - 1) / slots;
+        };
+        best = rounds(256, 128) < rounds(128, 256) ? 1 : 0;
+    }
     // 256x128 / 128x256 tiles take their weights through per-wave register rings (see the kernel)
     const bool wreg = best <= 1;
     const int ring_slots = wreg ? 0 : (best == 0 ? 4 : 8);
@@ -1708,7 +1736,7 @@ int launch_gemm(const GemmArgs& a, hipStream_t stream) {
         for (int i = 0; i < a.ntaps; i++) { if (a.dv[i] < lo) lo = a.dv[i]; if (a.dv[i] > hi) hi = a.dv[i]; }
         if (hi - lo <= 64 && hi >= 0 && lo <= 0) return launch_convslab(a, stream);
     }
-    if (a.out_split3) return -2;                                // only the conv-slab epilogue (epilogue_rows) writes split planes
+    if (a.out_split3 || a.K2) return -2;                        // only the conv-slab kernel writes split planes / takes a second source
     if (a.dtype == DT_F16) return -2;                           // half operands exist on the conv-slab kernel only
     // tile choice: padded N weighted by the tile's MFMA efficiency, ties -> wider BN
     static const int bns[3] = {128, 64, 32};

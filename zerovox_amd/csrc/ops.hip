@@ -511,17 +511,35 @@ __global__ __launch_bounds__(256) void k_se_pool_partial(const void* x, int xdt,
 #pragma unroll
     for (int e = 0; e < 8; e++) acc[e] = 0.f;
     const int r0 = sblk * rows_per_blk, r1 = min(total, r0 + rows_per_blk);
-    if (rg < rpp)
+    if (rg < rpp && xdt == DT_BF16) {
+        // four rows of the thread in flight per iteration (the pass is HBM-bound: one dependent 16-byte load per iteration left
+        // most of the bandwidth idle), the column of a row tracked incrementally instead of one integer division per row
+        const unsigned short* xp = (const unsigned short*)x + base + c8 * 8;
+        int r = r0 + rg, w = r % Wmax;
+        const int step_w = rpp % Wmax;
+        for (; r < r1; r += 4 * rpp) {
+            uint4 t[4]; bool ok[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int ru = r + u * rpp;
+                ok[u] = ru < r1 && w < Wb;
+                t[u] = ok[u] ? *(const uint4*)(xp + (long)ru * C) : make_uint4(0, 0, 0, 0);
+                w += step_w; if (w >= Wmax) w -= Wmax;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {                                           // (same order of additions as the one-row loop: rows ascending)
+                if (!ok[u]) continue;
+                acc[0] += __uint_as_float(t[u].x << 16); acc[1] += __uint_as_float(t[u].x & 0xffff0000u);
+                acc[2] += __uint_as_float(t[u].y << 16); acc[3] += __uint_as_float(t[u].y & 0xffff0000u);
+                acc[4] += __uint_as_float(t[u].z << 16); acc[5] += __uint_as_float(t[u].z & 0xffff0000u);
+                acc[6] += __uint_as_float(t[u].w << 16); acc[7] += __uint_as_float(t[u].w & 0xffff0000u);
+            }
+        }
+    } else if (rg < rpp)
         for (int r = r0 + rg; r < r1; r += rpp) {
             if (r % Wmax >= Wb) continue;
             const long off = base + (long)r * C + c8 * 8;
-            if (xdt == DT_BF16) {
-                const uint4 t = *(const uint4*)((const unsigned short*)x + off);
-                acc[0] += __uint_as_float(t.x << 16); acc[1] += __uint_as_float(t.x & 0xffff0000u);
-                acc[2] += __uint_as_float(t.y << 16); acc[3] += __uint_as_float(t.y & 0xffff0000u);
-                acc[4] += __uint_as_float(t.z << 16); acc[5] += __uint_as_float(t.z & 0xffff0000u);
-                acc[6] += __uint_as_float(t.w << 16); acc[7] += __uint_as_float(t.w & 0xffff0000u);
-            } else {
+            {
                 const float4 t0 = *(const float4*)((const float*)x + off), t1 = *(const float4*)((const float*)x + off + 4);
                 acc[0] += t0.x; acc[1] += t0.y; acc[2] += t0.z; acc[3] += t0.w; acc[4] += t1.x; acc[5] += t1.y; acc[6] += t1.z; acc[7] += t1.w;
             }
@@ -820,6 +838,44 @@ void launch_se_fc(const float* partial, int S, int H, const int* W, const float*
 }
 
 // y = relu(x * scale[b][c] + res): 8 channels (16 bytes of bf16) per thread, grid-stride over the map's vectors
+// bf16 maps: a thread owns 8 channels (its scale factors stay in registers) of four positions PP = 256 / lpr apart; all eight loads are
+// in flight before the first use, 32-bit index arithmetic, one modulo per thread (the column advances incrementally)
+__global__ __launch_bounds__(256) void k_se_apply_bf16(const unsigned short* x, const unsigned short* res, unsigned short* y, const float* scale, int H, int Wmax,
+                                                       const int* W, int C, int lpr_shift) {
+    const int b = blockIdx.y, lpr = 1 << lpr_shift, PP = 256 >> lpr_shift;
+    const int total = H * Wmax, Wb = W[b];
+    const int c = (threadIdx.x & (lpr - 1)) * 8;
+    const long base = (long)b * total * C + c;
+    const float4 s0 = *(const float4*)(scale + (long)b * C + c), s1 = *(const float4*)(scale + (long)b * C + c + 4);
+    const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+    int pos = blockIdx.x * (4 * PP) + (threadIdx.x >> lpr_shift);
+    int w = pos % Wmax;
+    const int step_w = PP % Wmax;
+    uint4 a[4], r[4]; bool ok[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        const int pu = pos + u * PP;
+        ok[u] = pu < total && w < Wb;
+        const long o = base + (long)(ok[u] ? pu : 0) * C;
+        a[u] = *(const uint4*)(x + o); r[u] = *(const uint4*)(res + o);
+        w += step_w; if (w >= Wmax) w -= Wmax;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        if (!ok[u]) continue;
+        const unsigned au[4] = {a[u].x, a[u].y, a[u].z, a[u].w}, ru[4] = {r[u].x, r[u].y, r[u].z, r[u].w};
+        unsigned short ov[8];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            ov[2 * i] = tobf(fmaxf(__uint_as_float(au[i] << 16) * sc[2 * i] + __uint_as_float(ru[i] << 16), 0.f));
+            ov[2 * i + 1] = tobf(fmaxf(__uint_as_float(au[i] & 0xffff0000u) * sc[2 * i + 1] + __uint_as_float(ru[i] & 0xffff0000u), 0.f));
+        }
+        uint4 out;
+        out.x = ov[0] | ((unsigned)ov[1] << 16); out.y = ov[2] | ((unsigned)ov[3] << 16);
+        out.z = ov[4] | ((unsigned)ov[5] << 16); out.w = ov[6] | ((unsigned)ov[7] << 16);
+        *(uint4*)(y + base + (long)(pos + u * PP) * C) = out;
+    }
+}
 __global__ __launch_bounds__(256) void k_se_apply(const void* x, const void* res, void* y, int dt, const float* scale, int H, int Wmax, const int* W, int C) {
     const int b = blockIdx.y, lpr = C >> 3;
     const long nvec = (long)H * Wmax * lpr;
@@ -857,6 +913,14 @@ __global__ __launch_bounds__(256) void k_se_apply(const void* x, const void* res
 }
 void launch_se_apply(const void* x, const void* res, void* y, int dt, const float* scale, int B, int H, int Wmax,
                      const int* W, int C, hipStream_t s) {
+    const int lpr = C >> 3;
+    if (dt == DT_BF16 && lpr >= 1 && lpr <= 64 && (lpr & (lpr - 1)) == 0 && (long)H * Wmax < (1l << 30)) {
+        int sh = 0; while ((1 << sh) < lpr) sh++;
+        const int per_blk = 4 * (256 >> sh);                                        // positions per block
+        hipLaunchKernelGGL(k_se_apply_bf16, dim3((unsigned)((H * Wmax + per_blk - 1) / per_blk), B), dim3(256), 0, s, (const unsigned short*)x,
+                           (const unsigned short*)res, (unsigned short*)y, scale, H, Wmax, W, C, sh);
+        return;
+    }
     const long nvec = (long)H * Wmax * (C >> 3);
     const long blocks = (nvec + 255) / 256;
     hipLaunchKernelGGL(k_se_apply, dim3((unsigned)(blocks < 2048 ? blocks : 2048), B), dim3(256), 0, s, x, res, y, dt, scale, H, Wmax, W, C);

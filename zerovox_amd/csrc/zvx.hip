@@ -88,6 +88,7 @@ struct zvx_ctx {
     std::vector<float> host_blob;
     std::map<std::string, DevBuf> bufs;
     std::map<const void*, const void*> packed;   // bf16 weight tensor -> its MFMA-fragment-order copy (conv-slab kernel)
+    std::map<const void*, const void*> pair_packed;   // StyleTTS residual blocks with a 1x1 shortcut: conv2 weight tensor -> combined fragment stream [conv2 | shortcut] per channel tile
     int dt = DT_BF16;               // activation / weight dtype of the bf16-able stages
     // config
     int H = 0, emb_dim = 0, punct_dim = 0, n_phone_rows = 0, n_punct_rows = 0, max_txt_len = 0, max_mel_len = 0;
@@ -109,6 +110,7 @@ struct zvx_ctx {
                                            // results), 1 = bf16 planes (rounds 2-3: 5e-5 on the encoder output; A/B), 0 = the exact-f32 MFMA
     const void* fft_xs_ready = nullptr;     // fft.xs holds the split planes of this buffer (written by the previous FFT block's last LayerNorm)
     int norm_fuse_maxb = 1 << 20;          // zvx_set_int("norm_fuse_maxb", n): batches of at most n utterances may take the one-launch InstanceNorm of the StyleTTS decoder (0: never; A/B)
+    int dec_sc_fuse = 1;                   // zvx_set_int("dec_sc_fuse", 0): the 1x1 shortcut of a StyleTTS residual block as its own launch (A/B; the fused form skips one 16-bit rounding of the conv2 result)
     int dec_flat = 1;                      // zvx_set_int("dec_flat", 0): the StyleTTS decoder's convolutions per utterance instead of batch-flattened (A/B, bit-identical)
     int dec_f16 = 1;                       // zvx_set_int("dec_f16", 0): StyleTTS decoder activations / weights in bf16 instead of IEEE half (A/B)
     int use_attn_f32 = 1;                  // zvx_set_int("attn_f32", 0): the encoder's attention as V^T / score / P.V GEMMs + softmax (A/B)
@@ -233,7 +235,7 @@ struct zvx_ctx {
     void stage_end(int s) { if (profile) { HIPCHK(hipEventRecord(stage_ev[s][1], stream)); stage_used[s] = true; } }
 
     void gemm(GemmArgs& a) {
-        if (a.flops <= 0) a.flops = 2.0 * (double)a.M * a.nbatch * a.nheads * (double)a.N * (double)a.K * a.ntaps;
+        if (a.flops <= 0) a.flops = 2.0 * (double)a.M * a.nbatch * a.nheads * (double)a.N * ((double)a.K * a.ntaps + (double)a.K2);
         if (!a.Wp && a.dtype != DT_F32) { auto it = packed.find(a.W); if (it != packed.end()) a.Wp = it->second; }
         a.slab_small = slab_small; a.xcd_flat = slab_flat;
         GemmEvent ev{};
@@ -247,7 +249,7 @@ struct zvx_ctx {
             const double esz = dtype_size(a.dtype);
             // algorithmic bytes: input rows + weights + everything the epilogue reads and writes (output, residual, running sum)
             const double cells = (double)a.M * a.nbatch * a.nheads * a.N;
-            ev.bytes = ((double)a.M * a.nbatch * a.nheads) * (double)a.K * esz * (a.fused ? 1 : 1) + (double)a.N * a.K * a.ntaps * esz * (a.fused ? 2 : 1) +
+            ev.bytes = ((double)a.M * a.nbatch * a.nheads) * (double)(a.K + a.K2) * esz + (double)a.N * ((double)a.K * a.ntaps + a.K2) * esz * (a.fused ? 2 : 1) +
                        (a.out ? cells * dtype_size(a.out_dtype) : 0.0) + ((a.res_mode && !a.fused) ? cells * dtype_size(a.res_dtype) : 0.0) +
                        ((a.accum && (a.accum_mode & 1)) ? cells * dtype_size(a.accum_dtype) : 0.0) + ((a.accum && (a.accum_mode & 2)) ? cells * dtype_size(a.accum_dtype) : 0.0);
             ev.tag = tag;
@@ -494,6 +496,20 @@ void upload_weights(zvx_ctx* c) {
             c->tensors[kv.first] = t;
         }
     }
+    // StyleTTS residual blocks with a learned shortcut (styletts.py:60-68, 130-139): out = (conv2(t) + conv1x1(x)) / sqrt(2).  The
+    // shortcut runs INSIDE the k = 3 convolution as a second source of its K loop (GemmArgs::X2), which needs the two fragment
+    // streams interleaved per 32-channel tile -- built once here, for the bf16 and the half copies
+    for (const char* blk : {"sty.enc0", "sty.dec0", "sty.dec1", "sty.dec2"})
+        for (const char* sfx : {"", ".h16"}) {
+            const std::string n2 = std::string(blk) + ".c2" + sfx, ns = std::string(blk) + ".sc" + sfx;
+            if (!c->has(n2) || !c->has(ns) || c->has(std::string(blk) + ".sc_b")) continue;
+            const Tensor& t2 = c->t(n2); const Tensor& ts = c->t(ns);
+            if (t2.dims.size() != 3 || ts.dims.size() != 3 || ts.dim(0) != 1 || ts.dim(1) != t2.dim(1) || !c->packed.count(t2.dev) || !c->packed.count(ts.dev)) continue;
+            const size_t bytes = (packed_weight_elems(t2.dim(0), t2.dim(1), t2.dim(2)) + packed_weight_elems(1, ts.dim(1), ts.dim(2))) * 2;
+            void* comb = c->buf("weights_pair." + n2, bytes);
+            launch_pack_pair(c->packed[t2.dev], t2.dim(0), t2.dim(2), c->packed[ts.dev], 1, ts.dim(2), t2.dim(1), comb, c->stream);
+            c->pair_packed[t2.dev] = comb;
+        }
     // f32 FFT blocks: Q, K and V projections as ONE GEMM (fs2.py:143-145) -- [Wq; Wk; Wv] and the biases concatenated once here
     {
         std::vector<std::pair<std::string, Tensor>> add;
@@ -944,11 +960,13 @@ void decoder_fs2(zvx_ctx* c, const float* feats, const float* spk_d, const int* 
 // a half-empty tile.  Lrows: the longest utterance.  dt: the decoder's activation dtype (bf16 / f16 / f32)
 struct StyCtx { zvx_ctx* c; int B, Lmax; const int* L_d; float* mean; float* rstd; int dt; int Lrows; int flat; const void* mel; };
 
+// x2 / ldx2 / Cin2: the block's 1x1 shortcut as a second source of this convolution (the caller has checked can_fuse_shortcut)
 void sty_conv(const StyCtx& s, const std::string& wname, const void* x, int ldx, int Cin, void* out, int ldo, int out_dt,
-              int Cout, const void* res, int ldr, float out_scale) {
+              int Cout, const void* res, int ldr, float out_scale, const void* x2 = nullptr, int ldx2 = 0, int Cin2 = 0) {
     zvx_ctx* c = s.c;
     const Tensor& w = c->t(s.dt == DT_F16 ? wname + ".h16" : wname);
     GemmArgs a = gemm_base(s.dt);
+    if (x2) { a.X2 = x2; a.x2_bs = (long)s.Lmax * ldx2; a.ldx2 = ldx2; a.K2 = Cin2; a.Wp = c->pair_packed.at(w.dev); }
     a.X = x; a.x_bs = (long)s.Lmax * ldx; a.ldx = ldx; a.W = w.dev; a.ldw = Cin; a.w_ts = (long)Cout * Cin;
     a.M = s.Lrows; a.N = Cout; a.K = Cin; a.nbatch = s.B; a.in_len = s.L_d; a.out_len = s.L_d;
     const bool to_mel = out == s.mel;                              // the mel projection writes the caller-visible [B][Lrows][n_mels] layout: per utterance
@@ -1010,8 +1028,15 @@ void decoder_styletts(zvx_ctx* c, const float* feats, const float* spk_d, const 
     sty_norm(s, e, H, H, t0, H, c->pf("sty.enc0.norm1_g"), c->pf("sty.enc0.norm1_b"), 0, 0, ACT_LRELU);
     sty_conv(s, "sty.enc0.c1", t0, H, H, t1, H, dt, H, nullptr, 0, 1.f);
     sty_norm(s, t1, H, H, t0, H, c->pf("sty.enc0.norm2_g"), c->pf("sty.enc0.norm2_b"), 0, 0, ACT_LRELU);
-    sty_conv(s, "sty.enc0.c2", t0, H, H, r, H2, dt, H2, nullptr, 0, 1.f);
-    sty_conv(s, "sty.enc0.sc", e, H, H, catA, CW, dt, H2, r, H2, inv_sqrt2);
+    auto can_fuse_shortcut = [&](const std::string& blk) {
+        return c->dec_sc_fuse && dt != DT_F32 && c->has(blk + ".c2") && c->pair_packed.count(c->t(dt == DT_F16 ? blk + ".c2.h16" : blk + ".c2").dev) != 0;
+    };
+    if (can_fuse_shortcut("sty.enc0")) {
+        sty_conv(s, "sty.enc0.c2", t0, H, H, catA, CW, dt, H2, nullptr, 0, inv_sqrt2, e, H, H);       // (conv2(t) + conv1x1(e)) / sqrt(2) in one launch
+    } else {
+        sty_conv(s, "sty.enc0.c2", t0, H, H, r, H2, dt, H2, nullptr, 0, 1.f);
+        sty_conv(s, "sty.enc0.sc", e, H, H, catA, CW, dt, H2, r, H2, inv_sqrt2);
+    }
     // encode.1: ResBlk1d(2H -> 2H), identity shortcut (in place on catA[:, 0:2H])
     sty_norm(s, catA, CW, H2, t0, H2, c->pf("sty.enc1.norm1_g"), c->pf("sty.enc1.norm1_b"), 0, 0, ACT_LRELU);
     sty_conv(s, "sty.enc1.c1", t0, H2, H2, t1, H2, dt, H2, nullptr, 0, 1.f);
@@ -1041,7 +1066,9 @@ void decoder_styletts(zvx_ctx* c, const float* feats, const float* spk_d, const 
         sty_norm(s, t1, bk.cout, bk.cout, t0, bk.cout, g2, b2, NA, 1, ACT_LRELU);
         void* out; int out_ld;
         if (bk.cat_out) { out = nxtcat; out_ld = CW; } else { out = (cur == xa) ? xb : xa; out_ld = H; }
-        if (c->has(p + ".sc")) {
+        if (c->has(p + ".sc") && can_fuse_shortcut(p)) {
+            sty_conv(s, p + ".c2", t0, bk.cout, bk.cout, out, out_ld, dt, bk.cout, nullptr, 0, inv_sqrt2, cur, cur_ld, bk.cin);
+        } else if (c->has(p + ".sc")) {
             sty_conv(s, p + ".c2", t0, bk.cout, bk.cout, r, bk.cout, dt, bk.cout, nullptr, 0, 1.f);
             sty_conv(s, p + ".sc", cur, cur_ld, bk.cin, out, out_ld, dt, bk.cout, r, bk.cout, inv_sqrt2);
         } else {
@@ -1668,6 +1695,7 @@ zvx_status zvx_set_int(zvx_ctx* c, const char* key, int64_t value) {
         else if (std::string(key) == "attn_f32") c->use_attn_f32 = (int)value;
         else if (std::string(key) == "dec_f16") c->dec_f16 = (int)value;
         else if (std::string(key) == "dec_flat") c->dec_flat = (int)value;
+        else if (std::string(key) == "dec_sc_fuse") c->dec_sc_fuse = (int)value;
         else if (std::string(key) == "norm_fuse_maxb") c->norm_fuse_maxb = (int)value;
         else if (std::string(key) == "va_overlap_maxb") c->va_overlap_maxb = (int)value;
         else if (std::string(key) == "voc_overlap_maxb") c->voc_overlap_maxb = (int)value;

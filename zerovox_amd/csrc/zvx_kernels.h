@@ -66,6 +66,11 @@ struct GemmArgs {
     // rows g with (g % bflat) >= in_len[g / bflat] are staged as zeros.  EVERY row of the flattened axis is written (rows past an
     // utterance's length receive finite-or-not junk): every consumer of such a tensor masks by the utterance lengths on the way in.
     int bflat;
+    // Second source (conv-slab kernel only): out += X2 . W2^T, a 1-tap product over K2 more input channels accumulated into the SAME
+    // f32 accumulators after the K chunks of X -- a residual block's 1x1 shortcut convolution inside its last k = 3 convolution
+    // (styletts.py:60-68: (conv2(.) + conv1x1(x)) / sqrt(2)).  X2 rows map like X rows (same batch stride rule under bflat); Wp
+    // is then the COMBINED fragment stream: per 32-channel tile the fragments of W, then those of W2 (pack_weights_pair).
+    const void* X2; long x2_bs; int ldx2, K2;
     int xcd_flat;                                                  // conv-slab: remap over the WHOLE grid (batch x tiles), not per utterance (zvx_set_int "slab_flat"; the context's switch)
     int slab_small;                                                // conv-slab tile choice for single requests (zvx_set_int "slab_small"; the context's switch): 0 none, 1 small row tiles, 2 + 32-channel tiles
     int out_split3;            // f32 result written as 16-bit split planes [hi | hi | lo] (row = 3 N, ldo elements apart): the input of the next 3-plane GEMM; 1 = bf16, 2 = IEEE half (lo x 2^11)
@@ -96,6 +101,8 @@ int gemm_variant_of(const GemmArgs& a);
 int launch_resfuse(GemmArgs a, hipStream_t stream);
 // fragment-order packing of a bf16 weight [ntaps][N][K] for the conv-slab kernel
 size_t packed_weight_elems(int ntaps, int N, int K);
+// combined stream of two packed weights with the same N (GemmArgs::X2): per 32-channel tile the fragments of A, then those of B
+void launch_pack_pair(const void* packedA, int ntapsA, int KA, const void* packedB, int ntapsB, int KB, int N, void* out, hipStream_t s);
 void launch_pack_weights(const void* w_bf16, int ntaps, int N, int K, void* out, hipStream_t s);
 const char* gemm_variant_name(int id);
 int gemm_num_variants();
