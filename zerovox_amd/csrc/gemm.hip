@@ -1673,7 +1673,8 @@ static int launch_convslab(GemmArgs a, hipStream_t stream) {
         // count of rounds stays, the per-utterance launch (whose partial tiles stage and store less) is kept
         const long slots = 2L * ncu;
         const long wg_utt = (long)ntn * ((a.M + bm - 1) / bm) * a.nbatch, wg_flat = (long)ntn * (((long)a.nbatch * a.bflat + bm - 1) / bm);
-        if ((wg_flat + slots - 1) / slots < (wg_utt + slots - 1) / slots) { a.flat_win = a.bflat; a.flat_rows = a.nbatch * a.bflat; a.M = a.flat_rows; a.nbatch = 1; }
+        // (slab_small bit 4: A/B switch, flatten whenever possible)
+        if ((a.slab_small & 16) || (wg_flat + slots - 1) / slots < (wg_utt + slots - 1) / slots) { a.flat_win = a.bflat; a.flat_rows = a.nbatch * a.bflat; a.M = a.flat_rows; a.nbatch = 1; }
         else a.bflat = 0;
     }
     const int ntm = (a.M + bm - 1) / bm;

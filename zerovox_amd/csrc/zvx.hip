@@ -580,29 +580,32 @@ void read_config(zvx_ctx* c) {
 // ------------------------------------------------------------------------------------------------
 struct FftWeights { std::string p; bool scln; const float* bg; long bg_bs; const float* post_add; };
 
-void fft_block(zvx_ctx* c, void* x, int dt, int B, int Lmax, const int* len_dev, int nheads, const FftWeights& w) {
+// Ls: rows per utterance of x and of every row-major buffer below (>= Lmax).  Ls > Lmax + the k = 9 convolution's halo lets the
+// static-weight GEMMs run batch-flattened (GemmArgs::bflat; `flat`): the FS2 decoder's 896 frames are 3.5 tiles of 256 rows.
+void fft_block(zvx_ctx* c, void* x, int dt, int B, int Lmax, const int* len_dev, int nheads, const FftWeights& w, int Ls = 0, bool flat = false) {
+    if (Ls <= 0) Ls = Lmax;
     const int H = c->H, d = H / nheads, Lp = (Lmax + 7) & ~7, F = c->ffn_dim;
     const size_t es = dtype_size(dt);
     const bool h16 = dt == DT_F16;                                               // the 16-bit tensors of this block are IEEE half (weights: the ".h16" copies)
     auto wdev = [&](const char* n) { return c->t(w.p + n + (h16 ? ".h16" : "")).dev; };
-    void* qk = c->buf("fft.qk", (size_t)B * Lmax * 2 * H * es);
+    void* qk = c->buf("fft.qk", (size_t)B * Ls * 2 * H * es);
     void* vt = c->buf("fft.vt", (size_t)B * H * Lp * es);
     float* sc = c->fbuf("fft.scores", (size_t)B * nheads * Lmax * Lp);
     void* P = c->buf("fft.P", (size_t)B * nheads * Lmax * Lp * es);
-    void* o = c->buf("fft.o", (size_t)B * Lmax * H * es);
-    float* y = c->fbuf("fft.y", (size_t)B * Lmax * H);
-    void* hbuf = c->buf("fft.h", (size_t)B * Lmax * F * es);
+    void* o = c->buf("fft.o", (size_t)B * Ls * H * es);
+    float* y = c->fbuf("fft.y", (size_t)B * Ls * H);
+    void* hbuf = c->buf("fft.h", (size_t)B * Ls * F * es);
 
     // f32 blocks (phoneme encoder) in bf16 mode: the static-weight GEMMs take bf16 split planes [hi | hi | lo] of their f32 input
     // against [wh | wl | wh] weights (K = 3 x the logical K): f32-class results from the bf16 MFMA
     const bool sp16 = c->enc_split == 2;                                          // IEEE-half planes (f32-class to 2^-24) / bf16 planes (2^-17)
     const char* const s3 = sp16 ? ".s3h" : ".s3";
     const bool split = dt == DT_F32 && c->enc_split && c->has(w.p + ".wqk" + s3);
-    void* xs = split ? c->buf("fft.xs", (size_t)B * Lmax * 3 * H * 2) : nullptr;
-    auto split_of = [&](const float* src, int C, void* dst) { launch_split3(src, C, dst, B, Lmax, len_dev, C, c->stream, sp16); };
+    void* xs = split ? c->buf("fft.xs", (size_t)B * Ls * 3 * H * 2) : nullptr;
+    auto split_of = [&](const float* src, int C, void* dst) { launch_split3(src, C, dst, B, Ls, len_dev, C, c->stream, sp16); };
     auto as_split = [&](GemmArgs& a, const void* planes, int C, const std::string& wname) {      // operand swap: same GEMM, 3-plane K axis
         const Tensor& ws = c->t(wname + s3);
-        a.dtype = sp16 ? DT_F16 : DT_BF16; a.X = planes; a.x_bs = (long)Lmax * 3 * C; a.ldx = 3 * C; a.K = 3 * C;
+        a.dtype = sp16 ? DT_F16 : DT_BF16; a.X = planes; a.x_bs = (long)Ls * 3 * C; a.ldx = 3 * C; a.K = 3 * C;
         a.alpha = ws.alpha;                                                                        // half planes carry w 2^s
         a.W = ws.dev; a.ldw = 3 * C; a.w_ts = (long)ws.dim(1) * 3 * C;
         a.flops = 2.0 * (double)a.M * a.nbatch * a.N * C * a.ntaps;                                 // algorithmic (f32) work, not the 3x issued
@@ -610,8 +613,8 @@ void fft_block(zvx_ctx* c, void* x, int dt, int B, int Lmax, const int* len_dev,
     // exact-f32 blocks with merged projection weights: one Q | K | V GEMM + one fused attention launch (attention.hip)
     AttnF32Args af;
     memset(&af, 0, sizeof af);
-    af.ld = 3 * H; af.bs = (long)Lmax * 3 * H; af.q_off = 0; af.k_off = H; af.v_off = 2 * H;
-    af.out = (float*)o; af.o_bs = (long)Lmax * H; af.ldo = H; af.len = len_dev; af.L = Lmax; af.D = d; af.nheads = nheads; af.nbatch = B;
+    af.ld = 3 * H; af.bs = (long)Ls * 3 * H; af.q_off = 0; af.k_off = H; af.v_off = 2 * H;
+    af.out = (float*)o; af.o_bs = (long)Ls * H; af.ldo = H; af.len = len_dev; af.L = Lmax; af.D = d; af.nheads = nheads; af.nbatch = B;
     af.scale = (float)(1.0 / pow((double)d, 0.5));
     const bool fused_f32 = dt == DT_F32 && c->use_attn_f32 && c->has(w.p + ".wqkv") && launch_attention_f32(af, c->stream, true);
     // split planes of a GEMM input come from its PRODUCER where that is one of ours (LayerNorm, the fused attention, the k = 9
@@ -620,13 +623,13 @@ void fft_block(zvx_ctx* c, void* x, int dt, int B, int Lmax, const int* len_dev,
     if (split && !xs_from_producer) split_of((const float*)x, H, xs);
     c->fft_xs_ready = nullptr;
     if (fused_f32) {
-        float* qkv = c->fbuf("fft.qkv", (size_t)B * Lmax * 3 * H);
+        float* qkv = c->fbuf("fft.qkv", (size_t)B * Ls * 3 * H);
         GemmArgs a = gemm_base(dt);
-        a.X = x; a.x_bs = (long)Lmax * H; a.ldx = H; a.W = c->t(w.p + ".wqkv").dev; a.ldw = H;
-        a.M = Lmax; a.N = 3 * H; a.K = H; a.nbatch = B; a.in_len = len_dev; a.out_len = len_dev;
+        a.X = x; a.x_bs = (long)Ls * H; a.ldx = H; a.W = c->t(w.p + ".wqkv").dev; a.ldw = H;
+        a.M = Lmax; a.N = 3 * H; a.K = H; a.nbatch = B; a.in_len = len_dev; a.out_len = len_dev; if (flat) a.bflat = Ls;
         if (split) { as_split(a, xs, H, w.p + ".wqkv"); a.out_dtype = DT_F32; }
         a.bias = c->pf(w.p + ".bqkv"); a.bias_mode = 1;
-        a.out = qkv; a.o_bs = (long)Lmax * 3 * H; a.ldo = 3 * H;
+        a.out = qkv; a.o_bs = (long)Ls * 3 * H; a.ldo = 3 * H;
         c->gemm(a);
         af.qkv = qkv;
         if (split) { af.planes = (unsigned short*)xs; af.planes_C = H; af.planes_f16 = sp16; }   // o as split planes for the output projection
@@ -635,26 +638,26 @@ void fft_block(zvx_ctx* c, void* x, int dt, int B, int Lmax, const int* len_dev,
     if (split) split_of((const float*)x, H, xs);
     {   // [Q | K] = x Wqk^T + b                                       fs2.py:143-144
         GemmArgs a = gemm_base(dt);
-        a.X = x; a.x_bs = (long)Lmax * H; a.ldx = H; a.W = wdev(".wqk"); a.ldw = H;
-        a.M = Lmax; a.N = 2 * H; a.K = H; a.nbatch = B; a.in_len = len_dev; a.out_len = len_dev;
+        a.X = x; a.x_bs = (long)Ls * H; a.ldx = H; a.W = wdev(".wqk"); a.ldw = H;
+        a.M = Lmax; a.N = 2 * H; a.K = H; a.nbatch = B; a.in_len = len_dev; a.out_len = len_dev; if (flat) a.bflat = Ls;
         if (split) { as_split(a, xs, H, w.p + ".wqk"); a.out_dtype = DT_F32; }
         a.bias = c->pf(w.p + ".bqk"); a.bias_mode = 1;
-        a.out = qk; a.o_bs = (long)Lmax * 2 * H; a.ldo = 2 * H;
+        a.out = qk; a.o_bs = (long)Ls * 2 * H; a.ldo = 2 * H;
         c->gemm(a);
     }
     if (h16) {   // half: V = x Wv^T + b on the conv-slab kernel (static weights), then one 16-bit transpose to the key-contiguous layout
         void* vrow = hbuf;                                                       // [B][Lmax][H]: the FFN buffer is idle here
         GemmArgs a = gemm_base(dt);
-        a.X = x; a.x_bs = (long)Lmax * H; a.ldx = H; a.W = wdev(".wv"); a.ldw = H;
-        a.M = Lmax; a.N = H; a.K = H; a.nbatch = B; a.in_len = len_dev; a.out_len = len_dev;
+        a.X = x; a.x_bs = (long)Ls * H; a.ldx = H; a.W = wdev(".wv"); a.ldw = H;
+        a.M = Lmax; a.N = H; a.K = H; a.nbatch = B; a.in_len = len_dev; a.out_len = len_dev; if (flat) a.bflat = Ls;
         a.bias = c->pf(w.p + ".bv"); a.bias_mode = 1;
-        a.out = vrow; a.o_bs = (long)Lmax * H; a.ldo = H;
+        a.out = vrow; a.o_bs = (long)Ls * H; a.ldo = H;
         c->gemm(a);
-        c->timed(0, (double)B * Lmax * H * 4.0, [&] { launch_transpose16(vrow, H, vt, Lp, B, Lmax, H, c->stream, len_dev); });   // V^T columns >= len[b]: zeros (stale rows of the shared FFN buffer)
+        c->timed(0, (double)B * Lmax * H * 4.0, [&] { launch_transpose16(vrow, H, vt, Lp, B, Ls, H, c->stream, len_dev); });   // V^T columns >= len[b]: zeros (stale rows of the shared FFN buffer)
     } else
     {   // V^T[h*d + j][l] = Wv x^T + b  (stored transposed so that P.V is K-contiguous)   fs2.py:145
         GemmArgs a = gemm_base(dt);
-        a.X = c->t(w.p + ".wv").dev; a.x_bs = 0; a.ldx = H; a.W = x; a.w_bs = (long)Lmax * H; a.ldw = H;
+        a.X = c->t(w.p + ".wv").dev; a.x_bs = 0; a.ldx = H; a.W = x; a.w_bs = (long)Ls * H; a.ldw = H;
         a.M = H; a.N = Lmax; a.K = H; a.nbatch = B; a.in_len_static = H;
         a.bias = c->pf(w.p + ".bv"); a.bias_mode = 2;
         a.out = vt; a.o_bs = (long)H * Lp; a.ldo = Lp;
@@ -667,8 +670,8 @@ void fft_block(zvx_ctx* c, void* x, int dt, int B, int Lmax, const int* len_dev,
     }
     FlashArgs fa;
     memset(&fa, 0, sizeof fa);
-    fa.qk = qk; fa.qk_bs = (long)Lmax * 2 * H; fa.ldq = 2 * H; fa.k_off = H; fa.vt = vt; fa.vt_bs = (long)H * Lp; fa.ldv = Lp;
-    fa.out = o; fa.o_bs = (long)Lmax * H; fa.ldo = H; fa.len = len_dev; fa.L = Lmax; fa.D = d; fa.nheads = nheads; fa.nbatch = B;
+    fa.qk = qk; fa.qk_bs = (long)Ls * 2 * H; fa.ldq = 2 * H; fa.k_off = H; fa.vt = vt; fa.vt_bs = (long)H * Lp; fa.ldv = Lp;
+    fa.out = o; fa.o_bs = (long)Ls * H; fa.ldo = H; fa.len = len_dev; fa.L = Lmax; fa.D = d; fa.nheads = nheads; fa.nbatch = B;
     fa.scale = (float)(1.0 / pow((double)d, 0.5));
     fa.f16 = h16;
     const bool flash = (dt == DT_BF16 || h16) && c->use_flash && launch_flash_attention(fa, c->stream, true);
@@ -679,8 +682,8 @@ void fft_block(zvx_ctx* c, void* x, int dt, int B, int Lmax, const int* len_dev,
     } else {
     {   // scores = Q K^T / sqrt(d)                                    fs2.py:49-50
         GemmArgs a = gemm_base(dt);
-        a.X = qk; a.x_bs = (long)Lmax * 2 * H; a.x_hs = d; a.ldx = 2 * H;
-        a.W = (const char*)qk + (size_t)H * es; a.w_bs = (long)Lmax * 2 * H; a.w_hs = d; a.ldw = 2 * H;
+        a.X = qk; a.x_bs = (long)Ls * 2 * H; a.x_hs = d; a.ldx = 2 * H;
+        a.W = (const char*)qk + (size_t)H * es; a.w_bs = (long)Ls * 2 * H; a.w_hs = d; a.ldw = 2 * H;
         a.M = Lmax; a.N = Lmax; a.K = d; a.nbatch = B; a.nheads = nheads; a.in_len = len_dev; a.out_len = len_dev;
         a.alpha = (float)(1.0 / pow((double)d, 0.5));
         a.out = sc; a.out_dtype = DT_F32; a.o_bs = (long)nheads * Lmax * Lp; a.o_hs = (long)Lmax * Lp; a.ldo = Lp;
@@ -693,7 +696,7 @@ void fft_block(zvx_ctx* c, void* x, int dt, int B, int Lmax, const int* len_dev,
         a.X = P; a.x_bs = (long)nheads * Lmax * Lp; a.x_hs = (long)Lmax * Lp; a.ldx = Lp;
         a.W = vt; a.w_bs = (long)H * Lp; a.w_hs = (long)d * Lp; a.ldw = Lp;
         a.M = Lmax; a.N = d; a.K = Lp; a.k_len = len_dev; a.nbatch = B; a.nheads = nheads; a.in_len = len_dev; a.out_len = len_dev;
-        a.out = o; a.o_bs = (long)Lmax * H; a.o_hs = d; a.ldo = H;
+        a.out = o; a.o_bs = (long)Ls * H; a.o_hs = d; a.ldo = H;
         a.flops = 2.0 * B * nheads * (double)Lmax * Lmax * d;
         c->gemm(a);
     }
@@ -701,48 +704,48 @@ void fft_block(zvx_ctx* c, void* x, int dt, int B, int Lmax, const int* len_dev,
     }
     {   // y = fc(O) + residual                                         fs2.py:158-162
         GemmArgs a = gemm_base(dt);
-        a.X = o; a.x_bs = (long)Lmax * H; a.ldx = H; a.W = wdev(".wo"); a.ldw = H;
-        a.M = Lmax; a.N = H; a.K = H; a.nbatch = B; a.in_len = len_dev; a.out_len = len_dev;
+        a.X = o; a.x_bs = (long)Ls * H; a.ldx = H; a.W = wdev(".wo"); a.ldw = H;
+        a.M = Lmax; a.N = H; a.K = H; a.nbatch = B; a.in_len = len_dev; a.out_len = len_dev; if (flat) a.bflat = Ls;
         a.bias = c->pf(w.p + ".bo"); a.bias_mode = 1;
-        a.res = x; a.r_bs = (long)Lmax * H; a.ldr = H; a.res_mode = 1; a.res_dtype = dt;
-        a.out = y; a.out_dtype = DT_F32; a.o_bs = (long)Lmax * H; a.ldo = H;
+        a.res = x; a.r_bs = (long)Ls * H; a.ldr = H; a.res_mode = 1; a.res_dtype = dt;
+        a.out = y; a.out_dtype = DT_F32; a.o_bs = (long)Ls * H; a.ldo = H;
         if (split) { if (!fused_f32) split_of((const float*)o, H, xs); as_split(a, xs, H, w.p + ".wo"); }
         c->gemm(a);
     }
     const double ln_bytes = (double)B * Lmax * H * (4.0 + es);
     c->timed(0, ln_bytes, [&] {
-        if (w.scln) launch_layernorm(y, DT_F32, H, x, dt, H, B, Lmax, len_dev, H, 1, 1e-8f, nullptr, nullptr, w.bg, w.bg_bs, nullptr, c->stream);
-        else launch_layernorm(y, DT_F32, H, x, dt, H, B, Lmax, len_dev, H, 0, 1e-5f, c->pf(w.p + ".ln1_g"), c->pf(w.p + ".ln1_b"), nullptr, 0, nullptr, c->stream, split ? xs : nullptr, sp16);
+        if (w.scln) launch_layernorm(y, DT_F32, H, x, dt, H, B, Ls, len_dev, H, 1, 1e-8f, nullptr, nullptr, w.bg, w.bg_bs, nullptr, c->stream);
+        else launch_layernorm(y, DT_F32, H, x, dt, H, B, Ls, len_dev, H, 0, 1e-5f, c->pf(w.p + ".ln1_g"), c->pf(w.p + ".ln1_b"), nullptr, 0, nullptr, c->stream, split ? xs : nullptr, sp16);
     });
     {   // h = relu(conv_k9(x))                                         fs2.py:198-200
         GemmArgs a = gemm_base(dt);
-        a.X = x; a.x_bs = (long)Lmax * H; a.ldx = H; a.W = wdev(".w1"); a.ldw = H; a.w_ts = (long)F * H;
-        a.M = Lmax; a.N = F; a.K = H; a.nbatch = B; a.in_len = len_dev; a.out_len = len_dev;
+        a.X = x; a.x_bs = (long)Ls * H; a.ldx = H; a.W = wdev(".w1"); a.ldw = H; a.w_ts = (long)F * H;
+        a.M = Lmax; a.N = F; a.K = H; a.nbatch = B; a.in_len = len_dev; a.out_len = len_dev; if (flat) a.bflat = Ls;
         set_taps_1d(a, c->ffn_k0, 1);
         a.bias = c->pf(w.p + ".b1"); a.bias_mode = 1; a.act = ACT_RELU;
-        a.out = hbuf; a.o_bs = (long)Lmax * F; a.ldo = F;
-        void* hs = split ? c->buf("fft.hs", (size_t)B * Lmax * 3 * F * 2) : nullptr;
+        a.out = hbuf; a.o_bs = (long)Ls * F; a.ldo = F;
+        void* hs = split ? c->buf("fft.hs", (size_t)B * Ls * 3 * F * 2) : nullptr;
         if (split) {
             if (w.scln) split_of((const float*)x, H, xs);                           // (SCLN blocks are never f32 + split today; kept correct)
             as_split(a, xs, H, w.p + ".w1");
-            a.out_dtype = DT_F32; a.out_split3 = sp16 ? 2 : 1; a.out = hs; a.o_bs = (long)Lmax * 3 * F; a.ldo = 3 * F;   // h straight into the planes of the k = 1 convolution
+            a.out_dtype = DT_F32; a.out_split3 = sp16 ? 2 : 1; a.out = hs; a.o_bs = (long)Ls * 3 * F; a.ldo = 3 * F;   // h straight into the planes of the k = 1 convolution
         }
         c->gemm(a);
     }
     {   // y = conv_k1(h) + residual                                    fs2.py:201-207
         GemmArgs a = gemm_base(dt);
-        a.X = hbuf; a.x_bs = (long)Lmax * F; a.ldx = F; a.W = wdev(".w2"); a.ldw = F; a.w_ts = (long)H * F;
-        a.M = Lmax; a.N = H; a.K = F; a.nbatch = B; a.in_len = len_dev; a.out_len = len_dev;
+        a.X = hbuf; a.x_bs = (long)Ls * F; a.ldx = F; a.W = wdev(".w2"); a.ldw = F; a.w_ts = (long)H * F;
+        a.M = Lmax; a.N = H; a.K = F; a.nbatch = B; a.in_len = len_dev; a.out_len = len_dev; if (flat) a.bflat = Ls;
         set_taps_1d(a, c->ffn_k1, 1);
         a.bias = c->pf(w.p + ".b2"); a.bias_mode = 1;
-        a.res = x; a.r_bs = (long)Lmax * H; a.ldr = H; a.res_mode = 1; a.res_dtype = dt;
-        a.out = y; a.out_dtype = DT_F32; a.o_bs = (long)Lmax * H; a.ldo = H;
-        if (split) as_split(a, c->buf("fft.hs", (size_t)B * Lmax * 3 * F * 2), F, w.p + ".w2");
+        a.res = x; a.r_bs = (long)Ls * H; a.ldr = H; a.res_mode = 1; a.res_dtype = dt;
+        a.out = y; a.out_dtype = DT_F32; a.o_bs = (long)Ls * H; a.ldo = H;
+        if (split) as_split(a, c->buf("fft.hs", (size_t)B * Ls * 3 * F * 2), F, w.p + ".w2");
         c->gemm(a);
     }
     c->timed(0, ln_bytes, [&] {
-        if (w.scln) launch_layernorm(y, DT_F32, H, x, dt, H, B, Lmax, len_dev, H, 1, 1e-8f, nullptr, nullptr, w.bg + 2 * H, w.bg_bs, w.post_add, c->stream);
-        else launch_layernorm(y, DT_F32, H, x, dt, H, B, Lmax, len_dev, H, 0, 1e-5f, c->pf(w.p + ".ln2_g"), c->pf(w.p + ".ln2_b"), nullptr, 0, w.post_add, c->stream, split ? xs : nullptr, sp16);
+        if (w.scln) launch_layernorm(y, DT_F32, H, x, dt, H, B, Ls, len_dev, H, 1, 1e-8f, nullptr, nullptr, w.bg + 2 * H, w.bg_bs, w.post_add, c->stream);
+        else launch_layernorm(y, DT_F32, H, x, dt, H, B, Ls, len_dev, H, 0, 1e-5f, c->pf(w.p + ".ln2_g"), c->pf(w.p + ".ln2_b"), nullptr, 0, w.post_add, c->stream, split ? xs : nullptr, sp16);
     });
     if (split && !w.scln) c->fft_xs_ready = x;                                       // the next block on the same buffer finds its input planes in fft.xs
 }
@@ -932,8 +935,11 @@ void decoder_fs2(zvx_ctx* c, const float* feats, const float* spk_d, const int* 
         HIPCHK(hipStreamSynchronize(c->stream));
         pe = d;
     }
-    void* x = c->buf("dec.x", (size_t)B * Lmax * H * dtype_size(dt));
-    launch_add_pe_cast(feats, pe, x, dt, H, B, Lmax, L_d, H, c->stream);
+    // 16-bit mode: every utterance gets ffn_k / 2 padding rows so that the FFT blocks' static-weight GEMMs run batch-flattened (fft_block)
+    const bool flat = dt != DT_F32 && c->dec_flat && B > 1;
+    const int Ls = flat ? Lmax + std::max(c->ffn_k0, c->ffn_k1) / 2 : Lmax;
+    void* x = c->buf("dec.x", (size_t)B * Ls * H * dtype_size(dt));
+    launch_add_pe_cast(feats, pe, x, dt, H, B, Lmax, L_d, H, c->stream, Ls);
     float* bg = nullptr; long bg_bs = 0;
     if (c->dec_scln) {      // all 2*layers SCLN affine vectors of the call in one GEMM: [b | g] = W s   (fs2.py:85)
         const int NA = 2 * c->dec_layers * 2 * H;
@@ -945,10 +951,10 @@ void decoder_fs2(zvx_ctx* c, const float* feats, const float* spk_d, const int* 
     }
     for (int i = 0; i < c->dec_layers; i++) {
         FftWeights w{"dec." + std::to_string(i), c->dec_scln != 0, bg ? bg + (long)i * 4 * H : nullptr, bg_bs, nullptr};
-        fft_block(c, x, dt, B, Lmax, L_d, c->dec_heads, w);
+        fft_block(c, x, dt, B, Lmax, L_d, c->dec_heads, w, Ls, flat);
     }
     GemmArgs a = gemm_base(dt);                             // mel_linear   fs2.py:313
-    a.X = x; a.x_bs = (long)Lmax * H; a.ldx = H; a.W = c->t(dt == DT_F16 ? "dec.mel_w.h16" : "dec.mel_w").dev; a.ldw = H;
+    a.X = x; a.x_bs = (long)Ls * H; a.ldx = H; a.W = c->t(dt == DT_F16 ? "dec.mel_w.h16" : "dec.mel_w").dev; a.ldw = H;
     a.M = Lmax; a.N = c->n_mels; a.K = H; a.nbatch = B; a.in_len = L_d; a.out_len = L_d;
     a.bias = c->pf("dec.mel_b"); a.bias_mode = 1;
     a.out = mel; a.out_dtype = DT_F32; a.o_bs = (long)Lmax * c->n_mels; a.ldo = c->n_mels;
