@@ -401,7 +401,7 @@ def main(argv=None, ctx_factory=default_ctx_factory):
         step()
     # One extra untimed step with events on every launch gives the per-stage roofline split and finds the dominant kernel
     # variant; inside the timed region only that variant's launches carry events (each timed launch costs ~4 us).
-    kstats_all, tstats = [], []
+    kstats_all, tstats, stage_ms_alone = [], [], None
     if args.profile >= 2:
         fence()
         ctx.set_int("profile", 2)
@@ -412,6 +412,7 @@ def main(argv=None, ctx_factory=default_ctx_factory):
         step()
         fence()
         kstats_all, tstats = ctx.kernel_stats(), ctx.tag_stats()
+        stage_ms_alone = ctx.stage_times()            # this step ran alone on the chip (nothing queued behind it)
         if kstats_all:
             dom_name = max(kstats_all, key=lambda k: k["ms"])["name"]
             ctx.set_int("profile_only", ctx.get_int("variant_id:" + dom_name))
@@ -460,6 +461,11 @@ def main(argv=None, ctx_factory=default_ctx_factory):
             "config": {"workload": workload, **cfg_extra, **({"overrides": overrides} if overrides else {})},
             "stage_ms_last_step": stage_ms, "output_ok": ok, "src_sha16": src_sha16(),
         }
+        if stage_ms_alone is not None:
+            # stage_ms_last_step are event pairs on the stream a stage runs on: with the front end of step i+1 queued under the vocoder of
+            # step i (config.front_overlap) the encoder / decoder figures are WALL times of work that waits for free CUs most of the time;
+            # the instrumented step below ran alone and gives the stages' own durations
+            res["stage_ms_one_step_alone"] = stage_ms_alone
         if rccl_info is not None:
             res["rccl"] = rccl_info                   # ranks the communicator itself counts, RCCL version, every rank's device
         if unit == "samples/s":
@@ -497,14 +503,25 @@ def main(argv=None, ctx_factory=default_ctx_factory):
                                "launches": dom["launches"], "avg_launch_ms": avg_ms,
                                "flops_per_launch": dom["flops"] / dom["launches"],
                                "alg_bytes_per_launch": dom["bytes"] / dom["launches"],
-                               "alg_GBps": dom["bytes"] / (dom["ms"] * 1e-3) / 1e9}
+                               "alg_GBps": dom["bytes"] / (dom["ms"] * 1e-3) / 1e9,
+                               "measured": "per-launch HIP events (carried by the dispatches) of every launch of this kernel inside the timed region"}
             ser = next((k for k in kstats_all if k["name"] == dom["name"] and k["launches"]), None)
-            if ser:
-                # the same kernel in the ONE untimed, fully instrumented step that ran alone on the chip (nothing of another step beside it)
+            overlapped = args.config == 2 and not args.host_out and overrides.get("front_overlap", 1) != 0
+            if ser and overlapped:
+                # Queued steps overlap: while this kernel runs, the NEXT step's encoder / decoder launches take CUs from it, so a launch in
+                # the timed region lasts longer than the kernel needs.  The kernel's own figure is that of the untimed, fully instrumented
+                # step, which ran alone on the chip ("roofline taken from the untimed instrumented step so its frac is
+                # not stretched"); the timed region's events stay beside it.
                 ser_tf = ser["flops"] / (ser["ms"] * 1e-3) / 1e12
-                res["roofline"]["alone"] = {"achieved": ser_tf, "frac": ser_tf / peak, "launches": ser["launches"], "avg_launch_ms": ser["ms"] / ser["launches"],
-                                            "note": "per-launch events of the untimed instrumented step (serial: no other step's front end on the chip); "
-                                                    "`achieved` / `frac` above are the timed region's, where the next step's encoder / decoder share the CUs"}
+                timed = {k: res["roofline"][k] for k in ("achieved", "frac", "launches", "avg_launch_ms", "alg_GBps")}
+                timed["note"] = ("the same per-launch events inside the timed region, where the next step's front end shares the CUs with this kernel "
+                                 "(config.front_overlap); rocprofv3 --kernel-trace of this command sees these durations")
+                res["roofline"].update({"achieved": ser_tf, "frac": ser_tf / peak, "launches": ser["launches"], "avg_launch_ms": ser["ms"] / ser["launches"],
+                                        "alg_GBps": ser["bytes"] / (ser["ms"] * 1e-3) / 1e9,
+                                        "measured": "per-launch HIP events (carried by the dispatches) of this kernel's launches in the ONE untimed, fully instrumented "
+                                                    "step of this run, which ran alone on the chip; `timed_region` holds the events of the timed region "
+                                                    "(profiles/*_kernel_trace_bench_n1_serial.txt is the rocprofv3 trace that agrees with avg_launch_ms: bench.py --set front_overlap=0)",
+                                        "timed_region": timed})
             if args.in_flight > 1:
                 res["roofline"]["note"] = ("launch durations measured while the other context's launches share the CUs (two vocoders side by side "
                                            "stretch each launch): the kernel's own roofline is on the in_flight = 1 line")

@@ -3,7 +3,7 @@
 # Results land in gpurun_out/prof_<tag>/ ; copy them into profiles/ (tools/install_profiles.sh <tag>) and commit.
 #   usage: tools/refresh_profiles.sh <tag> [quick|extra]     (extra = PMC passes for the secondary workloads only: other decoder / vocoders, single requests)
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 QUICK=${2:-}
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
@@ -22,12 +22,24 @@ profile_workload() {   # <name> <bench options...>
   for C in FETCH_SIZE WRITE_SIZE; do
     rm -rf /tmp/pm_$C; timeout 600 rocprofv3 --pmc $C -d /tmp/pm_$C -o pm -- $CMD > /dev/null 2>&1
     python $ROOT/tools/rocpd_summary.py $(find /tmp/pm_$C -name "*.db" | head -1) --pmc > $OUT/pmc_${C}_$NAME.txt
+    # per launch shape (kernel + grid): which convolutions of the step carry a variant's traffic
+    python $ROOT/tools/rocpd_summary.py $(find /tmp/pm_$C -name "*.db" | head -1) --pmc-grids > $OUT/pmc_${C}_by_grid_$NAME.txt
   done
   rm -rf /tmp/pm_m; timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES -d /tmp/pm_m -o pm -- $CMD > /dev/null 2>&1
   python $ROOT/tools/rocpd_summary.py $(find /tmp/pm_m -name "*.db" | head -1) --pmc > $OUT/pmc_mfma_$NAME.txt
   local TJ=traffic.json; [ "$NAME" != "bench_n1" ] && TJ=traffic_$NAME.json
   python $ROOT/tools/make_traffic_json.py $(find /tmp/pm_FETCH_SIZE -name "*.db" | head -1) $(find /tmp/pm_WRITE_SIZE -name "*.db" | head -1) $OUT/$TJ "$OPTS" $(find /tmp/pm_m -name "*.db" | head -1) > $OUT/traffic_json_$NAME.log 2>&1
   cp $OUT/$TJ $ROOT/profiles/$TJ          # the bench line below quotes it (same sources, same workload)
+}
+
+# kernel trace only (no PMC passes): the serial schedule of the headline, whose per-launch durations are the kernels' own
+trace_only() {   # <name> <bench options...>
+  local NAME=$1; shift
+  local CMD="python $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline $*"
+  rm -rf /tmp/kt; timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -o kt -- $CMD > /dev/null 2>&1
+  cp $(find /tmp/kt -name "*kernel_stats.csv" | head -1) $OUT/rocprofv3_kernel_stats_$NAME.csv
+  rm -rf /tmp/kt2; timeout 600 rocprofv3 --kernel-trace -d /tmp/kt2 -o kt -- $CMD > /dev/null 2>&1
+  python $ROOT/tools/rocpd_summary.py $(find /tmp/kt2 -name "*.db" | head -1) > $OUT/kernel_trace_$NAME.txt
 }
 
 if [ "$QUICK" = "extra" ]; then
@@ -45,9 +57,12 @@ if [ "$QUICK" = "extra" ]; then
   exit 0
 fi
 profile_workload bench_n1
+trace_only bench_n1_serial --set front_overlap=0
 python $ROOT/bench.py > $OUT/bench_n1.json 2> $OUT/bench_n1.err
 python $ROOT/bench.py --exact-encoder --no-cpu-baseline > $OUT/bench_n1_exact_encoder.json 2> $OUT/bench_n1_exact_encoder.err
 python $ROOT/bench.py --host-out --no-cpu-baseline > $OUT/bench_n1_host_out.json 2> $OUT/bench_n1_host_out.err
+python $ROOT/bench.py --set front_overlap=0 --no-cpu-baseline > $OUT/bench_n1_serial.json 2> $OUT/bench_n1_serial.err                 # A/B: every call's front end behind the previous vocoder
+python $ROOT/bench.py --set enc_split=1 --no-cpu-baseline > $OUT/bench_n1_bf16_planes.json 2> $OUT/bench_n1_bf16_planes.err          # A/B: the encoder's split products on bf16 planes (rounds 2-3)
 python $ROOT/bench.py --in-flight 2 --no-cpu-baseline > $OUT/bench_n1_in_flight2.json 2> $OUT/bench_n1_in_flight2.err
 if [ -z "$QUICK" ]; then
   profile_workload cfg4 --config 4

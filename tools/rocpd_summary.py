@@ -38,6 +38,19 @@ def pmc_summary(path):
     return rows
 
 
+def pmc_by_grid(path, top=40):
+    """Per (kernel, grid) averages of every counter: attributes a variant's traffic to the individual launch shapes of a step
+    (`--pmc-grids`; a launch shape = one convolution of the model here: same kernel + same grid)."""
+    db = sqlite3.connect(path)
+    cur = db.cursor()
+    rows = cur.execute("select kernel_name, grid_size_x, grid_size_y, counter_name, count(*), sum(value), avg(value), avg(duration) from counters_collection "
+                       "group by kernel_name, grid_size_x, grid_size_y, counter_name order by sum(value) desc").fetchall()
+    print(f"{'launches':>8} {'sum':>16} {'avg/launch':>14} {'avg_us':>9}  counter  grid  kernel")
+    for kn, gx, gy, cn, n, sm, av, du in rows[:top]:
+        if sm and sm > 0:
+            print(f"{n:8d} {sm:16.1f} {av:14.2f} {du / 1e3:9.2f}  {cn:14s} ({gx},{gy})  {kn[:100]}")
+
+
 def timeline(path, n):
     """The last n dispatches in start order: offset from the first of them, duration, gap to the latest end before it, queue."""
     db = sqlite3.connect(path)
@@ -57,6 +70,8 @@ def timeline(path, n):
 if __name__ == "__main__":
     if "--timeline" in sys.argv:
         timeline(sys.argv[1], sys.argv[sys.argv.index("--timeline") + 1])
+    elif "--pmc-grids" in sys.argv:
+        pmc_by_grid(sys.argv[1])
     elif "--pmc" in sys.argv:
         pmc_summary(sys.argv[1])
     else:

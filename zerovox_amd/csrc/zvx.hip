@@ -69,7 +69,8 @@ struct zvx_ctx {
     // next call's front end waits for ev_mel_free (recorded behind the vocoder's first kernel, which copies the mel into its padded
     // input).  A host that queues calls (ZVX_DEVICE_OUT | ZVX_NO_SYNC) gets the latency-paced front end (5-28 % of the matrix roof)
     // hidden under the previous call's vocoder; a host that waits for every call sees the serial schedule.  Results are bit-identical
-    // (same kernels on the same data).  zvx_set_int("front_overlap", 0): everything on `stream` (A/B).
+    // (same kernels on the same data).  zvx_set_int("front_overlap", v): 1 (default) = queued calls (ZVX_DEVICE_OUT | ZVX_NO_SYNC) take the
+    // two-stream schedule, 2 = every zvx_synthesize call does (tests), 0 = everything on `stream` (A/B).
     hipStream_t front_stream = nullptr;
     hipEvent_t ev_front_done = nullptr, ev_mel_free = nullptr, ev_main_join = nullptr;
     int front_overlap = 1;
@@ -1825,7 +1826,9 @@ zvx_status zvx_synthesize(zvx_ctx* c, const int32_t* phoneme, const int32_t* pun
             run_decode(c, c->fbuf("features", 0), c->fbuf("in.spk", 0), L_d, B, c->Lmax);
             if (mel_out && c->Lmax > 0) copy_out_rows(c, c->fbuf("mel", 0), c->Lmax, c->n_mels, mel_out, Lstride, B, flags & ZVX_DEVICE_OUT);
         };
-        if (c->front_overlap) {
+        // a call that waits for its own result (no ZVX_NO_SYNC) has nothing to overlap with: it stays on the one stream (two streams
+        // cost an event round trip, which a single short request would see); front_overlap 2 forces the two-stream schedule (tests)
+        if (c->front_overlap == 2 || (c->front_overlap == 1 && (flags & ZVX_NO_SYNC) && (flags & ZVX_DEVICE_OUT))) {
             // the front end on its own stream (see zvx_ctx::front_stream): ordered behind (1) whatever other entry points did to the
             // front-end buffers on the main stream, (2) the previous vocoder's read of the mel buffer -- and NOT behind that vocoder
             c->front_setup();
