@@ -961,6 +961,9 @@ def test_rccl_gather_path_on_a_one_rank_communicator():
         got = ctx.dev_to_host(recv_d, (3, N), np.float32)
         assert np.array_equal(got, ref)
         assert ctx.comm_max(1.25) == 1.25
+        info = ctx.comm_info()                                               # what bench.py puts into the N > 1 line ("rccl": {...})
+        assert info["world"] == 1 and info["comm_count"] == 1 and info["ranks_seen"] == 1 and info["version_code"] > 20000, info
+        assert info["device_pci"][0] is not None and ":" in info["device_pci"][0], info
         ctx.dev_free(wav_d); ctx.dev_free(recv_d)
     finally:
         ctx.close()
