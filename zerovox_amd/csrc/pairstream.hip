@@ -53,6 +53,11 @@ namespace zvx {
 #ifndef PS_RPF
 #define PS_RPF 1          // conv2: residual / running-sum rows of a block are requested before its main loop (not in its epilogue)
 #endif
+#ifndef PS_DMA_TAIL
+#define PS_DMA_TAIL 1     // conv1: the X rows of the next block are requested AFTER the block's main loop (in front of its T epilogue, which covers
+#endif                    // their latency) instead of between its MFMA steps.  The vector-memory counter retires in order: with the requests
+                          // inside the loop, every counted wait for a weight fragment also waited for the DMA requests issued before it -- an HBM
+                          // round trip per loop iteration (tools/micro: k = 3 conv1 main loop 660 k -> 319 k cycles without them)
 #ifdef PS_PROFILE
 #define PS_STAMP(k) do { const unsigned long long t_ = __builtin_readcyclecounter(); tacc[k] += t_ - tlast; tlast = t_; } while (0)
 #else
@@ -65,8 +70,8 @@ __device__ __forceinline__ void ps_role(const PairArgs& a, unsigned char* lds, c
     constexpr int R = PS_R, H2 = (NT - 1) / 2, NS = 8 * NT, WD = PS_WD;
     // DMA instructions per loop iteration: a fixed number (vmcnt counts stay uniform), enough for the real pieces to be issued
     // BEFORE the last iteration (whose waits then retire them: the rows are in LDS when the step's barrier is reached)
-    constexpr int EPI = ROLE == 0 ? (PS_NDMA + NT - 2) / (NT - 1) : 0;
-    static_assert(ROLE == 1 || EPI * (NT - 1) >= PS_NDMA, "DMA slots");
+    constexpr int EPI = (ROLE == 0 && !PS_DMA_TAIL) ? (PS_NDMA + NT - 2) / (NT - 1) : 0;
+    static_assert(ROLE == 1 || PS_DMA_TAIL || EPI * (NT - 1) >= PS_NDMA, "DMA slots");
     const int l32 = lane & 31, hi = lane >> 5;
     const int dil = a.dil, H1 = dil * H2, DX = a.DX, DT = a.DT, G0 = a.G0;
     // LDS byte addresses are used raw: the dynamic region starts at 0 (no static __shared__ in this kernel)
@@ -187,7 +192,7 @@ __device__ __forceinline__ void ps_role(const PairArgs& a, unsigned char* lds, c
             constexpr int PD = PS_PD;
             static_assert(PD == 1 || PD == 2, "prefetch distance");
             uint4 xs[4][4];                                                    // fragment sets: step i uses set i & 3
-            const i32x4 rsd = dma_rsrc(gx, dma_real);
+            const i32x4 rsd = PS_DMA_TAIL ? (i32x4){0, 0, 0, 0} : dma_rsrc(gx, dma_real);
             bases_common(0);
 #pragma unroll
             for (int j = 0; j < 4; j++) bases_tile(j, bs);
@@ -221,7 +226,7 @@ __device__ __forceinline__ void ps_role(const PairArgs& a, unsigned char* lds, c
                             if (kk == 1) bases_tile(j, nbs);
                             if (j == 3) {
                                 if (!(PS_EXP & 1)) wload(next_off + i * 1024, i);          // the slot just consumed takes the fragment 8 steps on
-                                if (ROLE == 0 && !(PS_EXP & 8)) {
+                                if (ROLE == 0 && !PS_DMA_TAIL && !(PS_EXP & 8)) {
                                     // this iteration's DMA instructions, spread over its steps (pieces past PS_NDMA: surplus, zero-fill the scratch KiB).
                                     // ALL of them are issued before step 7: that step's wait then leaves exactly this iteration's 7 + EPI
                                     // requests outstanding, so after the last iteration every real piece (issued earlier) has landed.
@@ -380,7 +385,12 @@ __device__ __forceinline__ void ps_role(const PairArgs& a, unsigned char* lds, c
         for (int s = 0; s <= nb + 1; s++) {
             if (ROLE == 0) {
                 if (s < nb) {
-                    main_loop(s + 1 < nb);                                     // fetches the X rows of block s + 1 on the way
+                    main_loop(s + 1 < nb);                                     // (PS_DMA_TAIL 0: fetches the X rows of block s + 1 on the way)
+                    if (PS_DMA_TAIL && !(PS_EXP & 8) && s + 1 < nb) {          // the X rows of block s + 1: this wave's 8 pieces of 4 rows, landed by the step barrier
+                        const i32x4 rsd = dma_rsrc(gx, true);
+#pragma unroll
+                        for (int pc = 0; pc < PS_NDMA; pc++) dma_piece(rsd, gx, x_wr, ct * PS_NDMA + pc, true);
+                    }
                     PS_STAMP(0);
                     gx += R; x_wr += R; if (x_wr >= DX) x_wr -= DX;
                     if (PS_PRIO & 2) __builtin_amdgcn_s_setprio(2);
@@ -414,6 +424,7 @@ __device__ __forceinline__ void ps_role(const PairArgs& a, unsigned char* lds, c
                     PS_STAMP(0);
                 }
             }
+            if (PS_DMA_TAIL && ROLE == 0 && s < nb) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this step's DMA pieces (and the ring's first fragments of the next block) have landed
             if (s <= nb) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
             PS_STAMP(2);
         }
