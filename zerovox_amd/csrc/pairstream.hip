@@ -51,8 +51,8 @@ namespace zvx {
 #define PS_RES_LDS 1      // conv2's residual rows come from the X ring (read one step before the block's main loop, while they are still there)
 #endif                    // instead of a second trip to global memory
 #ifndef PS_RPF
-#define PS_RPF 1          // conv2: residual / running-sum rows of a block are requested before its main loop (not in its epilogue)
-#endif
+#define PS_RPF 2          // conv2: the running-sum rows of a block are requested 2: right BEHIND its main loop (a step before its epilogue; round 4),
+#endif                    // 1: before its main loop (round 3: the loop's first counted weight wait then also waits for them -- in-order retirement), 0: in its epilogue
 #ifndef PS_DMA_TAIL
 #define PS_DMA_TAIL 1     // conv1: the X rows of the next block are requested AFTER the block's main loop (in front of its T epilogue, which covers
 #endif                    // their latency) instead of between its MFMA steps.  The vector-memory counter retires in order: with the requests
@@ -418,8 +418,9 @@ __device__ __forceinline__ void ps_role(const PairArgs& a, unsigned char* lds, c
                     residual_reads(s);                                         // block s: its epilogue is two steps away
                 }
                 if (s >= 1 && s <= nb) {
-                    if (PS_RPF) epilogue_loads(g2);                            // rows of THIS block: in registers long before its epilogue (next step)
+                    if (PS_RPF == 1) epilogue_loads(g2);                       // rows of THIS block: in registers long before its epilogue (next step)
                     main_loop(false);
+                    if (PS_RPF == 2) epilogue_loads(g2);                       // ... requested here: the step barrier and the partner's MFMAs cover their latency
                     t_rd += R; if (t_rd >= DT) t_rd -= DT;
                     PS_STAMP(0);
                 }
