@@ -64,7 +64,10 @@ const char* zvx_last_error(const zvx_ctx* ctx);
 int64_t    zvx_get_int(const zvx_ctx* ctx, const char* key);
 /* "profile" 0/1/2 (0 off, 1 per-stage events, 2 + per-GEMM-launch events); "profile_only" variant id (-1 = all);
  * "shape_log" 0/1 (one stderr line per timed launch); "max_frames" hard cap on a predicted mel length (default 2^18:
- * the reference has none, fs2.py:678-681 -- a garbage log-duration must not drive an allocation -> ZVX_E_BUFFER) */
+ * the reference has none, fs2.py:678-681 -- a garbage log-duration must not drive an allocation -> ZVX_E_BUFFER).
+ * Every other key is an A/B switch of a scheduling / tiling / arithmetic choice (INTEGRATION.md has the table: "enc_split",
+ * "front_overlap", "front_prio", "dec_flat", "dec_sc_fuse", "dec_f16", "pairstream", "resstream", "slab_small", "slab_flat", ...);
+ * all of them live in the context.  Unknown keys: ZVX_E_INVALID. */
 zvx_status zvx_set_int(zvx_ctx* ctx, const char* key, int64_t value);
 
 /* Speaker encoder: ref_mels [B][Tmax][80] log-mels, lens[B] frames -> out [B][hidden], L2-normalised.
@@ -117,6 +120,10 @@ zvx_status zvx_vocode_mel(zvx_ctx* ctx, const float* mel, const int32_t* P, int 
  * QUEUES work on the context's stream and returns (the host inputs are copied into pinned staging before it returns and may be
  * reused at once; mel_len is filled from the durations): successive calls keep the GPU fed whatever the host thread's timing.
  * With predicted durations the call waits once, for the predicted mel lengths.
+ * Queued calls overlap (round 4): the context issues encoder / variance adaptor / mel decoder on its front stream and the vocoder on
+ * its main stream; call i + 1's front end waits only for call i's vocoder to have copied the mel, so it runs UNDER that vocoder
+ * (23.1 -> 21.2 ms per 32 x 128-phoneme batch on one context; bit-identical to the serial schedule; zvx_set_int "front_overlap").
+ * A device mel output (mel_out with ZVX_DEVICE_OUT) is written on the front stream; zvx_sync drains every stream.
  * Replaces ZeroVox.inference_ex (model.py:308-347) over B independent utterances. */
 zvx_status zvx_synthesize(zvx_ctx* ctx, const int32_t* phoneme, const int32_t* puncts, const int32_t* duration,
                           const int32_t* T, int B, int Tmax, const float* spk, const int32_t* pad_to,
