@@ -241,7 +241,7 @@ def _cpu_baseline_onednn(config, T, decoder, vocoder, cores, unit):
     in a child process (this process holds the HIP runtime of libzvx; torch brings its own).  The child first checks the port against
     the plain NumPy oracle on a small case."""
     import subprocess
-    units = {2: 3, 4: 3, 5: 40}[config]
+    units = {2: 8, 4: 6, 5: 80}[config]                   # ~10 s of CPU work on 16 threads
     try:
         out = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "oracle", "onednn_port.py"), str(config),
                               decoder, vocoder, str(cores), str(units), str(T)],

@@ -1,9 +1,11 @@
 """CPU ORACLE -- TEST INFRASTRUCTURE ONLY (bench.py's `cpu_baseline` leg runs this file in a child process; nothing else does).
 
-The NumPy oracle (`oracle/zvx_oracle.py`) with its three convolution primitives evaluated by torch / oneDNN on the host cores --
-the library the reference itself runs on a CPU (zerovox/tts/hifigan.py, styletts.py, fs2.py build their layers from torch.nn.Conv1d /
-ConvTranspose1d / Conv2d).  Everything else (normalisations, attention, length regulation, control flow) stays the NumPy
-restatement.  This is the CPU baseline that is comparable to the reference's own CPU path; the plain NumPy oracle's im2col + sgemm
+The NumPy oracle (`oracle/zvx_oracle.py`) with its three convolution primitives and its leaky-ReLU evaluated by torch / oneDNN on the
+host cores -- the library the reference itself runs on a CPU (zerovox/tts/hifigan.py, styletts.py, fs2.py build their layers from
+torch.nn.Conv1d / ConvTranspose1d / Conv2d and F.leaky_relu) -- and with HiFi-GAN's weight norm folded once before the clock starts, as
+the reference's `remove_weight_norm()` does at load (round 4: the NumPy `np.where` activation and the per-call fold were 60 % of the
+port's time and are not what a CPU has to pay).  Everything else (normalisations, attention, length regulation, control flow) stays
+the NumPy restatement.  This is the CPU baseline that is comparable to the reference's own CPU path; the plain NumPy oracle's im2col + sgemm
 convolutions are 10-30x slower than oneDNN's and say little about what a CPU can do.
 
 The child first checks the patched oracle against the unpatched one on a small case (same weights), then times the bounded sample,
@@ -42,14 +44,26 @@ def main():
         with torch.no_grad():
             return F.conv2d(tn(x)[None], tn(w), None if b is None else tn(b), stride=stride, padding=padding)[0].numpy()
 
+    def leaky_relu(x, slope):                       # F.leaky_relu, as every activation of the reference (multi-threaded; np.where is one thread)
+        with torch.no_grad():
+            return F.leaky_relu(tn(x), float(slope)).numpy()
+
     cfg = zcfg.medium_modelcfg(decoder)
     sd = zw.tts_state_dict(cfg, 0)
     hcfg = zcfg.hifigan_config(vocoder)
     hsd = zw.hifigan_state_dict(hcfg, 0)
-    plain = (O.conv1d, O.conv_transpose1d, O.conv2d)
+    plain = (O.conv1d, O.conv_transpose1d, O.conv2d, O.leaky_relu)
+    # HiFi-GAN: the reference folds weight norm ONCE at load (Generator.remove_weight_norm, hifigan.py:132-139, called by get_meldec,
+    # model.py:86-118); the oracle's fold_wn returns a stored ".weight" as it is.  (The StyleTTS convolutions keep their weight norm in
+    # the reference too -- styletts.py:25-34 -- and are folded per call here as there.)
+    hsd_folded = dict(hsd)
+    for k in [k for k in hsd if k.endswith(".weight_v")]:
+        pre = k[: -len(".weight_v")]
+        hsd_folded[pre + ".weight"] = O.fold_wn(hsd, pre)
+        del hsd_folded[pre + ".weight_v"], hsd_folded[pre + ".weight_g"]
 
     def patched(on):
-        O.conv1d, O.conv_transpose1d, O.conv2d = (conv1d, conv_transpose1d, conv2d) if on else plain
+        O.conv1d, O.conv_transpose1d, O.conv2d, O.leaky_relu = (conv1d, conv_transpose1d, conv2d, leaky_relu) if on else plain
 
     # equivalence on a small case first: the patched oracle is the same function
     if config == 5:
@@ -58,13 +72,13 @@ def main():
         diff = float(np.abs(np.asarray(a) - np.asarray(b)).max())
     elif config == 4:
         m = np.random.default_rng(3).standard_normal((80, 24)).astype(np.float32)
-        a = O.hifigan_generator(m, hsd, hcfg); patched(True); b = O.hifigan_generator(m, hsd, hcfg)
+        a = O.hifigan_generator(m, hsd, hcfg); patched(True); b = O.hifigan_generator(m, hsd_folded, hcfg)
         diff = float(np.abs(a - b).max())
     else:
         ph, pu, spk, dur = synthetic.utterance(6, 0, "const7")
         a = O.inference_ex(sd, hsd, cfg, hcfg, ph, pu, spk, duration=dur, pad_to=8)["wav"]
         patched(True)
-        b = O.inference_ex(sd, hsd, cfg, hcfg, ph, pu, spk, duration=dur, pad_to=8)["wav"]
+        b = O.inference_ex(sd, hsd_folded, cfg, hcfg, ph, pu, spk, duration=dur, pad_to=8)["wav"]
         diff = float(np.abs(a - b).max())
     if not diff < 1e-3:
         raise SystemExit(f"oneDNN-backed oracle differs from the NumPy oracle by {diff}")
@@ -74,12 +88,12 @@ def main():
     if config == 2:
         for u in range(units):
             ph, pu, spk, dur = synthetic.utterance(T, u, "const7")
-            n += len(O.inference_ex(sd, hsd, cfg, hcfg, ph, pu, spk, duration=dur, pad_to=896)["wav"])
+            n += len(O.inference_ex(sd, hsd_folded, cfg, hcfg, ph, pu, spk, duration=dur, pad_to=896)["wav"])
         what = f"{units} utterances of the workload ({T} phonemes -> 896 frames -> 229376 samples each)"
     elif config == 4:
         for u in range(units):
             mel = np.random.default_rng(7 + u).standard_normal((80, 1024)).astype(np.float32)
-            n += len(O.hifigan_generator(mel, hsd, hcfg))
+            n += len(O.hifigan_generator(mel, hsd_folded, hcfg))
         what = f"{units} utterances of the workload (1024-frame N(0,1) mels -> 262144 samples each)"
     else:
         mels = np.random.default_rng(8).standard_normal((units, 258, 80)).astype(np.float32)
