@@ -36,3 +36,10 @@ def test_streaming_kernels_stay_within_their_wave_budget(resources):
     for k, v in rs.items():
         assert v.get("vgpr_spill", 0) == 0 and v.get("scratch", 0) == 0, (k, v)
         assert v["occupancy"] >= 2, (k, v)                                                # 8 and 12 waves per workgroup need 2 resp. 3 per SIMD
+
+
+def test_pair_kernel_keeps_two_waves_per_simd_without_spills(resources):
+    ps = {k: v for k, v in resources.items() if "pairstream128_kernel" in k}
+    assert len(ps) == 12                                                              # k = 3 / 7 / 11 x four epilogue modes
+    for k, v in ps.items():
+        assert v.get("vgpr_spill", 0) == 0 and v.get("scratch", 0) == 0 and v["occupancy"] >= 2, (k, v)   # 8 waves per workgroup: conv1 + conv2 on every SIMD
