@@ -1,4 +1,4 @@
-// pairstream_exp.hip -- EXPERIMENTAL FORK of zerovox_amd/csrc/pairstream.hip for traffic cut-outs only (tools/micro/ps_bench_exp.hip): PS_EXP 128 = half of the
+// pairstream_exp.hip -- EXPERIMENTAL FORK of zerovox_amd/csrc/pairstream.hip for traffic cut-outs only (tools/micro/psx_bench.hip): PS_EXP 128 = half of the
 // x-fragment LDS reads (odd row tiles reuse the even tile's fragment), 256 = a second weight-fragment load per MFMA step (into a scratch register): together
 // the operand traffic of a 64-row x 64-channel wave tile.  Results are wrong by design; only the timing means something.
 // pairstream.hip -- one HiFi-GAN ResBlock1 iteration (hifigan.py:51-55)
