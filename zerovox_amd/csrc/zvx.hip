@@ -1990,9 +1990,9 @@ zvx_status zvx_comm_gather(zvx_ctx* c, const void* local, size_t bytes, void* re
 zvx_status zvx_comm_max_f64(zvx_ctx* c, double* value) {
     return guarded(c, [&] {
         if (!c->comm_stream || !value) fail(ZVX_E_STATE, "zvx_comm_max_f64: call zvx_comm_init first");
-        c->sync();
+        double* d = (double*)c->buf("comm.scalar", 64);      // (a first use zero-fills it on the compute stream: taken BEFORE the drain below,
+        c->sync();                                           //  the communication stream must not see that fill land on top of its copy)
         if (!c->comm) return;
-        double* d = (double*)c->buf("comm.scalar", 64);
         HIPCHK(hipMemcpyAsync(d, value, sizeof(double), hipMemcpyHostToDevice, c->comm_stream));
         NCCLCHK(rccl().AllReduce(d, d, 1, ncclFloat64, ncclMax, c->comm, c->comm_stream));
         HIPCHK(hipMemcpyAsync(value, d, sizeof(double), hipMemcpyDeviceToHost, c->comm_stream));
@@ -2010,6 +2010,7 @@ zvx_status zvx_comm_info(zvx_ctx* c, int64_t* out, int n_out) {
         if (!c->comm_stream || !out) fail(ZVX_E_STATE, "zvx_comm_info: call zvx_comm_init first");
         const int W = c->world;
         if (n_out < 4 + W) fail(ZVX_E_BUFFER, "zvx_comm_info: need %d entries", 4 + W);
+        double* const d = (double*)c->buf("comm.info", (size_t)(W + 1) * 8);      // (allocated -- and zero-filled on the compute stream -- before the drain)
         c->sync();
         for (int i = 0; i < n_out; i++) out[i] = -1;
         out[0] = W;
@@ -2027,7 +2028,6 @@ zvx_status zvx_comm_info(zvx_ctx* c, int64_t* out, int n_out) {
             if (r.CommCount) NCCLCHK(r.CommCount(c->comm, &n));
             if (r.GetVersion) NCCLCHK(r.GetVersion(&ver));
             out[1] = n; out[2] = ver;
-            double* d = (double*)c->buf("comm.info", (size_t)(W + 1) * 8);
             HIPCHK(hipMemcpyAsync(d, v.data(), (size_t)(W + 1) * 8, hipMemcpyHostToDevice, c->comm_stream));
             NCCLCHK(r.AllReduce(d, d, 1, ncclFloat64, ncclSum, c->comm, c->comm_stream));
             NCCLCHK(r.AllReduce(d + 1, d + 1, W, ncclFloat64, ncclMax, c->comm, c->comm_stream));
