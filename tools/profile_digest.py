@@ -19,9 +19,9 @@ for name in ("n1", "n1_serial", "n1_exact_encoder", "n1_bf16_planes", "n1_host_o
         print(f"{name:18s} (missing)")
         continue
     r = j.get("roofline", {})
-    tr = r.get("timed_region", {})
+    tr = r.get("alone", {})
     print(f"{name:18s} {j['ms_per_step']:8.3f} ms  {j['value']:.4g} {j['unit']:10s} dom {r.get('kernel', '-'):24s} frac {r.get('frac', 0):.3f} avg {r.get('avg_launch_ms', 0):.4f} ms"
-          + (f"  timed-region frac {tr['frac']:.3f} avg {tr['avg_launch_ms']:.4f}" if tr else "") + f"  traffic {r.get('traffic')}  sha {j.get('src_sha16')}")
+          + (f"  alone-on-chip frac {tr['frac']:.3f} avg {tr['avg_launch_ms']:.4f}" if tr else "") + f"  traffic {r.get('traffic')}  sha {j.get('src_sha16')}")
 j = load("n1")
 if j:
     print("stage_ms_one_step_alone", {k: round(v, 3) for k, v in (j.get("stage_ms_one_step_alone") or {}).items()})

@@ -117,6 +117,7 @@ class Context:
         self.n_mels = self.get_int("n_mels")
         self.hop = self.get_int("hop")
         self.device = device
+        self.rank, self.world = 0, 1                 # until comm_init: comm_info() then reports the C side's ZVX_E_STATE, not an AttributeError
 
     def close(self):
         if getattr(self, "_h", None):

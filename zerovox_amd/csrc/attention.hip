@@ -3,7 +3,7 @@
 //     out[q][:] = softmax_k( Q[q].K[k] / sqrt(d)  masked to k < len ) . V[k][:]
 //
 // One workgroup = one (utterance, head, 128-query tile); its four waves own 32 queries each.  Keys / values stream through
-// LDS in 32-key tiles (double-buffered, global loads of tile t+1 in flight while tile t is computed); the [L][L] score
+// LDS in 64-key tiles (double-buffered, global loads of tile t+1 in flight while tile t is computed); the [L][L] score
 // matrix never exists in HBM (the unfused path moved 2 x 205 MB of f32 scores + 2 x 103 MB of bf16 probabilities per layer
 // at B = 32, L = 896).  Online softmax keeps (running max, running sum) per query in registers.
 //
@@ -27,7 +27,7 @@ static thread_local hipEvent_t g_fa_ev_start = nullptr, g_fa_ev_stop = nullptr;
 void flash_profile_events(hipEvent_t start, hipEvent_t stop) { g_fa_ev_start = start; g_fa_ev_stop = stop; }
 
 #define FA_BQ 128
-#define FA_BK 32
+#define FA_BK 64
 #define FA_NKB (FA_BK / 32)      // 32-key blocks per tile
 
 // F16: Q / K / V^T / output (and the probabilities fed to the second product) are IEEE half instead of bf16 (the FS2 decoder in
@@ -47,6 +47,39 @@ __device__ __forceinline__ f32x16 fa_mfma(const uint4& a_, const uint4& b_, cons
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a_), __builtin_bit_cast(bf16x8, b_), c_, 0, 0, 0);
 }
 
+// One chain of N = NACC x SPA matrix steps whose A fragments come from LDS: fragment I sits at `base` + (I / SPA) * ACCB + (I % SPA) * 32
+// (a compile-time immediate of its ds_read_b128), feeds accumulator I / SPA together with B operand bop[I % SPA], and is requested PD
+// steps ahead of its MFMA into a ring of PD + 1 register sets (counted lgkmcnt: LDS operations complete in order).  Left to hipcc the
+// loop was `ds_read; s_waitcnt lgkmcnt(0); v_mfma` with ONE register set -- every matrix step paid a whole LDS round trip (round 4:
+// ~130 cycles per 32-cycle MFMA).  The caller guarantees an empty LGKM queue at entry.
+template <int I, int N, int PD, int SPA, int ACCB>
+__device__ __forceinline__ void fa_read(uint4 (&xf)[PD + 1], unsigned base) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(xf[I % (PD + 1)]) : "v"(base), "n"((I / SPA) * ACCB + (I % SPA) * 32));
+}
+template <int I, int N, int PD, int SPA, int ACCB>
+__device__ __forceinline__ void fa_prefetch(uint4 (&xf)[PD + 1], unsigned base) {
+    if constexpr (I < PD && I < N) { fa_read<I, N, PD, SPA, ACCB>(xf, base); fa_prefetch<I + 1, N, PD, SPA, ACCB>(xf, base); }
+}
+template <int I, int N, int PD, int SPA, int ACCB, bool F16, int NACC>
+__device__ __forceinline__ void fa_steps(uint4 (&xf)[PD + 1], unsigned base, f32x16 (&acc)[NACC], const uint4 (&bop)[SPA]) {
+    if constexpr (I < N) {
+        if constexpr (I + PD < N) fa_read<I + PD, N, PD, SPA, ACCB>(xf, base);
+        asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(N - 1 - I >= PD ? PD : N - 1 - I) : "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        acc[I / SPA] = fa_mfma<F16>(xf[I % (PD + 1)], bop[I % SPA], acc[I / SPA]);
+        __builtin_amdgcn_sched_barrier(0);
+        fa_steps<I + 1, N, PD, SPA, ACCB, F16, NACC>(xf, base, acc, bop);
+    }
+}
+template <int PD, int SPA, int ACCB, bool F16, int NACC>
+__device__ __forceinline__ void fa_chain(unsigned base, f32x16 (&acc)[NACC], const uint4 (&bop)[SPA]) {
+    uint4 xf[PD + 1];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    fa_prefetch<0, NACC * SPA, PD, SPA, ACCB>(xf, base);
+    fa_steps<0, NACC * SPA, PD, SPA, ACCB, F16, NACC>(xf, base, acc, bop);
+}
+
 template <int D, bool F16>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void flash_attn_kernel(const FlashArgs a) {
     constexpr int KS = (D + 15) / 16, DP = KS * 16;             // k16 steps / padded depth of Q.K
@@ -59,9 +92,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // [2][K tile | V^T tile]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l32 = lane & 31, hi = lane >> 5;
-    const int b = blockIdx.y / a.nheads, h = blockIdx.y - b * a.nheads;
+    const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;   // LDS byte address of the window
+    // workgroups reach the 8 XCDs round-robin in launch order: remap so that each XCD walks a CONTIGUOUS range of (utterance, head,
+    // query tile) -- the <= 7 query tiles of one (utterance, head) then share that XCD's L2 for the 0.95 MB of K / V^T they all stream
+    // (round 4: query tile fastest on blockIdx.x put them on 7 different XCDs: 515 MB moved per launch for 121 MB of tensors)
+    const int nq = (a.L + FA_BQ - 1) / FA_BQ;
+    int wgi;
+    {
+        const int nwg = gridDim.x, id = blockIdx.x, qn = nwg >> 3, rn = nwg & 7, xcd = id & 7;
+        wgi = (xcd < rn ? xcd * (qn + 1) : rn * (qn + 1) + (xcd - rn) * qn) + (id >> 3);
+    }
+    const int bh = wgi / nq, b = bh / a.nheads, h = bh - b * a.nheads;
     const int len = a.len ? a.len[b] : a.L;
-    const int q0 = blockIdx.x * FA_BQ;
+    const int q0 = (wgi - bh * nq) * FA_BQ;
     if (q0 >= len) return;
     const unsigned short* const Qg = (const unsigned short*)a.qk + (long)b * a.qk_bs + (long)h * D;
     const unsigned short* const Kg = Qg + a.k_off;
@@ -77,36 +120,60 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         if (q < len && d0 < D) qf[s] = *(const uint4*)(Qg + (long)q * a.ldq + d0);       // D % 8 == 0: a chunk is all inside or all padding
     }
 
-    // ---- staging of one K / V^T tile: global -> registers (issued a tile ahead) -> LDS ----
-    uint4 kreg[KIT], vreg[VIT];
-    auto load_tile = [&](int k0) {
+    // ---- staging of one K / V^T tile: global -> registers (issued a phase ahead) -> LDS.  ONE register set serves both halves: the
+    //      K rows of tile t+1 are requested in front of tile t's score product and committed behind it, the V^T rows in front of the
+    //      softmax / second product and committed behind that (64-key tiles would not fit the register file with both in flight).
+    //      Thread -> (row tid / 8 [+ 32], 16-byte chunk tid % 8 [+ 8 j]): 128 contiguous bytes per row and instruction, and every
+    //      address of a tile is ONE per-thread offset plus wave-uniform / immediate terms (no address registers to keep alive) ----
+    static_assert(FA_BK == 64 && KCH <= 40 && DO <= 288, "staging map");
+    constexpr int KJ = (KCH + 7) / 8;                           // chunk groups per K row (5: the last one holds chunk 32 and the zero pad 33)
+    constexpr int VJ = (D + 31) / 32;                           // row groups of V^T (9: the last one rows 256 .. 263)
+    constexpr int SIT = 2 * KJ > VJ ? 2 * KJ : VJ;
+    uint4 stg[SIT];
+    const int srow = tid >> 3, sch = tid & 7;
+    const unsigned k_goff = (unsigned)(srow * a.ldq + sch * 8) * 2u, k_loff = (unsigned)(srow * KP + sch * 16);
+    const unsigned v_goff = (unsigned)(srow * a.ldv + sch * 8) * 2u, v_loff = (unsigned)(srow * VP + sch * 16);
+    // K rows past the utterance are clamped to its last row (their scores are masked), V^T columns past it are zeros (0 x junk)
+    auto load_k = [&](int k0) {
 #pragma unroll
-        for (int it = 0; it < KIT; it++) {
-            const int c = tid + it * 256, row = c / KCH, ch = c - row * KCH;
-            kreg[it] = make_uint4(0, 0, 0, 0);
-            if (c < FA_BK * KCH && k0 + row < len && ch * 8 < D) kreg[it] = *(const uint4*)(Kg + (long)(k0 + row) * a.ldq + ch * 8);
-        }
+        for (int g = 0; g < 2; g++) {
+            const int row = min(k0 + 32 * g + srow, len - 1) - srow;                                 // (uniform part + this thread's row)
+            const unsigned char* const base = (const unsigned char*)Kg + (long)row * a.ldq * 2;
 #pragma unroll
-        for (int it = 0; it < VIT; it++) {
-            const int c = tid + it * 256, row = c / VCH, ch = c - row * VCH;
-            vreg[it] = make_uint4(0, 0, 0, 0);
-            if (c < DO * VCH && row < D && k0 + ch * 8 < len) vreg[it] = *(const uint4*)(Vg + (long)row * a.ldv + k0 + ch * 8);
-        }
-    };
-    auto store_tile = [&](int buf) {
-        unsigned char* const kb = lds + buf * (KBYTES + VBYTES);
-        unsigned char* const vb = kb + KBYTES;
-#pragma unroll
-        for (int it = 0; it < KIT; it++) {
-            const int c = tid + it * 256, row = c / KCH, ch = c - row * KCH;
-            if (c < FA_BK * KCH) *(uint4*)(kb + row * KP + ch * 16) = kreg[it];
-        }
-#pragma unroll
-        for (int it = 0; it < VIT; it++) {
-            const int c = tid + it * 256, row = c / VCH, ch = c - row * VCH;
-            if (c < DO * VCH) *(uint4*)(vb + row * VP + ch * 16) = vreg[it];
+            for (int j = 0; j < KJ; j++)
+                if (j * 8 + 7 < D / 8 || sch + j * 8 < D / 8) stg[g * KJ + j] = *(const uint4*)(base + k_goff + j * 128);
         }
     };
+    auto store_k = [&](int buf) {
+        unsigned char* const kb = lds + buf * (KBYTES + VBYTES) + k_loff;
+#pragma unroll
+        for (int g = 0; g < 2; g++)
+#pragma unroll
+            for (int j = 0; j < KJ; j++)
+                if (j * 8 + 7 < D / 8 || sch + j * 8 < D / 8) *(uint4*)(kb + g * 32 * KP + j * 128) = stg[g * KJ + j];
+    };
+    auto load_v = [&](int k0) {
+        const bool kok = k0 + sch * 8 < len;                                                          // len % 8 keys of a chunk: V^T columns [len, roundup8) are zeros in HBM
+        const unsigned char* const base = (const unsigned char*)Vg + (long)k0 * 2 + v_goff;
+#pragma unroll
+        for (int it = 0; it < VJ; it++) {
+            stg[it] = make_uint4(0, 0, 0, 0);
+            if (kok && (it * 32 + 31 < D || srow + it * 32 < D)) stg[it] = *(const uint4*)(base + (long)it * 32 * a.ldv * 2);
+        }
+    };
+    auto store_v = [&](int buf) {
+        unsigned char* const vb = lds + buf * (KBYTES + VBYTES) + KBYTES + v_loff;
+#pragma unroll
+        for (int it = 0; it < VJ; it++)
+            if (it * 32 + 31 < D || srow + it * 32 < D) *(uint4*)(vb + it * 32 * VP) = stg[it];
+    };
+    // the zero pad of the K rows' depth (chunk D / 8 .. KCH - 1: multiplied with Q's zero pad, must be finite) is written once
+    if (D / 8 < KCH) {
+        for (int i = tid; i < 2 * FA_BK * (KCH - D / 8); i += 256) {
+            const int buf = i / (FA_BK * (KCH - D / 8)), r = i % (FA_BK * (KCH - D / 8)), row = r / (KCH - D / 8), ch = D / 8 + r % (KCH - D / 8);
+            *(uint4*)(lds + buf * (KBYTES + VBYTES) + row * KP + ch * 16) = make_uint4(0, 0, 0, 0);
+        }
+    }
 
     f32x16 o[NDB];
 #pragma unroll
@@ -117,42 +184,46 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const float sc = a.scale * 1.4426950408889634f;             // exp(x) = exp2(x log2 e)
 
     const int ntiles = (len + FA_BK - 1) / FA_BK;
-    load_tile(0);
-    store_tile(0);
+    load_k(0); store_k(0);
+    load_v(0); store_v(0);
     __syncthreads();
     for (int t = 0; t < ntiles; t++) {
         const int k0 = t * FA_BK;
-        if (t + 1 < ntiles) load_tile(k0 + FA_BK);              // in flight while this tile is computed
+        if (t + 1 < ntiles) load_k(k0 + FA_BK);                 // in flight under the score product
         const unsigned char* const kb = lds + (t & 1) * (KBYTES + VBYTES);
         const unsigned char* const vb = kb + KBYTES;
 
         // ---- S^T = K.Q^T: two 32-key blocks x 32 queries ----
         f32x16 s[FA_NKB];
 #pragma unroll
-        for (int kbk = 0; kbk < FA_NKB; kbk++) {
+        for (int kbk = 0; kbk < FA_NKB; kbk++)
 #pragma unroll
             for (int e = 0; e < 16; e++) s[kbk][e] = 0.f;
-            const unsigned char* const rowp = kb + (kbk * 32 + l32) * KP + hi * 16;
-#pragma unroll
-            for (int st = 0; st < KS; st++) {
-                const uint4 kf = *(const uint4*)(rowp + st * 32);
-                s[kbk] = fa_mfma<F16>(kf, qf[st], s[kbk]);
-            }
-        }
+        fa_chain<3, KS, 32 * KP, F16, FA_NKB>(lds_base + (unsigned)(kb - lds) + (unsigned)(l32 * KP + hi * 16), s, qf);
+        // the other buffer's K half: last read in tile t-1's score product, behind that tile's closing barrier
+        if (t + 1 < ntiles) { store_k((t + 1) & 1); load_v(k0 + FA_BK); }
         // ---- online softmax over this lane's 32 keys (+ the partner lane's 32): key of element (kbk, g, e) = 32 kbk + 8 g + 4 hi + e ----
+        // the scores stay unscaled: p = exp2(s * sc - m) is one fma in front of v_exp_f32, the running max is kept in scaled units
+        if (k0 + FA_BK > len) {                                     // wave-uniform: only an utterance's last tile has keys to mask
+#pragma unroll
+            for (int kbk = 0; kbk < FA_NKB; kbk++)
+#pragma unroll
+                for (int e = 0; e < 16; e++) {
+                    const int key = k0 + kbk * 32 + 8 * (e >> 2) + 4 * hi + (e & 3);
+                    if (key >= len) s[kbk][e] = -INFINITY;
+                }
+        }
         float mt = -INFINITY;
 #pragma unroll
         for (int kbk = 0; kbk < FA_NKB; kbk++)
 #pragma unroll
-            for (int e = 0; e < 16; e++) {
-                const int key = k0 + kbk * 32 + 8 * (e >> 2) + 4 * hi + (e & 3);
-                const float v = key < len ? s[kbk][e] * sc : -INFINITY;
-                s[kbk][e] = v;
-                mt = fmaxf(mt, v);
-            }
+            for (int e = 0; e < 16; e++) mt = fmaxf(mt, s[kbk][e]);
         mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
-        const float m_new = fmaxf(m_run, mt);                   // finite: every tile has at least one valid key
-        const float alpha = exp2f(m_run - m_new);               // first tile: exp2(-inf) = 0
+        const float m_new = fmaxf(m_run, mt * sc);                  // finite: every tile has at least one valid key (sc > 0)
+        // the running max moves in the first tiles and rarely afterwards: when it has moved for NO query of the wave the rescale
+        // factor is exactly 1 for all of them and the 144 accumulator multiplies are skipped (identical results)
+        const bool moved = __builtin_amdgcn_ballot_w64(m_new != m_run) != 0;
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);  // first tile: exp2(-inf) = 0
         m_run = m_new;
         float rs = 0.f;
         unsigned pk[FA_NKB][8];                                      // probabilities as bf16 pairs: pk[kbk][2 g + (0: e 0,1 | 1: e 2,3)]
@@ -160,16 +231,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         for (int kbk = 0; kbk < FA_NKB; kbk++)
 #pragma unroll
             for (int g = 0; g < 4; g++) {
-                const float p0 = exp2f(s[kbk][4 * g] - m_new), p1 = exp2f(s[kbk][4 * g + 1] - m_new);
-                const float p2 = exp2f(s[kbk][4 * g + 2] - m_new), p3 = exp2f(s[kbk][4 * g + 3] - m_new);
+                const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kbk][4 * g], sc, -m_new)), p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kbk][4 * g + 1], sc, -m_new));
+                const float p2 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kbk][4 * g + 2], sc, -m_new)), p3 = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kbk][4 * g + 3], sc, -m_new));
                 rs += (p0 + p1) + (p2 + p3);
                 pk[kbk][2 * g] = fa_pack2<F16>(p0, p1); pk[kbk][2 * g + 1] = fa_pack2<F16>(p2, p3);
             }
-        l_run = l_run * alpha + rs;
+        if (moved) {
+            l_run *= alpha;
 #pragma unroll
-        for (int i = 0; i < NDB; i++)
+            for (int i = 0; i < NDB; i++)
 #pragma unroll
-            for (int e = 0; e < 16; e++) o[i][e] *= alpha;
+                for (int e = 0; e < 16; e++) o[i][e] *= alpha;
+        }
+        l_run += rs;
         // ---- P^T as B operand of O^T += V^T.P^T: lanes l / l+32 swap the halves of every 8-key group (v_permlane32_swap) ----
         uint4 pf[2 * FA_NKB];                                            // key steps of 16: step 2 kbk + t covers keys 32 kbk + 16 t .. + 15
 #pragma unroll
@@ -185,16 +259,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 pf[2 * kbk + tt] = make_uint4(a0, a1, b0, b1);
             }
         // ---- O^T += V^T.P^T ----
-#pragma unroll
-        for (int i = 0; i < NDB; i++) {
-            const unsigned char* const rowp = vb + (i * 32 + l32) * VP + hi * 16;
-#pragma unroll
-            for (int st = 0; st < 2 * FA_NKB; st++) {
-                const uint4 vf = *(const uint4*)(rowp + st * 32);
-                o[i] = fa_mfma<F16>(vf, pf[st], o[i]);
-            }
-        }
-        if (t + 1 < ntiles) store_tile((t + 1) & 1);            // the other buffer: last read in tile t-1, behind the barrier below
+        fa_chain<3, 2 * FA_NKB, 32 * VP, F16, NDB>(lds_base + (unsigned)(vb - lds) + (unsigned)(l32 * VP + hi * 16), o, pf);
+        if (t + 1 < ntiles) store_v((t + 1) & 1);               // the other buffer's V^T half: last read in tile t-1
         __syncthreads();
     }
     // ---- out[q][h D + d] = O[d][q] / l ----
@@ -222,7 +288,8 @@ bool launch_flash_attention(const FlashArgs& a, hipStream_t stream, bool dry_run
     if (dry_run) return true;
     constexpr int D = 264, KS = (D + 15) / 16, DP = KS * 16, DO = (D + 31) / 32 * 32;
     const size_t lds = 2 * ((size_t)FA_BK * (DP * 2 + 16) + (size_t)DO * (FA_BK * 2 + 16));
-    const dim3 grid((a.L + FA_BQ - 1) / FA_BQ, a.nbatch * a.nheads), block(256);
+    const dim3 grid(((a.L + FA_BQ - 1) / FA_BQ) * a.nbatch * a.nheads), block(256);      // 1-D: the kernel deals (utterance, head, query tile) to the XCDs itself
+    if (lds > 160 * 1024) return false;
     static std::atomic<bool> attr_done{false};
     if (!attr_done) {
         (void)hipFuncSetAttribute((const void*)flash_attn_kernel<264, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);

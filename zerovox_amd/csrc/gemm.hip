@@ -1416,7 +1416,7 @@ static bool launch_resfuse_persist_c(const GemmArgs& a, hipStream_t stream) {
     constexpr int BM1 = 32 * TM * (4 / (C >= 32 ? C / 32 : 1));
     const int h2 = (a.ntaps - 1) / 2, bmo = BM1 - 2 * h2;
     const int ntm = (a.M + bmo - 1) / bmo, ntiles = ntm * a.nbatch;
-    const int ncu = num_cus();
+    const int ncu = persistent_cus();
     dim3 grid(ntiles < ncu ? ntiles : ncu);
     for (int t = 0; t < a.ntaps; t++)                      // the kernel derives the taps from (kernel size, dilation)
         if (a.dv[t] != t - h2 || a.dv1[t] != (t - h2) * (a.dv1[1] - a.dv1[0])) return false;

@@ -677,7 +677,7 @@ template <int KT, int CC>
 __global__ __launch_bounds__(256) void k_conv_post_tanh(const void* x, int xdt, int ldx, long x_bs, const float* __restrict__ w, float bias, int kt, int C,
                                  void* wav, long wav_bs, int Nmax, int pcm16, const int* in_len, int len_mul, const int* out_len, int out_mul) {
     extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
-    const int es = xdt == DT_BF16 ? 2 : 4, rowb = C * es, pitch = rowb + 16, half = (kt - 1) / 2, nrows = 256 + kt - 1;
+    const int es = xdt != DT_F32 ? 2 : 4, rowb = C * es, pitch = rowb + 16, half = (kt - 1) / 2, nrows = 256 + kt - 1;
     // KT, CC > 0 (HiFi-GAN: 7 taps x 32 channels, bf16): the tap / channel loops unroll and the weights are read with uniform
     // addresses straight from `w` (scalar loads, SGPR operands) instead of 56 LDS reads per sample; otherwise staged in LDS
     float* wl = (float*)(sm + (size_t)nrows * pitch);
@@ -715,10 +715,9 @@ __global__ __launch_bounds__(256) void k_conv_post_tanh(const void* x, int xdt, 
             for (int c = 0; c < CC; c += 8) {
                 const uint4 t = *(const uint4*)(row + c * 2);
                 const float* ww = w + k * CC + c;
-                acc += __uint_as_float(t.x << 16) * ww[0] + __uint_as_float(t.x & 0xffff0000u) * ww[1]
-                     + __uint_as_float(t.y << 16) * ww[2] + __uint_as_float(t.y & 0xffff0000u) * ww[3]
-                     + __uint_as_float(t.z << 16) * ww[4] + __uint_as_float(t.z & 0xffff0000u) * ww[5]
-                     + __uint_as_float(t.w << 16) * ww[6] + __uint_as_float(t.w & 0xffff0000u) * ww[7];
+                float v[8];
+                unpack8(t, xdt, v);                                            // bf16 or IEEE half (the vocoder's 16-bit dtype)
+                acc += v[0] * ww[0] + v[1] * ww[1] + v[2] * ww[2] + v[3] * ww[3] + v[4] * ww[4] + v[5] * ww[5] + v[6] * ww[6] + v[7] * ww[7];
             }
         }
         put(n, tanhf(acc));
@@ -728,14 +727,13 @@ __global__ __launch_bounds__(256) void k_conv_post_tanh(const void* x, int xdt, 
         const long m = n + k - half;
         if (m < 0 || m >= nin) continue;
         const unsigned char* row = sm + (threadIdx.x + k) * pitch;
-        if (xdt == DT_BF16) {
+        if (xdt != DT_F32) {
             for (int c = 0; c < C; c += 8) {
                 const uint4 t = *(const uint4*)(row + c * 2);
                 const float* ww = wl + k * C + c;
-                acc += __uint_as_float(t.x << 16) * ww[0] + __uint_as_float(t.x & 0xffff0000u) * ww[1]
-                     + __uint_as_float(t.y << 16) * ww[2] + __uint_as_float(t.y & 0xffff0000u) * ww[3]
-                     + __uint_as_float(t.z << 16) * ww[4] + __uint_as_float(t.z & 0xffff0000u) * ww[5]
-                     + __uint_as_float(t.w << 16) * ww[6] + __uint_as_float(t.w & 0xffff0000u) * ww[7];
+                float v[8];
+                unpack8(t, xdt, v);
+                acc += v[0] * ww[0] + v[1] * ww[1] + v[2] * ww[2] + v[3] * ww[3] + v[4] * ww[4] + v[5] * ww[5] + v[6] * ww[6] + v[7] * ww[7];
             }
         } else {
             for (int c = 0; c < C; c += 4) {
@@ -751,9 +749,9 @@ void launch_conv_post_tanh(const void* x, int x_dt, int ldx, long x_bs, const fl
                            int ktaps, int C, void* wav, long wav_bs, int pcm16, int B, int Nmax, const int* in_len,
                            int len_mul, const int* out_len, int out_mul, hipStream_t s) {
     if (Nmax <= 0) return;
-    const size_t es = x_dt == DT_BF16 ? 2 : 4;
+    const size_t es = x_dt != DT_F32 ? 2 : 4;
     const size_t lds = (size_t)(256 + ktaps - 1) * (C * es + 16) + (size_t)ktaps * C * sizeof(float);
-    if (x_dt == DT_BF16 && ktaps == 7 && C == 32)
+    if (x_dt != DT_F32 && ktaps == 7 && C == 32)
         hipLaunchKernelGGL((k_conv_post_tanh<7, 32>), dim3((Nmax + 255) / 256, B), dim3(256), lds, s, x, x_dt, ldx, x_bs, w,
                            bias, ktaps, C, wav, wav_bs, Nmax, pcm16, in_len, len_mul, out_len, out_mul);
     else

@@ -452,7 +452,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     else ps_role<1, NT, AM, HAS_OUT>(a, lds, lane, wave - 4);
 }
 
-static int ps_ncu() { return num_cus(); }
+static int ps_ncu() { return persistent_cus(); }
 
 bool launch_pairstream(PairArgs a, hipStream_t stream, bool dry_run, hipEvent_t ev_start, hipEvent_t ev_stop) {
     if (a.C != 128 || a.ldx != a.C || a.dil < 1 || !a.W1 || !a.W2 || !a.b1 || !a.b2) return false;

@@ -470,7 +470,7 @@ __global__ __launch_bounds__(128 * NPAIR * (C / 32) * RSPLIT) void resstream_ker
 // ------------------------------------------------------------------------------------------------
 // launcher
 // ------------------------------------------------------------------------------------------------
-static int ncu() { return num_cus(); }
+static int ncu() { return persistent_cus(); }
 
 template <int C, int NT, int NPAIR, int RSPLIT, int DP>
 static bool launch_rs(StreamArgs& a, hipStream_t stream, bool dry_run) {

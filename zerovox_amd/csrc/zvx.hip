@@ -6,6 +6,7 @@
 #include "../../include/zvx.h"
 #include "zvx_kernels.h"
 
+#include <hip/hip_ext.h>
 #include <dlfcn.h>
 #include <math.h>
 #include <cmath>
@@ -57,7 +58,8 @@ struct GemmEvent { hipEvent_t a, b; int variant; double flops, bytes; long rows;
 
 struct zvx_ctx {
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;          // the stream launches are being issued on (swapped to a side stream and back by the schedules below)
+    hipStream_t main0 = nullptr;           // the context's main stream (what `stream` is outside those swaps)
     // multi-GPU (zvx_comm_*): communicator, its own stream, and per-buffer "the gather has read this" events
     hipStream_t comm_stream = nullptr;
     hipStream_t voc_aux[2] = {nullptr, nullptr};   // single requests: the non-final pairs of the 2nd / 3rd ResBlock of a vocoder stage run beside the 1st
@@ -154,10 +156,18 @@ struct zvx_ctx {
     bool has(const std::string& name) const { return tensors.count(name) != 0; }
     const float* pf(const std::string& name) const { return (const float*)t(name).dev; }
 
+    // A buffer about to be freed may still be read by work queued on ANY of the context's streams (the two-stream schedule: the front
+    // end of call i + 1 regrows "mel" on the front stream while call i's launch_mel_pad is queued on the main stream) -- every stream
+    // of the context is drained first; hipFree's own device-wide synchronisation is not a contract to lean on
+    void drain_for_free() {
+        HIPCHK(hipStreamSynchronize(stream));
+        for (hipStream_t s2 : {main0, front_stream, aux_stream, voc_aux[0], voc_aux[1], comm_stream})
+            if (s2 && s2 != stream) HIPCHK(hipStreamSynchronize(s2));
+    }
     void* buf(const std::string& name, size_t bytes) {
         DevBuf& d = bufs[name];
         if (bytes > d.cap) {
-            if (d.base) { HIPCHK(hipStreamSynchronize(stream)); HIPCHK(hipFree(d.base)); d.base = nullptr; d.p = nullptr; }
+            if (d.base) { drain_for_free(); HIPCHK(hipFree(d.base)); d.base = nullptr; d.p = nullptr; }
             size_t cap = bytes + bytes / 8 + 256;
             HIPCHK(hipMalloc(&d.base, cap));
             HIPCHK(hipMemsetAsync(d.base, 0, cap, stream));
@@ -173,7 +183,7 @@ struct zvx_ctx {
         char* base = (char*)buf(pool, stride * names.size());
         for (size_t i = 0; i < names.size(); i++) {
             DevBuf& d = bufs[names[i]];
-            if (d.base) { HIPCHK(hipStreamSynchronize(stream)); HIPCHK(hipFree(d.base)); d.base = nullptr; }
+            if (d.base) { drain_for_free(); HIPCHK(hipFree(d.base)); d.base = nullptr; }
             d.p = base + i * stride; d.cap = stride;
         }
         *stride_out = stride;
@@ -321,10 +331,13 @@ struct zvx_ctx {
         for (int i = 0; i < 2; i++) if (voc_aux[i]) (void)hipStreamSynchronize(voc_aux[i]);
         front_dirty_main = true; mel_free_pending = false;
     }
+    int cu_split = 0;                      // ZVX_CU_SPLIT (environment, read by zvx_create): CUs reserved for the front stream; 0 = no spatial split
+    std::vector<uint32_t> cu_mask_front, cu_mask_main;
     int front_prio = 1;                    // zvx_set_int("front_prio", v): priority of the front stream: 1 = highest the device offers, -1 = lowest, 0 = default
     void front_setup() {
         if (front_stream) return;
-        if (front_prio) {
+        if (cu_split > 0) HIPCHK(hipExtStreamCreateWithCUMask(&front_stream, (uint32_t)cu_mask_front.size(), cu_mask_front.data()));
+        else if (front_prio) {
             int least = 0, greatest = 0;                                     // (numerically: greatest priority = the smaller value)
             HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
             HIPCHK(hipStreamCreateWithPriority(&front_stream, hipStreamNonBlocking, front_prio > 0 ? greatest : least));
@@ -1628,7 +1641,24 @@ zvx_status zvx_create(const char* manifest, const void* weights, size_t nbytes, 
         if (device < 0 || device >= ndev) fail(ZVX_E_INVALID, "device %d out of range (%d visible)", device, ndev);
         c->device = device;
         HIPCHK(hipSetDevice(device));
+        // ZVX_CU_SPLIT=n (A/B experiment, VERDICT r4 #1c): a SPATIAL split of the chip between the two streams of the front-end overlap --
+        // the front stream may only use n CUs, the main stream (vocoder) the other num_cus() - n, and the persistent vocoder kernels size
+        // their grids for those.  ZVX_CU_SPLIT_MODE: 0 = the front stream's CUs are the mask's lowest n bits, 1 = n / 8 bits in each group of 32
+        if (const char* sp = getenv("ZVX_CU_SPLIT")) c->cu_split = std::max(0, std::min(atoi(sp), num_cus() - 8));
+        if (c->cu_split > 0) {
+            const int mode = getenv("ZVX_CU_SPLIT_MODE") ? atoi(getenv("ZVX_CU_SPLIT_MODE")) : 0;
+            const int n = num_cus(), words = (n + 31) / 32;
+            c->cu_mask_front.assign(words, 0u); c->cu_mask_main.assign(words, 0u);
+            for (int i = 0; i < n; i++) {
+                const bool front = mode == 0 ? i < c->cu_split : (i % 32) < c->cu_split / std::max(1, n / 32);
+                (front ? c->cu_mask_front : c->cu_mask_main)[i / 32] |= 1u << (i % 32);
+            }
+            HIPCHK(hipExtStreamCreateWithCUMask(&c->stream, (uint32_t)words, c->cu_mask_main.data()));
+            int nm = 0; for (int i = 0; i < n; i++) nm += (c->cu_mask_main[i / 32] >> (i % 32)) & 1;
+            persistent_cus_override().store(nm);
+        } else
         HIPCHK(hipStreamCreate(&c->stream));
+        c->main0 = c->stream;
         for (int s = 0; s < ZVX_T_COUNT; s++) { HIPCHK(hipEventCreate(&c->stage_ev[s][0])); HIPCHK(hipEventCreate(&c->stage_ev[s][1])); c->stage_used[s] = false; c->stage_ms[s] = 0.f; }
         parse_manifest(c, manifest, weights, nbytes);
         read_config(c);

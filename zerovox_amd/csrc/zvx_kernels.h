@@ -18,6 +18,10 @@ inline int num_cus() {
     static const int n = [] { int dev = 0, v = 0; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256; return v; }();
     return n;
 }
+// CUs the PERSISTENT vocoder kernels size their grids for: num_cus(), or fewer when the context's main stream is confined to a CU mask
+// (zvx_create with ZVX_CU_SPLIT=n: the front stream owns n CUs, the main stream the rest -- an A/B experiment)
+inline std::atomic<int>& persistent_cus_override() { static std::atomic<int> v{0}; return v; }
+inline int persistent_cus() { const int o = persistent_cus_override().load(std::memory_order_relaxed); return o > 0 ? o : num_cus(); }
 
 enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_LRELU = 2, ACT_TANH = 3 };
 
