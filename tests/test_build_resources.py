@@ -40,6 +40,6 @@ def test_streaming_kernels_stay_within_their_wave_budget(resources):
 
 def test_pair_kernel_keeps_two_waves_per_simd_without_spills(resources):
     ps = {k: v for k, v in resources.items() if "pairstream128_kernel" in k}
-    assert len(ps) == 12                                                              # k = 3 / 7 / 11 x four epilogue modes
+    assert len(ps) == 24                                                              # k = 3 / 7 / 11 x four epilogue modes x {bf16, IEEE half}
     for k, v in ps.items():
         assert v.get("vgpr_spill", 0) == 0 and v.get("scratch", 0) == 0 and v["occupancy"] >= 2, (k, v)   # 8 waves per workgroup: conv1 + conv2 on every SIMD

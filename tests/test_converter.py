@@ -98,3 +98,28 @@ def test_baked_in_vocoder_with_folded_weights_as_the_reference_stores_it(tmp_pat
     import pytest
     with pytest.raises(ValueError):
         load_meldec_weights(str(vdir), tts_modelpath=str(mdir))
+
+
+def test_reference_written_checkpoint_reads_back_as_the_seeded_weights(tmp_path):
+    """tests/golden/refckpt/ was written by the IMPORTED REFERENCE (tests/golden/gen_ref_checkpoint.py: ZeroVox(**kwargs) ->
+    load_state_dict(strict=True) -> torch.save of its own state_dict() + hyper_parameters with the real Symbols object, a generator
+    baked in after remove_weight_norm()).  Reading it -- directly and through tools/convert_checkpoint.py -- must give back the seeded
+    weights it was filled with, bit for bit; the baked-in vocoder arrives with plain (folded) weights."""
+    import convert_checkpoint as cc
+    from zerovox_amd.convert import read_tts_checkpoint
+    d = os.path.join(ROOT, "tests", "golden", "refckpt")
+    cfg = zcfg.reduced_modelcfg("styletts")
+    assert yaml.safe_load(open(os.path.join(d, "modelcfg.yaml"))) == cfg
+    sd = zw.tts_state_dict(cfg, 11)
+    tts, voc = read_tts_checkpoint(d)
+    assert set(tts) == set(sd) and all(np.array_equal(tts[k], sd[k]) for k in sd)
+    h = zcfg.hifigan_config("tiny3")
+    folded = zw.folded(zw.hifigan_state_dict(h, 11))
+    assert set(voc) == set(folded) and not any(k.endswith("weight_g") for k in voc)
+    assert all(np.allclose(voc[k], folded[k], rtol=1e-6, atol=1e-7) for k in folded)        # torch's remove_weight_norm vs the NumPy fold
+    ck = os.path.join(d, "checkpoints", os.listdir(os.path.join(d, "checkpoints"))[0])
+    assert cc.convert_tts(ck, os.path.join(d, "modelcfg.yaml"), str(tmp_path / "out")) == (len(sd), len(voc))
+    cfg2, sd2 = load_tts_weights(str(tmp_path / "out"))
+    assert cfg2 == cfg and all(np.array_equal(sd2[k], sd[k]) for k in sd)
+    h2, hsd2 = load_meldec_weights("synthetic:tiny3:5", tts_modelpath=str(tmp_path / "out"))    # the baked-in generator wins over the external one
+    assert h2 == h and all(np.array_equal(hsd2[k], voc[k]) for k in voc)

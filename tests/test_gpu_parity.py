@@ -10,12 +10,13 @@ Stated tolerances
             an f32 half-ulp, see ops.hip), so log-duration / pitch / energy / features keep the f32 tolerance (2e-4) and every
             discrete decision (duration, pitch / energy bucket) is held to the SAME 1e-3 ambiguity margin as the f32 mode
             (test_predicted_durations_and_buckets_exact[bf16], test_headline_shape_discrete_decisions...).
-            Both mel decoders run in IEEE HALF in this mode (f16 weights + activations, the same MFMA rate; bf16 for the vocoder
-            and the speaker encoder): their single-product bf16 floor was 7e-2 (StyleTTS) / 2.9e-2 (FS2) max on the log-mel, above
-            SURVEY 8c's 2e-2; in half they measure <= 1.02e-2 / 0.22 % rms and <= 3.6e-3 / 0.09 % over every fixture.  Limits =
-            SURVEY.md 8c's own: mel max|err| <= 2e-2, rms <= 0.4 % of the reference rms; waveform in [-1, 1] max|err| <= 1e-2 and
-            rms <= 2e-3, end to end AND for the vocoder alone (measured <= 8.5e-3 / 1.9e-3 end to end, <= 6.3e-3 / 1.3e-3 for
-            the vocoder alone).  ZVX_ERR_LOG=<file> makes every comparison append what it measured.
+            Both mel decoders AND (round 5) the HiFi-GAN vocoder run in IEEE HALF in this mode (f16 weights + activations on the
+            f16 MFMA; bf16 for the speaker encoder): the decoders' single-product bf16 floor was 7e-2 (StyleTTS) / 2.9e-2 (FS2) max
+            on the log-mel, above SURVEY 8c's 2e-2; in half they measure <= 1.02e-2 / 0.22 % rms and <= 3.8e-3 / 0.09 % over every
+            fixture.  Mel limits = SURVEY.md 8c's own: max|err| <= 2e-2, rms <= 0.4 % of the reference rms.  Waveform in [-1, 1]:
+            SURVEY 8c allows 1e-2 / 2e-3 rms; the half vocoder is held to 4e-3 / 8e-4 end to end and 2e-3 / 4e-4 alone (measured
+            <= 1.97e-3 / 4.2e-4 and <= 9.8e-4 / 1.6e-4; the bf16 vocoder of rounds 1-4 -- zvx_set_int("voc_f16", 0) -- measured
+            <= 8.5e-3 / 1.9e-3 and <= 6.3e-3 / 1.3e-3).  ZVX_ERR_LOG=<file> makes every comparison append what it measured.
 """
 import os
 
@@ -89,14 +90,27 @@ def check_mel(a, b, prec, what, kind="fastspeech2"):
     assert rms <= lim_rel * ref_rms and mx <= lim_mx, f"{what}: mel err max {mx:.3e} rms {rms:.3e} (ref rms {ref_rms:.3g})"
 
 
+def check_embed16(e, ref, what):
+    """16-bit mode (the speaker encoder runs in bf16): a unit-norm 528-vector is held to cosine >= 0.9999 with the f32 reference
+    and max |err| <= 2.5e-3 (SURVEY 8c gives no figure for this path; measured over every fixture, raw-audio input and the sampled
+    clips of configs[4]: 1 - cosine <= 4.0e-5, max |err| <= 1.2e-3 -- ZVX_ERR_LOG prints them)."""
+    e, ref = np.asarray(e, np.float64), np.asarray(ref, np.float64)
+    cos = float(np.dot(e, ref) / (np.linalg.norm(e) * np.linalg.norm(ref)))
+    mx = float(np.abs(e - ref).max())
+    _errlog("embed", what, 1.0 - cos, mx)
+    assert cos >= 0.9999 and mx <= 2.5e-3, f"{what}: cosine {cos:.6f}, max err {mx:.3e}"
+
+
 def check_wav(a, b, prec, what, e2e=True):
-    """16-bit mode: SURVEY 8c's waveform bound, 1e-2 abs / 2e-3 rms, end to end and for the vocoder alone (measured over every fixture:
-    <= 8.5e-3 / 1.9e-3 end to end with either decoder, <= 6.3e-3 / 1.3e-3 for the vocoder alone)."""
+    """16-bit mode (round 5: the vocoder's tensors are IEEE half).  SURVEY 8c's waveform bound is 1e-2 abs / 2e-3 rms; the limits here are
+    what the half vocoder measures, with 2x margin: end to end 4e-3 abs / 8e-4 rms (measured over every fixture and the headline shape:
+    <= 1.97e-3 / 4.2e-4), the vocoder alone 2e-3 / 4e-4 (measured <= 9.8e-4 / 1.6e-4).  With the bf16 vocoder of rounds 1-4
+    (zvx_set_int("voc_f16", 0)) the same comparisons read <= 8.5e-3 / 1.9e-3 and <= 6.3e-3 / 1.3e-3."""
     if prec == "f32":
         return check_f32(a, b, what)
     mx, rms, _, _ = stats(a, b)
     _errlog("wav-e2e" if e2e else "wav-voc", what, mx, rms)
-    lim_mx, lim_rms = (1e-2, 2e-3)
+    lim_mx, lim_rms = (4e-3, 8e-4) if e2e else (2e-3, 4e-4)
     assert mx <= lim_mx and rms <= lim_rms, f"{what}: wav err max {mx:.3e} rms {rms:.3e}"
 
 
@@ -281,8 +295,11 @@ def test_speaker_encoder_against_golden(name, prec):
     ctx = ctx_for("styletts", "tiny", prec)
     e = ctx.spkemb(g["ref_mel"][None], np.array([g["ref_mel"].shape[0]], np.int32))[0]
     assert abs(np.linalg.norm(e) - 1.0) < 1e-4
-    mx, _, _, bm = stats(e, g["embed"])
-    assert mx <= (2e-5 if prec == "f32" else 0.05 * bm), f"embed err {mx:.3e} (ref max {bm:.3g})"
+    if prec == "f32":
+        mx, _, _, bm = stats(e, g["embed"])
+        assert mx <= 2e-5, f"embed err {mx:.3e} (ref max {bm:.3g})"
+    else:
+        check_embed16(e, g["embed"], name)
 
 
 def test_speaker_encoder_ragged_batch():
@@ -621,8 +638,11 @@ def test_speaker_embed_end_to_end_from_raw_audio(prec):
     assert 0 < len(trimmed) < len(wav)
     mel, _ = MO.get_mel_from_wav(trimmed, 22050, 1024, 256, 1024, 80, 0, 8000)
     ref = O.resnet_se34v2(mel.T, sd, cfg)
-    mx, _, _, bm = stats(e[0, 0], ref)
-    assert mx <= (5e-5 if prec == "f32" else 0.05 * bm), f"speaker_embed err {mx:.3e} (ref max {bm:.3g})"
+    if prec == "f32":
+        mx, _, _, bm = stats(e[0, 0], ref)
+        assert mx <= 5e-5, f"speaker_embed err {mx:.3e} (ref max {bm:.3g})"
+    else:
+        check_embed16(e[0, 0], ref, "speaker_embed from raw audio")
 
 
 @pytest.mark.parametrize("prec", ["f32", "bf16"])
@@ -1086,6 +1106,68 @@ def test_config4_hifigan_v1_alone_1024_frames():
     assert out[0].std() > 1e-3 and not np.array_equal(out[0], out[1])
 
 
+def test_vocoder_in_ieee_half_against_bf16_and_the_oracle():
+    """Round 5: the vocoder's 16-bit tensors are IEEE half (zvx_set_int("voc_f16", 1), the default); voc_f16 = 0 runs the bf16 kernels of
+    rounds 1-4 on the same context.  On a 256-frame N(0,1) mel both must meet the oracle, and half must be at least 3x closer (measured
+    ~8x: 11 significand bits against 8)."""
+    h, hsd = voc_sd("v1")
+    ctx = ctx_for("styletts", "v1", "bf16")
+    mel = np.random.default_rng(21).standard_normal((256, 80)).astype(np.float32)
+    ref = O.hifigan_generator(mel.T, hsd, h)
+    try:
+        ctx.set_int("voc_f16", 0); wb = ctx.vocode_mel(mel[None], np.array([256], np.int32))[0]
+        ctx.set_int("voc_f16", 1); wh = ctx.vocode_mel(mel[None], np.array([256], np.int32))[0]
+    finally:
+        ctx.set_int("voc_f16", 1)
+    eb, eh = stats(wb, ref), stats(wh, ref)
+    _errlog("wav-voc", "voc_f16 A/B bf16", eb[0], eb[1]); _errlog("wav-voc", "voc_f16 A/B half", eh[0], eh[1])
+    assert eb[0] <= 1e-2 and eb[1] <= 2e-3, f"bf16 vocoder: {eb[:2]}"
+    check_wav(wh, ref, "bf16", "half vocoder", e2e=False)
+    assert eh[1] * 3 <= eb[1], f"half rms {eh[1]:.3e} is not 3x below bf16 rms {eb[1]:.3e}"
+
+
+@pytest.mark.parametrize("voc", ["v1", "v2", "v3"])
+def test_half_vocoder_saturates_instead_of_overflowing(voc):
+    """IEEE half tops out at 65504.  Mels scaled by 16 and by 256 drive the activations of the wide stages far past that; every 16-bit
+    store of the vocoder saturates (MODE.FP16_OVFL in the kernels, v_med3 in the run-time epilogues), so the waveform stays finite and
+    inside [-1, 1] -- no Inf, no NaN from Inf - Inf -- and at the nominal scale the result is untouched by the clamps (oracle check)."""
+    h, hsd = voc_sd(voc)
+    ctx = ctx_for("styletts", voc, "bf16")
+    P = np.array([40, 33], np.int32)
+    rng = np.random.default_rng(31)
+    mel = np.zeros((2, 40, 80), np.float32)
+    for b in range(2):
+        mel[b, :P[b]] = rng.standard_normal((P[b], 80)).astype(np.float32)
+    w1 = ctx.vocode_mel(mel, P)
+    check_wav(w1[0, :P[0] * 256], O.hifigan_generator(mel[0, :P[0]].T, hsd, h), "bf16", f"{voc} x1", e2e=False)
+    for scale in (16.0, 256.0, 4096.0):
+        w = ctx.vocode_mel(mel * scale, P)
+        assert np.isfinite(w).all() and np.abs(w).max() <= 1.0, f"{voc} x{scale}: non-finite or out-of-range samples"
+        assert np.abs(w[0, :P[0] * 256]).max() > 0.0
+        assert not w[1, P[1] * 256:].any()
+
+
+def test_non_finite_mel_values_stay_inside_their_utterance():
+    """zvx_vocode_mel with a NaN / Inf in ONE utterance of a batch (gemm.hip, pairstream.hip and resstream.hip are compiled with
+    -fno-honor-nans: min / max of the leaky-relu forms do not propagate NaN the IEEE way).  Defined behaviour (include/zvx.h): no fault,
+    the call succeeds, the samples of the poisoned utterance are unspecified (finite or not), every OTHER utterance of the batch is bit
+    for bit what it is without the poison, and a later clean call on the same context is unaffected."""
+    ctx = ctx_for("styletts", "v1", "bf16")
+    P = np.array([48, 48, 31], np.int32)
+    rng = np.random.default_rng(41)
+    mel = np.zeros((3, 48, 80), np.float32)
+    for b in range(3):
+        mel[b, :P[b]] = rng.standard_normal((P[b], 80)).astype(np.float32)
+    clean = ctx.vocode_mel(mel, P)
+    bad = mel.copy()
+    bad[1, 10, 3] = np.nan; bad[1, 20, 7] = np.inf; bad[1, 30, 11] = -np.inf
+    out = ctx.vocode_mel(bad, P)
+    assert np.array_equal(out[0], clean[0]) and np.array_equal(out[2], clean[2])
+    assert not out[2, P[2] * 256:].any()
+    again = ctx.vocode_mel(mel, P)
+    assert np.array_equal(again, clean)
+
+
 def test_config5_speaker_encoder_1000_clips():
     """configs[4]: 1000 x [258, 80] N(0,1) reference mels in batches of 50: unit norm everywhere, 8 sampled clips against the
     oracle, and batch invariance (clip i in its batch == clip i alone, to f32 round-off)."""
@@ -1098,9 +1180,7 @@ def test_config5_speaker_encoder_1000_clips():
     assert emb.shape == (1000, 528) and np.isfinite(emb).all()
     assert np.abs(np.linalg.norm(emb, axis=1) - 1.0).max() < 1e-4
     for i in (0, 49, 50, 333, 512, 777, 950, 999):
-        ref = O.resnet_se34v2(mels[i], sd, cfg)
-        mx, _, _, bm = stats(emb[i], ref)
-        assert mx <= 0.05 * bm, f"clip {i}: embed err {mx:.3e} (ref max {bm:.3g})"
+        check_embed16(emb[i], O.resnet_se34v2(mels[i], sd, cfg), f"clip {i}")
     solo = ctx.spkemb(mels[333:334], np.array([258], np.int32))
     assert np.abs(solo[0] - emb[333]).max() < 1e-6                      # tile shapes follow the batch size: equal to f32 round-off, not bit for bit
 
@@ -1144,49 +1224,35 @@ def test_config2_secondary_workload_variable_lengths_full_size(kind):
         assert np.array_equal(solo["mel"][0, :n], mel[b, :n]), f"utt {b}: mel depends on the batch"
 
 
-def test_converted_checkpoint_runs_and_baked_in_vocoder_wins(tmp_path):
-    """SURVEY 8 f-2 end to end: a Lightning-style checkpoint (state_dict + pickled hyper_parameters holding a `Symbols`
-    object, a vocoder baked in under `_meldec.`) -> tools/convert_checkpoint.py -> ZeroVoxTTS.load_model(directory) ->
-    synthesis on the GPU equals the synthetic-weights path; the baked-in generator overrides the external one."""
-    import json
+@pytest.mark.parametrize("prec", ["f32", "bf16"])
+def test_reference_written_checkpoint_reproduces_the_reference_output(prec, tmp_path):
+    """SURVEY 8 f-2 end to end on a checkpoint the REFERENCE wrote (tests/golden/gen_ref_checkpoint.py, reduced-width model: hidden 32,
+    ~2 MB): the model directory as the reference lays it out (modelcfg.yaml + checkpoints/*.ckpt with pickled hyper_parameters holding
+    the real `Symbols` object, a generator baked in under `_meldec.` after remove_weight_norm()) -> ZeroVoxTTS.load_model, directly and
+    through tools/convert_checkpoint.py -> inference_ex on the GPU == the reference's own inference_ex output stored next to it, with
+    forced and with predicted durations; the baked-in generator overrides the external one (other seed)."""
     import sys
-    import types
-    import torch
-    import yaml
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
     import convert_checkpoint as cc
     from zerovox_amd.synthesize import ZeroVoxTTS
-    cfg, sd = tts_sd("styletts")
-    h, hsd = voc_sd("tiny")
-    hsd_other = zw.hifigan_state_dict(h, 5)                                   # the EXTERNAL vocoder carries different weights
-    cc._install_symbols_stub()
-    sym = sys.modules["zerovox.tts.symbols"].Symbols(zcfg.PHONES, zcfg.PUNCTS)
-    state = {k: torch.from_numpy(np.array(v)) for k, v in sd.items()}
-    state.update({"_meldec." + k: torch.from_numpy(np.array(v)) for k, v in hsd.items()})
-    ck = tmp_path / "checkpoint.pkl"
-    torch.save({"state_dict": state, "hyper_parameters": {"symbols": sym, "lr": 1e-4}}, ck)
-    mc = tmp_path / "modelcfg.yaml"
-    yaml.safe_dump(cfg, open(mc, "w"))
-    assert cc.convert_tts(str(ck), str(mc), str(tmp_path / "tts")) == (len(sd), len(hsd))
-    gk = tmp_path / "generator.ckpt"
-    torch.save({"generator": {k: torch.from_numpy(np.array(v)) for k, v in hsd_other.items()}}, gk)
-    cj = tmp_path / "config.json"
-    json.dump(h, open(cj, "w"))
-    cc.convert_vocoder(str(gk), str(cj), str(tmp_path / "voc"))
-    _, synth = ZeroVoxTTS.load_model(str(tmp_path / "tts"), str(tmp_path / "voc"), infer_device="cuda:0", precision="f32")
-    _, ref_synth = ZeroVoxTTS.load_model("synthetic:styletts", "synthetic:tiny", infer_device="cuda:0", precision="f32")
-    spk = synthetic.utterance(4, 3)[2][None, None]
-    a = synth.tts_ex("converted checkpoint", spk, duration=[4] * 19)
-    b = ref_synth.tts_ex("converted checkpoint", spk, duration=[4] * 19)
-    assert a[2] == b[2] == 76 and np.array_equal(a[0], b[0]) and np.array_equal(a[3], b[3])
-    # ... and equals the ORACLE on the same weights (the baked-in vocoder hsd, not the external one), ids from the text front end
-    ph, pu = synth.transcript2phonemids("converted checkpoint")
-    out = O.inference_ex(sd, hsd, cfg, h, np.array(ph, np.int32), np.array(pu, np.int32), spk.reshape(-1), duration=np.full(len(ph), 4, np.int32), pad_to=689)
-    assert out["mel_len"] == 76 and len(ph) == 19
-    check_f32(a[3], out["mel"], "converted checkpoint: mel against the oracle")
-    check_f32(a[0], out["wav"], "converted checkpoint: wav against the oracle")
-    other = O.inference_ex(sd, hsd_other, cfg, h, np.array(ph, np.int32), np.array(pu, np.int32), spk.reshape(-1), duration=np.full(len(ph), 4, np.int32), pad_to=689)
-    assert np.abs(other["wav"] - a[0]).max() > 1e-3                          # the external generator would have given another waveform
+    d = os.path.join(GOLDEN, "refckpt")
+    g = np.load(os.path.join(GOLDEN, "refckpt_expected.npz"))
+    ck = os.path.join(d, "checkpoints", os.listdir(os.path.join(d, "checkpoints"))[0])
+    cc.convert_tts(ck, os.path.join(d, "modelcfg.yaml"), str(tmp_path / "tts"))
+    x = {"phoneme": g["phoneme"][None], "puncts": g["puncts"][None], "duration": g["duration"][None]}
+    outs = []
+    for path in (d, str(tmp_path / "tts")):
+        _, synth = ZeroVoxTTS.load_model(path, "synthetic:tiny3:5", infer_device="cuda:0", precision=prec)
+        for tag, forced in (("forced", True), ("pred", False)):
+            synth._model._min_mel_len = 689
+            wav, ml, logd, mel = synth._model.inference_ex(x, g["spk"][None, None], force_duration=forced)
+            assert ml == int(g[tag + "_mel_len"]), f"{tag}: mel_len {ml} != {int(g[tag + '_mel_len'])}"
+            check_f32(logd[0], g[tag + "_log_duration"], f"{tag}: log_duration")
+            check_mel(mel.T, g[tag + "_mel"].T, prec, f"{tag}: mel", "styletts")
+            check_wav(wav, g[tag + "_wav"], prec, f"{tag}: wav")
+            outs.append(wav)
+        synth._model.close()
+    assert np.array_equal(outs[0], outs[2]) and np.array_equal(outs[1], outs[3])             # converted directory == reference layout read directly
 
 
 def test_demo_cli_prints_the_reference_rtf_lines(capsys, monkeypatch, tmp_path):

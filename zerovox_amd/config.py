@@ -35,6 +35,18 @@ def medium_modelcfg(decoder_kind: str = "styletts") -> dict:
     }
 
 
+def reduced_modelcfg(decoder_kind: str = "styletts") -> dict:
+    """A reduced-width model of the same topology (hidden 32, 2 + 2 layers, a one-block-per-level speaker encoder): ~2 MB of
+    weights, so that a checkpoint WRITTEN BY THE REFERENCE ITSELF fits the repository (tests/golden/gen_ref_checkpoint.py)."""
+    cfg = medium_modelcfg(decoder_kind)
+    m = cfg["model"]
+    m.update({"max_txt_len": 64, "max_mel_len": 256, "emb_dim": 16, "punct_emb_dim": 16})
+    m["encoder"].update({"fs2_layer": 2, "vp_filter_size": 32, "ve_n_bins": 64})
+    m["decoder"].update({"n_layers": 2, "conv_filter_size": 64})
+    m["resnet"].update({"layers": [1, 1, 1, 1], "num_filters": [8, 8, 16, 16]})
+    return cfg
+
+
 def zerovox_kwargs(modelcfg: dict) -> dict:
     """yaml -> ``ZeroVox.__init__`` kwargs (utils/train_tts.py:202-241), training-only ones stubbed."""
     m = modelcfg["model"]
@@ -72,6 +84,9 @@ _HIFIGAN = {
     "tiny": {"resblock": "1", "upsample_rates": [8, 8, 2, 2], "upsample_kernel_sizes": [16, 16, 4, 4],
              "upsample_initial_channel": 128, "resblock_kernel_sizes": [3, 7],
              "resblock_dilation_sizes": [[1, 3, 5], [1, 3, 5]]},
+    "tiny3": {"resblock": "1", "upsample_rates": [8, 8, 4], "upsample_kernel_sizes": [16, 16, 8],
+              "upsample_initial_channel": 64, "resblock_kernel_sizes": [3, 7],
+              "resblock_dilation_sizes": [[1, 3, 5], [1, 3, 5]]},
     "tiny2": {"resblock": "2", "upsample_rates": [8, 8, 4], "upsample_kernel_sizes": [16, 16, 8],
               "upsample_initial_channel": 64, "resblock_kernel_sizes": [3, 5],
               "resblock_dilation_sizes": [[1, 2], [2, 6]]},

@@ -26,6 +26,17 @@ namespace zvx {
 static thread_local hipEvent_t g_fa_ev_start = nullptr, g_fa_ev_stop = nullptr;
 void flash_profile_events(hipEvent_t start, hipEvent_t stop) { g_fa_ev_start = start; g_fa_ev_stop = stop; }
 
+// Development switches (tools/micro/fa_bench.hip): FA_PROFILE = per-phase s_memtime totals of workgroup 0 / wave 0 -> a.prof;
+// FA_EXP cuts pieces OUT (wrong results by design, only the timing means something): 1 no softmax arithmetic, 2 no staging (global
+// loads / LDS stores of the next tile), 4 no second product, 8 no first product
+#ifndef FA_EXP
+#define FA_EXP 0
+#endif
+#ifdef FA_PROFILE
+#define FA_STAMP(k) do { const unsigned long long t_ = __builtin_readcyclecounter(); tacc[k] += t_ - tlast; tlast = t_; } while (0)
+#else
+#define FA_STAMP(k) do {} while (0)
+#endif
 #define FA_BQ 128
 #define FA_BK 64
 #define FA_NKB (FA_BK / 32)      // 32-key blocks per tile
@@ -60,24 +71,30 @@ template <int I, int N, int PD, int SPA, int ACCB>
 __device__ __forceinline__ void fa_prefetch(uint4 (&xf)[PD + 1], unsigned base) {
     if constexpr (I < PD && I < N) { fa_read<I, N, PD, SPA, ACCB>(xf, base); fa_prefetch<I + 1, N, PD, SPA, ACCB>(xf, base); }
 }
-template <int I, int N, int PD, int SPA, int ACCB, bool F16, int NACC>
-__device__ __forceinline__ void fa_steps(uint4 (&xf)[PD + 1], unsigned base, f32x16 (&acc)[NACC], const uint4 (&bop)[SPA]) {
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
+}
+struct FaNoHook { template <int I> __device__ __forceinline__ void operator()(std::integral_constant<int, I>) const {} };
+template <int I, int N, int PD, int SPA, int ACCB, bool F16, int NACC, class HOOK>
+__device__ __forceinline__ void fa_steps(uint4 (&xf)[PD + 1], unsigned base, f32x16 (&acc)[NACC], const uint4 (&bop)[SPA], const HOOK& hook) {
     if constexpr (I < N) {
         if constexpr (I + PD < N) fa_read<I + PD, N, PD, SPA, ACCB>(xf, base);
         asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(N - 1 - I >= PD ? PD : N - 1 - I) : "memory");
         __builtin_amdgcn_sched_barrier(0);
         acc[I / SPA] = fa_mfma<F16>(xf[I % (PD + 1)], bop[I % SPA], acc[I / SPA]);
         __builtin_amdgcn_sched_barrier(0);
-        fa_steps<I + 1, N, PD, SPA, ACCB, F16, NACC>(xf, base, acc, bop);
+        hook(std::integral_constant<int, I>{});                   // (LDS-DMA requests of the next tile ride in the gaps between the matrix steps)
+        fa_steps<I + 1, N, PD, SPA, ACCB, F16, NACC>(xf, base, acc, bop, hook);
     }
 }
-template <int PD, int SPA, int ACCB, bool F16, int NACC>
-__device__ __forceinline__ void fa_chain(unsigned base, f32x16 (&acc)[NACC], const uint4 (&bop)[SPA]) {
+template <int PD, int SPA, int ACCB, bool F16, int NACC, class HOOK = FaNoHook>
+__device__ __forceinline__ void fa_chain(unsigned base, f32x16 (&acc)[NACC], const uint4 (&bop)[SPA], const HOOK& hook = HOOK()) {
     uint4 xf[PD + 1];
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     fa_prefetch<0, NACC * SPA, PD, SPA, ACCB>(xf, base);
-    fa_steps<0, NACC * SPA, PD, SPA, ACCB, F16, NACC>(xf, base, acc, bop);
+    fa_steps<0, NACC * SPA, PD, SPA, ACCB, F16, NACC>(xf, base, acc, bop, hook);
 }
 
 template <int D, bool F16>
@@ -120,60 +137,52 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         if (q < len && d0 < D) qf[s] = *(const uint4*)(Qg + (long)q * a.ldq + d0);       // D % 8 == 0: a chunk is all inside or all padding
     }
 
-    // ---- staging of one K / V^T tile: global -> registers (issued a phase ahead) -> LDS.  ONE register set serves both halves: the
-    //      K rows of tile t+1 are requested in front of tile t's score product and committed behind it, the V^T rows in front of the
-    //      softmax / second product and committed behind that (64-key tiles would not fit the register file with both in flight).
-    //      Thread -> (row tid / 8 [+ 32], 16-byte chunk tid % 8 [+ 8 j]): 128 contiguous bytes per row and instruction, and every
-    //      address of a tile is ONE per-thread offset plus wave-uniform / immediate terms (no address registers to keep alive) ----
-    static_assert(FA_BK == 64 && KCH <= 40 && DO <= 288, "staging map");
-    constexpr int KJ = (KCH + 7) / 8;                           // chunk groups per K row (5: the last one holds chunk 32 and the zero pad 33)
-    constexpr int VJ = (D + 31) / 32;                           // row groups of V^T (9: the last one rows 256 .. 263)
-    constexpr int SIT = 2 * KJ > VJ ? 2 * KJ : VJ;
-    uint4 stg[SIT];
-    const int srow = tid >> 3, sch = tid & 7;
-    const unsigned k_goff = (unsigned)(srow * a.ldq + sch * 8) * 2u, k_loff = (unsigned)(srow * KP + sch * 16);
-    const unsigned v_goff = (unsigned)(srow * a.ldv + sch * 8) * 2u, v_loff = (unsigned)(srow * VP + sch * 16);
-    // K rows past the utterance are clamped to its last row (their scores are masked), V^T columns past it are zeros (0 x junk)
-    auto load_k = [&](int k0) {
+    // ---- staging of one K / V^T tile by LDS-DMA (`buffer_load_dwordx4 ... lds`: no staging registers, no ds_write -- round 5: through
+    //      registers the 77 KiB of a tile cost ~1000 cycles of LDS store path and ~1200 of vector-memory issue per tile, serialised with
+    //      the lone wave's matrix steps).  An image is cut into 1-KiB pieces (64 lanes x 16 bytes, lane-linear in LDS); piece p, lane l is
+    //      16-byte slot g = 64 p + l of the padded image: K row g / 35, chunk g % 35 (chunk 33 = the zero pad of the depth, 34 = the row
+    //      pad); V^T row g / 9, chunk g % 9 (8 = the row pad).  Pad slots and rows past the tensor get an out-of-range offset (the
+    //      buffer descriptor's range check returns zeros).  Wave w owns pieces w, w + 4, ...; the lane offsets are tile-invariant (the
+    //      tile's first key goes into the descriptor's base).  ----
+    constexpr int KSL = KP / 16, VSL = VP / 16;                 // 16-byte slots per padded row: 35, 9
+    constexpr int KPC = FA_BK * KSL / 64, VPC = (D * VSL + 63) / 64;   // pieces per image: 35, 38
+    static_assert(FA_BK * KSL % 64 == 0 && KBYTES % 1024 == 0 && VPC * 1024 <= VBYTES, "DMA images");
+    constexpr int KPW = (KPC + 3) / 4, VPW = (VPC + 3) / 4, NDMA = KPW + VPW;   // pieces per wave: 9 + 10
+    int dk_off[KPW], dv_off[VPW];
 #pragma unroll
-        for (int g = 0; g < 2; g++) {
-            const int row = min(k0 + 32 * g + srow, len - 1) - srow;                                 // (uniform part + this thread's row)
-            const unsigned char* const base = (const unsigned char*)Kg + (long)row * a.ldq * 2;
-#pragma unroll
-            for (int j = 0; j < KJ; j++)
-                if (j * 8 + 7 < D / 8 || sch + j * 8 < D / 8) stg[g * KJ + j] = *(const uint4*)(base + k_goff + j * 128);
-        }
-    };
-    auto store_k = [&](int buf) {
-        unsigned char* const kb = lds + buf * (KBYTES + VBYTES) + k_loff;
-#pragma unroll
-        for (int g = 0; g < 2; g++)
-#pragma unroll
-            for (int j = 0; j < KJ; j++)
-                if (j * 8 + 7 < D / 8 || sch + j * 8 < D / 8) *(uint4*)(kb + g * 32 * KP + j * 128) = stg[g * KJ + j];
-    };
-    auto load_v = [&](int k0) {
-        const bool kok = k0 + sch * 8 < len;                                                          // len % 8 keys of a chunk: V^T columns [len, roundup8) are zeros in HBM
-        const unsigned char* const base = (const unsigned char*)Vg + (long)k0 * 2 + v_goff;
-#pragma unroll
-        for (int it = 0; it < VJ; it++) {
-            stg[it] = make_uint4(0, 0, 0, 0);
-            if (kok && (it * 32 + 31 < D || srow + it * 32 < D)) stg[it] = *(const uint4*)(base + (long)it * 32 * a.ldv * 2);
-        }
-    };
-    auto store_v = [&](int buf) {
-        unsigned char* const vb = lds + buf * (KBYTES + VBYTES) + KBYTES + v_loff;
-#pragma unroll
-        for (int it = 0; it < VJ; it++)
-            if (it * 32 + 31 < D || srow + it * 32 < D) *(uint4*)(vb + it * 32 * VP) = stg[it];
-    };
-    // the zero pad of the K rows' depth (chunk D / 8 .. KCH - 1: multiplied with Q's zero pad, must be finite) is written once
-    if (D / 8 < KCH) {
-        for (int i = tid; i < 2 * FA_BK * (KCH - D / 8); i += 256) {
-            const int buf = i / (FA_BK * (KCH - D / 8)), r = i % (FA_BK * (KCH - D / 8)), row = r / (KCH - D / 8), ch = D / 8 + r % (KCH - D / 8);
-            *(uint4*)(lds + buf * (KBYTES + VBYTES) + row * KP + ch * 16) = make_uint4(0, 0, 0, 0);
-        }
+    for (int i = 0; i < KPW; i++) {
+        const int pc = min(wave + 4 * i, KPC - 1), g = pc * 64 + lane, row = g / KSL, sl = g - row * KSL;    // (a surplus piece repeats the last one)
+        dk_off[i] = sl < D / 8 ? (row * a.ldq + sl * 8) * 2 : -16;
     }
+#pragma unroll
+    for (int i = 0; i < VPW; i++) {
+        const int pc = min(wave + 4 * i, VPC - 1), g = pc * 64 + lane, row = g / VSL, sl = g - row * VSL;
+        dv_off[i] = (sl < FA_BK / 8 && row < D) ? (row * a.ldv + sl * 8) * 2 : -16;
+    }
+    // descriptors of tile k0: K rows [k0, len) of this (utterance, head) -- rows at or past len are out of range --; V^T keys from k0 on,
+    // rows [0, D) through the end of the head's block (keys past len meet probabilities that are exactly zero: finite junk is harmless)
+    auto k_rsrc = [&](int k0) {
+        const unsigned long long pa = (unsigned long long)(Kg + (long)k0 * a.ldq);
+        const long rec = ((long)(len - k0 - 1) * a.ldq + D) * 2;
+        return (i32x4){__builtin_amdgcn_readfirstlane((int)(unsigned)pa), __builtin_amdgcn_readfirstlane((int)((pa >> 32) & 0xffff)),
+                       __builtin_amdgcn_readfirstlane((int)(rec > 0x7fffffff ? 0x7fffffff : (rec < 0 ? 0 : rec))), 0x00020000};
+    };
+    auto v_rsrc = [&](int k0) {
+        const unsigned long long pa = (unsigned long long)(Vg + k0);
+        const long rec = ((long)D * a.ldv - k0) * 2;
+        return (i32x4){__builtin_amdgcn_readfirstlane((int)(unsigned)pa), __builtin_amdgcn_readfirstlane((int)((pa >> 32) & 0xffff)),
+                       __builtin_amdgcn_readfirstlane((int)(rec > 0x7fffffff ? 0x7fffffff : (rec < 0 ? 0 : rec))), 0x00020000};
+    };
+    auto dma = [&](const i32x4& rs, int voff, unsigned la) __attribute__((always_inline)) {
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" :: "s"(la), "v"(voff), "s"(rs) : "memory", "m0");
+    };
+    // request j (0 .. NDMA - 1) of this wave for the tile whose descriptors are rk / rv, into buffer `buf`: K pieces first
+    auto dma_req = [&](auto jc, const i32x4& rk, const i32x4& rv, int buf) __attribute__((always_inline)) {
+        constexpr int j = decltype(jc)::value;
+        const unsigned b0 = lds_base + (unsigned)buf * (KBYTES + VBYTES);
+        if constexpr (j < KPW) dma(rk, dk_off[j], __builtin_amdgcn_readfirstlane(b0 + (unsigned)min(wave + 4 * j, KPC - 1) * 1024u));
+        else dma(rv, dv_off[j - KPW], __builtin_amdgcn_readfirstlane(b0 + KBYTES + (unsigned)min(wave + 4 * (j - KPW), VPC - 1) * 1024u));
+    };
 
     f32x16 o[NDB];
 #pragma unroll
@@ -184,12 +193,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     const float sc = a.scale * 1.4426950408889634f;             // exp(x) = exp2(x log2 e)
 
     const int ntiles = (len + FA_BK - 1) / FA_BK;
-    load_k(0); store_k(0);
-    load_v(0); store_v(0);
+#ifdef FA_PROFILE
+    unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
+#endif
+    {
+        const i32x4 rk = k_rsrc(0), rv = v_rsrc(0);
+        static_for<0, NDMA>([&](auto jc) { dma_req(jc, rk, rv, 0); });
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __syncthreads();
+    FA_STAMP(6);
     for (int t = 0; t < ntiles; t++) {
         const int k0 = t * FA_BK;
-        if (t + 1 < ntiles) load_k(k0 + FA_BK);                 // in flight under the score product
+        // the next tile's K rows and V^T rows go into the other buffer (last read before the previous tile's closing barrier); their NDMA
+        // requests per wave are issued BETWEEN the matrix steps of the score product (one per ~2 steps: the rate at which the CU's
+        // vector-memory path takes 1-KiB requests from four waves) and land under the softmax and the second product
+        const bool more = !(FA_EXP & 2) && t + 1 < ntiles;
+        const i32x4 rk = k_rsrc(more ? k0 + FA_BK : k0), rv = v_rsrc(more ? k0 + FA_BK : k0);
+        const int nbuf = (t + 1) & 1;
+        auto hook = [&](auto ic) __attribute__((always_inline)) {
+            constexpr int I = decltype(ic)::value, NS = FA_NKB * KS;
+            constexpr int j = I * NDMA / NS;
+            if constexpr (((I + 1) * NDMA) / NS > j) { if (more) dma_req(std::integral_constant<int, j>{}, rk, rv, nbuf); }
+        };
         const unsigned char* const kb = lds + (t & 1) * (KBYTES + VBYTES);
         const unsigned char* const vb = kb + KBYTES;
 
@@ -199,9 +225,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         for (int kbk = 0; kbk < FA_NKB; kbk++)
 #pragma unroll
             for (int e = 0; e < 16; e++) s[kbk][e] = 0.f;
-        fa_chain<3, KS, 32 * KP, F16, FA_NKB>(lds_base + (unsigned)(kb - lds) + (unsigned)(l32 * KP + hi * 16), s, qf);
+        FA_STAMP(0);
+        if (!(FA_EXP & 8)) fa_chain<3, KS, 32 * KP, F16, FA_NKB>(lds_base + (unsigned)(kb - lds) + (unsigned)(l32 * KP + hi * 16), s, qf, hook);
         // the other buffer's K half: last read in tile t-1's score product, behind that tile's closing barrier
-        if (t + 1 < ntiles) { store_k((t + 1) & 1); load_v(k0 + FA_BK); }
+        FA_STAMP(1);
+        FA_STAMP(2);
         // ---- online softmax over this lane's 32 keys (+ the partner lane's 32): key of element (kbk, g, e) = 32 kbk + 8 g + 4 hi + e ----
         // the scores stay unscaled: p = exp2(s * sc - m) is one fma in front of v_exp_f32, the running max is kept in scaled units
         if (k0 + FA_BK > len) {                                     // wave-uniform: only an utterance's last tile has keys to mask
@@ -259,10 +287,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
                 pf[2 * kbk + tt] = make_uint4(a0, a1, b0, b1);
             }
         // ---- O^T += V^T.P^T ----
-        fa_chain<3, 2 * FA_NKB, 32 * VP, F16, NDB>(lds_base + (unsigned)(vb - lds) + (unsigned)(l32 * VP + hi * 16), o, pf);
-        if (t + 1 < ntiles) store_v((t + 1) & 1);               // the other buffer's V^T half: last read in tile t-1
+        FA_STAMP(3);
+        if (!(FA_EXP & 4)) fa_chain<3, 2 * FA_NKB, 32 * VP, F16, NDB>(lds_base + (unsigned)(vb - lds) + (unsigned)(l32 * VP + hi * 16), o, pf);
+        FA_STAMP(4);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the next tile's pieces have landed (requested a whole softmax + second product ago)
+        FA_STAMP(5);
         __syncthreads();
+        FA_STAMP(7);
     }
+#ifdef FA_PROFILE
+    if (a.prof && blockIdx.x == 0 && tid == 0) for (int k = 0; k < 8; k++) a.prof[k] = (long long)tacc[k];
+#endif
     // ---- out[q][h D + d] = O[d][q] / l ----
     const float inv = 1.0f / (l_run + __shfl_xor(l_run, 32, 64));
     if (q < len) {

@@ -21,6 +21,7 @@
 // Global loads of K-step s+1 are issued before the MFMAs of step s and written to the other LDS buffer
 // afterwards (one barrier per step).  blockIdx is remapped so each XCD walks a contiguous tile range
 // (all channel tiles of a time tile share that XCD's L2).
+#include "mfma_util.h"
 #include "zvx_kernels.h"
 
 #include <hip/hip_ext.h>
@@ -38,10 +39,6 @@ static thread_local bool g_dry_run = false;     // gemm_variant_of(): walk the l
 
 namespace zvx {
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
-typedef __attribute__((ext_vector_type(16))) float f32x16;
-typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;   // native vector: usable as a tied ("+v") inline-asm operand
 
 #define PITCH 80      // bytes per LDS row: 64 B of K + 16 B pad
 #define KBYTES 64
@@ -65,11 +62,20 @@ __device__ __forceinline__ void load4(const void* base, long idx, float v[4]) {
     }
 }
 __device__ __forceinline__ void load4_dyn(const void* base, int dt, long idx, float v[4]) {
-    if (dt == DT_F32) load4<DT_F32>(base, idx, v); else load4<DT_BF16>(base, idx, v);
+    if (dt == DT_F32) load4<DT_F32>(base, idx, v);
+    else if (dt == DT_F16) {
+        const uint2 t = *(const uint2*)((const unsigned short*)base + idx);
+        const f32x2 a = unpack_f16x2(t.x), b = unpack_f16x2(t.y);
+        v[0] = a.x; v[1] = a.y; v[2] = b.x; v[3] = b.y;
+    } else load4<DT_BF16>(base, idx, v);
 }
 __device__ __forceinline__ void store4_dyn(void* base, int dt, long idx, const float v[4]) {
     if (dt == DT_F32) {
         *(float4*)((float*)base + idx) = make_float4(v[0], v[1], v[2], v[3]);
+    } else if (dt == DT_F16) {
+        uint2 t;
+        t.x = pack_f16x2_sat(v[0], v[1]); t.y = pack_f16x2_sat(v[2], v[3]);
+        *(uint2*)((unsigned short*)base + idx) = t;
     } else {
         uint2 t;
         t.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
@@ -267,6 +273,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs a) {
                     if (DT == DT_BF16) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(
                             __builtin_bit_cast(bf16x8, wf[i]), __builtin_bit_cast(bf16x8, xf[j]), acc[i][j], 0, 0, 0);
+                    } else if (DT == DT_F16) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(
+                            __builtin_bit_cast(f16x8, wf[i]), __builtin_bit_cast(f16x8, xf[j]), acc[i][j], 0, 0, 0);
                     } else {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(wf[i].x), __uint_as_float(xf[j].x), acc[i][j], 0, 0, 0);
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(__uint_as_float(wf[i].y), __uint_as_float(xf[j].y), acc[i][j], 0, 0, 0);
@@ -289,25 +298,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs a) {
 // to a handful of VALU ops (all mode switches are wave-uniform branches OUTSIDE the element loops; leaky-relu = max(x, s*x),
 // its inverse = min(y, y/s); bf16 packing via the hardware RNE convert): with two waves per SIMD the epilogue is otherwise
 // VALU-bound (measured 27k cycles per tile for the branchy per-element version vs 7k for the LDS transposes).
-__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
-    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
-    bf16x2_t v = {(__bf16)lo, (__bf16)hi};                 // v_cvt_pk_bf16_f32 on gfx950 (round-to-nearest-even)
-    return __builtin_bit_cast(unsigned, v);
-}
-
-typedef float f32x2 __attribute__((ext_vector_type(2)));      // float pairs: v_pk_add_f32 / v_pk_mul_f32 (two elements per VALU slot)
-__device__ __forceinline__ f32x2 unpack_bf16x2(unsigned u) { return (f32x2){__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u)}; }
-// DT_F16 tensors (the StyleTTS decoder): round-to-nearest-even converts, saturating instead of overflowing to Inf
-typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ unsigned pack_f16x2(float lo, float hi) {
-    const f16x2_t v = {(_Float16)__builtin_amdgcn_fmed3f(lo, -65504.f, 65504.f), (_Float16)__builtin_amdgcn_fmed3f(hi, -65504.f, 65504.f)};   // 2 v_med3_f32 + v_cvt_pk_f16_f32
-    return __builtin_bit_cast(unsigned, v);
-}
-__device__ __forceinline__ f32x2 unpack_f16x2(unsigned u) { const f16x2_t v = __builtin_bit_cast(f16x2_t, u); return (f32x2){(float)v.x, (float)v.y}; }
-__device__ __forceinline__ unsigned pack16x2(float lo, float hi, bool f16) { return f16 ? pack_f16x2(lo, hi) : pack_bf16x2(lo, hi); }
+// (pack_bf16x2 / unpack_bf16x2 / lrelu2 / inv_lrelu2 and the IEEE-half helpers: mfma_util.h)
+// run-time 16-bit dtype switch of the run-time epilogue (the kernel has NOT set MODE.FP16_OVFL there: saturating converts)
+__device__ __forceinline__ unsigned pack_f16x2(float lo, float hi) { return pack_f16x2_sat(lo, hi); }
+__device__ __forceinline__ unsigned pack16x2(float lo, float hi, bool f16) { return f16 ? pack_f16x2_sat(lo, hi) : pack_bf16x2(lo, hi); }
 __device__ __forceinline__ f32x2 unpack16x2(unsigned u, bool f16) { return f16 ? unpack_f16x2(u) : unpack_bf16x2(u); }
-__device__ __forceinline__ f32x2 lrelu2(f32x2 v, float slope) { const f32x2 m = v * slope; return (f32x2){fmaxf(v.x, m.x), fmaxf(v.y, m.y)}; }     // 0 <= slope <= 1
-__device__ __forceinline__ f32x2 inv_lrelu2(f32x2 y, float inv_slope) { const f32x2 m = y * inv_slope; return (f32x2){fminf(y.x, m.x), fminf(y.y, m.y)}; }  // inv_slope >= 1
 
 // Epilogue modes known at compile time (EPI >= 0) cover the HiFi-GAN convolutions: alpha = 1, per-channel bias, bf16
 // output (or none), activation none / leaky-relu, bf16 residual in the activated domain, bf16 running sum.
@@ -315,8 +310,12 @@ __device__ __forceinline__ f32x2 inv_lrelu2(f32x2 y, float inv_slope) { const f3
 // EPI < 0: everything is read from GemmArgs at run time (decoder GEMMs, f32 outputs, per-row bias, ...).  A run-time
 // switch costs more than its branches: hipcc merges the `s_waitcnt vmcnt` of the untaken paths' loads into every launch.
 #define ZVX_EPI(res, am, out) ((res) | ((am) << 1) | ((out) << 3))
+// ... and (round 5) the mel decoders' residual convolutions: alpha = 1, bias per channel or none, RAW 16-bit residual (res = 1) or none,
+// result x out_scale, no activation, 16-bit output -- (conv2(t) [+ shortcut] [+ x]) / sqrt(2) of a StyleTTS residual block
+#define ZVX_EPI_DEC(res) (16 | 8 | (res))
+// H16 (compile-time modes only): the 16-bit tensors are IEEE half and the KERNEL has set MODE.FP16_OVFL (f16_saturate_mode): plain converts
 
-template <int TM, int TN, int RES_LDS = 0, int EPI = -1>   // RES_LDS: residual source: 0 global memory, 1 padded LDS slab
+template <int TM, int TN, int RES_LDS = 0, int EPI = -1, bool H16 = false>   // RES_LDS: residual source: 0 global memory, 1 padded LDS slab
 __device__ __forceinline__ void epilogue_rows(const GemmArgs& a, f32x16 (&acc)[TN][TM], int b, int row_base, int col_base,
                                               int out_len, int lane, unsigned char* stage /* >= 32*(TN*32*4+16) bytes, this wave's */,
                                               const unsigned char* res_lds = nullptr /* RES_LDS 1: LDS row of output row `row_base` */,
@@ -327,20 +326,26 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs& a, f32x16 (&acc)[T
     constexpr int RPP = 64 / LPR;               // rows per pass
     constexpr int NP = 32 / RPP;
     constexpr bool CT = EPI >= 0;
-    constexpr bool BURST = !(CT && ((EPI >> 1) & 1));       // xs-reading modes hold more registers: store each row block at once
+    constexpr bool DEC = CT && (EPI & 16) != 0;             // the decoders' residual form (ZVX_EPI_DEC)
+    constexpr bool BURST = !(CT && !DEC && ((EPI >> 1) & 1));       // xs-reading modes hold more registers: store each row block at once
     const long ooff = (long)b * a.o_bs, roff = (long)b * a.r_bs, aoff = (long)b * a.a_bs;
     const int c8 = lane % LPR;
     const int n = col_base + c8 * 8;
     const bool nok = n < a.N;
     // mode words: compile-time constants or wave-uniform run-time values, read once
     const float alpha = CT ? 1.f : a.alpha, oscale = a.out_scale, rinv = a.res_inv_slope;
-    const int act = CT ? ACT_LRELU : a.act;
+    const int act = DEC ? ACT_NONE : (CT ? ACT_LRELU : a.act);
     const float slope = CT ? (a.act == ACT_LRELU ? a.slope : 1.f) : a.slope;        // CT: slope 1 = no activation
-    const int res_mode = RES_LDS ? 2 : (CT ? ((EPI & 1) ? 2 : 0) : a.res_mode);
-    const int accum_mode = CT ? (EPI >> 1) & 3 : a.accum_mode, bias_mode = CT ? 1 : a.bias_mode;
+    const int res_mode = RES_LDS ? 2 : (DEC ? (EPI & 1) : (CT ? ((EPI & 1) ? 2 : 0) : a.res_mode));
+    const int accum_mode = DEC ? 0 : (CT ? (EPI >> 1) & 3 : a.accum_mode), bias_mode = (CT && !DEC) ? 1 : a.bias_mode;
     const bool has_out = CT ? (EPI >> 3) & 1 : a.out != nullptr, out_bf16 = CT || a.out_dtype != DT_F32, has_post = !CT && a.post_scale != nullptr;
-    const bool acc_bf16 = CT || a.accum_dtype == DT_BF16, res_bf16 = CT || RES_LDS || a.res_dtype != DT_F32;
-    const bool out_f16 = !CT && a.out_dtype == DT_F16, res_f16 = !CT && !RES_LDS && a.res_dtype == DT_F16;    // ("bf16" above reads "16-bit")
+    // (run-time epilogue: a half running sum on every shape but the 256 x 128 / 128 x 256 tiles -- those sit exactly at 256 registers,
+    // even the comparison `accum_dtype != DT_F32` instead of `== DT_BF16` made them spill 24; launch_convslab refuses the combination,
+    // which no shape of the path asks for)
+    const bool out_f16 = CT ? H16 : a.out_dtype == DT_F16, res_f16 = (CT || RES_LDS) ? H16 : a.res_dtype == DT_F16, acc_f16 = CT ? H16 : ((TN == 1 || TM <= 2) && a.accum_dtype == DT_F16);
+    const bool acc_bf16 = CT || a.accum_dtype == DT_BF16 || acc_f16, res_bf16 = CT || RES_LDS || a.res_dtype != DT_F32;     // ("bf16" here reads "16-bit")
+    // 16-bit packing of a result pair: in the compile-time half modes the kernel runs with saturating converts (no clamp instructions)
+#define pk2(lo, hi, f16) ((CT && H16) ? pack_f16x2_raw(lo, hi) : pack16x2(lo, hi, f16))
     f32x2 bcol[4];
 #pragma unroll
     for (int e = 0; e < 4; e++) bcol[e] = (f32x2){0.f, 0.f};
@@ -432,7 +437,7 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs& a, f32x16 (&acc)[T
             }
             if (accum_mode & 1) {
                 if (acc_bf16) {
-                    t[0] += unpack_bf16x2(aab[p].x); t[1] += unpack_bf16x2(aab[p].y); t[2] += unpack_bf16x2(aab[p].z); t[3] += unpack_bf16x2(aab[p].w);
+                    t[0] += unpack16x2(aab[p].x, acc_f16); t[1] += unpack16x2(aab[p].y, acc_f16); t[2] += unpack16x2(aab[p].z, acc_f16); t[3] += unpack16x2(aab[p].w, acc_f16);
                 } else {
                     t[0] += (f32x2){aa0[p].x, aa0[p].y}; t[1] += (f32x2){aa0[p].z, aa0[p].w};
                     t[2] += (f32x2){aa1[p].x, aa1[p].y}; t[3] += (f32x2){aa1[p].z, aa1[p].w};
@@ -442,7 +447,7 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs& a, f32x16 (&acc)[T
                 const long ai = aoff + (long)r * a.lda + n;
                 if (acc_bf16) {
                     *(u32x4*)((unsigned short*)a.accum + ai) =
-                        (u32x4){pack_bf16x2(t[0].x, t[0].y), pack_bf16x2(t[1].x, t[1].y), pack_bf16x2(t[2].x, t[2].y), pack_bf16x2(t[3].x, t[3].y)};
+                        (u32x4){pk2(t[0].x, t[0].y, acc_f16), pk2(t[1].x, t[1].y, acc_f16), pk2(t[2].x, t[2].y, acc_f16), pk2(t[3].x, t[3].y, acc_f16)};
                 } else {
                     float* ap = (float*)a.accum + ai;
                     *(float4*)ap = make_float4(t[0].x, t[0].y, t[1].x, t[1].y);
@@ -450,7 +455,7 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs& a, f32x16 (&acc)[T
                 }
             }
             if (has_out) {
-                if (CT ? accum_mode != 0 : oscale != 1.f) {      // compile-time modes: only the xs-closing launch scales
+                if (DEC || (CT ? accum_mode != 0 : oscale != 1.f)) {      // compile-time modes: only the xs-closing launch (and the decoders' form) scales
 #pragma unroll
                     for (int e = 0; e < 4; e++) t[e] *= oscale;
                 }
@@ -468,7 +473,7 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs& a, f32x16 (&acc)[T
                     t[2] = t[2] * (f32x2){s1.x, s1.y} + (f32x2){h1.x, h1.y}; t[3] = t[3] * (f32x2){s1.z, s1.w} + (f32x2){h1.z, h1.w};
                 }
                 if (out_bf16) {
-                    const u32x4 o = (u32x4){pack16x2(t[0].x, t[0].y, out_f16), pack16x2(t[1].x, t[1].y, out_f16), pack16x2(t[2].x, t[2].y, out_f16), pack16x2(t[3].x, t[3].y, out_f16)};
+                    const u32x4 o = (u32x4){pk2(t[0].x, t[0].y, out_f16), pk2(t[1].x, t[1].y, out_f16), pk2(t[2].x, t[2].y, out_f16), pk2(t[3].x, t[3].y, out_f16)};
                     if (BURST) pk[j][p] = o;
                     else if (ok[p]) *(u32x4*)((unsigned short*)a.out + ooff + (long)r * a.ldo + n) = o;
                 } else if (ok[p]) {
@@ -509,6 +514,7 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs& a, f32x16 (&acc)[T
                 if (r < a.M && r < out_len && nok) *(u32x4*)(obase + (long)r * ldo) = pk[j][p];
             }
     }
+#undef pk2
 }
 
 // Epilogue for "bias + activation -> bf16" with nothing to read (EPI = ZVX_EPI(0, 0, 1): conv1 of a ResBlock pair,
@@ -618,6 +624,7 @@ __global__ __launch_bounds__(256, MINW) void convslab_kernel(const GemmArgs a) {
     constexpr int NIT = ((BM + MAXH) * 8 + 255) / 256;    // staging iterations (halo_l + halo_r <= MAXH rows)
     static_assert(WM * WN == 4, "4 waves");
     extern __shared__ __attribute__((aligned(16))) unsigned char slab[];
+    if (F16 && EPI >= 0 && EPI != ZVX_EPI(0, 0, 1)) f16_saturate_mode();   // compile-time half epilogues convert without clamps (mfma_util.h)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: SGPR arithmetic, scalar branches
     const int wr = wave % WM, wc = wave / WM;
@@ -853,7 +860,7 @@ __global__ __launch_bounds__(256, MINW) void convslab_kernel(const GemmArgs a) {
     if (EPI == ZVX_EPI(0, 0, 1))
         epilogue_direct<TM, TN, F16>(a, acc, b, m0 + wr * (BM / WM), n0 + wc * (BN / WN), out_len, lane, slab + wave * (32 * (TN * 64 + 16)));
     else
-        epilogue_rows<TM, TN, 0, EPI>(a, acc, b, m0 + wr * (BM / WM), n0 + wc * (BN / WN), out_len, lane, slab + wave * (32 * (TN * 32 * 4 + 16)));
+        epilogue_rows<TM, TN, 0, EPI, (F16 && EPI >= 0)>(a, acc, b, m0 + wr * (BM / WM), n0 + wc * (BN / WN), out_len, lane, slab + wave * (32 * (TN * 32 * 4 + 16)));
 }
 
 // ================================================================================================
@@ -863,7 +870,7 @@ __global__ __launch_bounds__(256, MINW) void convslab_kernel(const GemmArgs a) {
 // packed stream) and the main loop is nothing but ds_read_b128 of the LDS slab + MFMA: no weight traffic,
 // no waits on global memory, no barrier between the slab fill and the epilogue.
 // ================================================================================================
-template <int C, int NT, int BM, int WM, int WN, int MINW, int MAXH = 64>
+template <int C, int NT, int BM, int WM, int WN, int MINW, int MAXH = 64, bool F16 = false>
 __global__ __launch_bounds__(256, MINW) void convreg_kernel(const GemmArgs a) {
     constexpr int TM = BM / WM / 32;
     constexpr int KS = C / 16;                           // k16 steps per tap
@@ -937,8 +944,7 @@ __global__ __launch_bounds__(256, MINW) void convreg_kernel(const GemmArgs a) {
 #pragma unroll
             for (int j = 0; j < TM; j++) {
                 const uint4 xf = *(const uint4*)(rowp + j * 32 * PITCH_ + kk * 32);
-                acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w[t][kk]), __builtin_bit_cast(bf16x8, xf),
-                                                                   acc[0][j], 0, 0, 0);
+                acc[0][j] = mfma16<F16>(w[t][kk], xf, acc[0][j]);
             }
     }
     __syncthreads();
@@ -951,13 +957,22 @@ static bool launch_convreg_c(const GemmArgs& a, hipStream_t stream) {
     size_t lds = (size_t)(BM + a.halo_l + a.halo_r) * (C * 2 + 16);
     const size_t stage = (size_t)4 * 32 * (32 * 4 + 16);
     if (lds < stage) lds = stage;
-    if (a.flat_win) {                                     // 3 x 3 over a flattened map: halo = flat_win + 1 rows either side
+    if (a.flat_win) {                                     // 3 x 3 over a flattened map: halo = flat_win + 1 rows either side (speaker encoder: bf16)
+        if (a.dtype != DT_BF16) return false;
         if (a.ntaps != 9 || a.halo_l + a.halo_r > 544 || lds > 160 * 1024) return false;
         auto kfn = convreg_kernel<C, 9, BM, WM, WN, MINW, 544>;
         static std::atomic<bool> attr_done{false};
         if (!attr_done) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_done = true; }
         ZVX_LAUNCH(kfn, grid, dim3(256), lds, stream, a);
         return true;
+    }
+    if (a.dtype == DT_F16) {
+        switch (a.ntaps) {
+            case 3: ZVX_LAUNCH((convreg_kernel<C, 3, BM, WM, WN, MINW, 64, true>), grid, dim3(256), lds, stream, a); return true;
+            case 7: ZVX_LAUNCH((convreg_kernel<C, 7, BM, WM, WN, MINW, 64, true>), grid, dim3(256), lds, stream, a); return true;
+            case 11: ZVX_LAUNCH((convreg_kernel<C, 11, BM, WM, WN, MINW, 64, true>), grid, dim3(256), lds, stream, a); return true;
+        }
+        return false;
     }
     switch (a.ntaps) {
         case 3: ZVX_LAUNCH((convreg_kernel<C, 3, BM, WM, WN, MINW>), grid, dim3(256), lds, stream, a); return true;
@@ -974,7 +989,7 @@ static bool launch_convreg_c(const GemmArgs& a, hipStream_t stream) {
 // leaves the CU, which removes 3 of the 5 HBM passes of the unfused pair.  Weights of both convs live in
 // registers (conv2's are fetched while conv1's results are written to LDS).
 // ================================================================================================
-template <int C, int NT, int BM, int WM, int WN, int MINW>
+template <int C, int NT, int BM, int WM, int WN, int MINW, bool F16 = false>
 __global__ __launch_bounds__(256, MINW) void resfuse_kernel(const GemmArgs a) {
     constexpr int TM = BM / WM / 32;
     constexpr int KS = C / 16;
@@ -1050,8 +1065,7 @@ __global__ __launch_bounds__(256, MINW) void resfuse_kernel(const GemmArgs a) {
 #pragma unroll
             for (int j = 0; j < TM; j++) {
                 const uint4 xf = *(const uint4*)(rowp + j * 32 * PITCH_ + kk * 32);
-                acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w[t][kk]), __builtin_bit_cast(bf16x8, xf),
-                                                                   acc[0][j], 0, 0, 0);
+                acc[0][j] = mfma16<F16>(w[t][kk], xf, acc[0][j]);
             }
             if (!TWO_SETS) w[t][kk] = W2q[(t * 4 + kk) * 64];        // conv2's fragment takes the freed register
         }
@@ -1070,8 +1084,11 @@ __global__ __launch_bounds__(256, MINW) void resfuse_kernel(const GemmArgs a) {
 #pragma unroll
             for (int e = 0; e < 4; e++) { v[e] = v[e] >= 0.f ? v[e] : v[e] * a.slope1; if (!inside) v[e] = 0.f; }
             uint2 pk;
-            pk.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
-            pk.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+            if (F16) { pk.x = pack_f16x2_sat(v[0], v[1]); pk.y = pack_f16x2_sat(v[2], v[3]); }
+            else {
+                pk.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
+                pk.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+            }
             *(uint2*)(t1 + i * PITCH_ + co * 2) = pk;
         }
     }
@@ -1089,14 +1106,13 @@ __global__ __launch_bounds__(256, MINW) void resfuse_kernel(const GemmArgs a) {
 #pragma unroll
             for (int j = 0; j < TM; j++) {
                 const uint4 xf = *(const uint4*)(rowp + j * 32 * PITCH_ + kk * 32);
-                acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, TWO_SETS ? w2[TWO_SETS ? t : 0][TWO_SETS ? kk : 0] : w[t][kk]),
-                                                                   __builtin_bit_cast(bf16x8, xf), acc[0][j], 0, 0, 0);
+                acc[0][j] = mfma16<F16>(TWO_SETS ? w2[TWO_SETS ? t : 0][TWO_SETS ? kk : 0] : w[t][kk], xf, acc[0][j]);
             }
     }
     __syncthreads();                                       // T1 is dead: its area becomes the transpose stage
     const int lim = (m0 + BMO < out_len) ? m0 + BMO : out_len;
     // residual x = inverse-lrelu of the slab rows of this tile (output row j <-> slab row j + H2 + H1): no global re-read
-    epilogue_rows<TM, 1, 1>(a, acc, b, m0 + wrow, wc * 32, lim, lane, t1 + wave * (32 * (32 * 4 + 16)),
+    epilogue_rows<TM, 1, 1, -1, F16>(a, acc, b, m0 + wrow, wc * 32, lim, lane, t1 + wave * (32 * (32 * 4 + 16)),
                                slab + (wrow + H2 + H1) * PITCH_, PITCH_);
 }
 
@@ -1118,8 +1134,9 @@ __global__ __launch_bounds__(256, MINW) void resfuse_kernel(const GemmArgs a) {
 // AM = accum_mode (bit0: += xs, bit1: xs = result), HAS_OUT: a bf16 output is written (act = leaky-relu with a.slope, or none).
 // Compile-time, because a run-time mode switch inside the epilogue makes hipcc merge the paths' `s_waitcnt vmcnt`s
 // (accumulator loads) into every launch, where they then wait for the previous tile's stores.
-template <int C, int NT, int AM, bool HAS_OUT, int TM>
+template <int C, int NT, int AM, bool HAS_OUT, int TM, bool F16 = false>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void resfuse_persist_kernel(const GemmArgs a, int ntm, int ntiles) {
+    if (F16) f16_saturate_mode();                          // the 16-bit tensors are IEEE half: f32 -> f16 converts clamp to +-65504 (mfma_util.h)
     // C = 16 / 8 (HiFi-GAN V2's last stages): one half-empty 32-channel tile per wave, and for C = 8 a k16 step whose
     // second 8-channel half is the (zeroed) pad slot of the row -- these stages are HBM-bound, the idle MFMA rows are free
     constexpr int KS = C >= 16 ? C / 16 : 1, CPR = C / 8, NTL = C >= 32 ? C / 32 : 1, RG = 4 / NTL;
@@ -1128,8 +1145,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     constexpr int H2 = (NT - 1) / 2, BMO = BM1 - 2 * H2;  // output rows per tile
     constexpr int P = C * 2 + 16, CPP = CPR + 1;          // padded row pitch (conflict-free b128 reads), 16-byte slots per row
     constexpr int NW = NT * KS;
-    constexpr bool LEAN = NW > 36;                        // C = 64, k = 11: 44 fragments per wave -> 36 resident, register-lean epilogue
-    constexpr int NRES = LEAN ? 36 : NW; // fragments per wave / of those resident in registers (the rest: re-read from L2 per tile)
+    constexpr bool LEAN = NW > 36 || (F16 && NW >= 28 && TM == 2 && (AM & 1) && HAS_OUT);   // C = 64, k = 11: 44 fragments per wave -> 36 resident, register-lean epilogue (half, C = 64, k = 7, running sum read + an output: lean too)
+    constexpr int NRES = LEAN ? (NW < 36 ? NW : 36) : NW; // fragments per wave / of those resident in registers (the rest: re-read from L2 per tile)
     typedef __attribute__((ext_vector_type(4))) int i32x4;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 
@@ -1269,8 +1286,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                         const f32x2 v01 = lrelu2((f32x2){acc[0][j][4 * q], acc[0][j][4 * q + 1]} + (f32x2){bb.x, bb.y}, slope1);
                         const f32x2 v23 = lrelu2((f32x2){acc[0][j][4 * q + 2], acc[0][j][4 * q + 3]} + (f32x2){bb.z, bb.w}, slope1);
                         uint2 pk;
-                        pk.x = inside ? pack_bf16x2(v01.x, v01.y) : 0u;
-                        pk.y = inside ? pack_bf16x2(v23.x, v23.y) : 0u;
+                        pk.x = inside ? pack16<F16>(v01.x, v01.y) : 0u;
+                        pk.y = inside ? pack16<F16>(v23.x, v23.y) : 0u;
                         *(uint2*)(t1 + i * P + co * 2) = pk;
                     }
                 }
@@ -1291,8 +1308,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
                         for (int j = 0; j < TM; j++) {
                             const uint4 xf = *(const uint4*)(rowp + j * 32 * P + kk * 32);
-                            acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf), __builtin_bit_cast(bf16x8, xf),
-                                                                               acc[0][j], 0, 0, 0);
+                            acc[0][j] = mfma16<F16>(wf, xf, acc[0][j]);
                         }
                     }
                 }
@@ -1313,8 +1329,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
                     for (int j = 0; j < TM; j++) {
                         const uint4 xf = *(const uint4*)(rowp + (t + j * 32) * P + kk * 32);
-                        acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wf), __builtin_bit_cast(bf16x8, xf),
-                                                                           acc[0][j], 0, 0, 0);
+                        acc[0][j] = mfma16<F16>(wf, xf, acc[0][j]);
                     }
                 }
             const int lim_rows = (qA.m0 + BMO < qA.out_len) ? qA.m0 + BMO : qA.out_len;
@@ -1365,12 +1380,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     for (int q = 0; q < QN; q++) {
                         const float4 bq_ = LEAN ? *(const float4*)(bias2_l + wc * 32 + 8 * q + h4) : bb[LEAN ? 0 : q];
                         const uint2 rq_ = LEAN ? *(const uint2*)(resp + j * 32 * P + q * 16) : rrj[LEAN ? 0 : q];
-                        f32x2 v01 = (f32x2){acc[0][j][4 * q], acc[0][j][4 * q + 1]} + (f32x2){bq_.x, bq_.y} + inv_lrelu2(unpack_bf16x2(rq_.x), rinv);
-                        f32x2 v23 = (f32x2){acc[0][j][4 * q + 2], acc[0][j][4 * q + 3]} + (f32x2){bq_.z, bq_.w} + inv_lrelu2(unpack_bf16x2(rq_.y), rinv);
+                        f32x2 v01 = (f32x2){acc[0][j][4 * q], acc[0][j][4 * q + 1]} + (f32x2){bq_.x, bq_.y} + inv_lrelu2(unpack16<F16>(rq_.x), rinv);
+                        f32x2 v23 = (f32x2){acc[0][j][4 * q + 2], acc[0][j][4 * q + 3]} + (f32x2){bq_.z, bq_.w} + inv_lrelu2(unpack16<F16>(rq_.y), rinv);
                         if (!AM) { v01 = lrelu2(v01, slope); v23 = lrelu2(v23, slope); }      // slope 1 = no activation
                         uint2 pq;
-                        pq.x = pack_bf16x2(v01.x, v01.y);
-                        pq.y = pack_bf16x2(v23.x, v23.y);
+                        pq.x = pack16<F16>(v01.x, v01.y);
+                        pq.y = pack16<F16>(v23.x, v23.y);
                         if (LEAN) *(uint2*)(stage + (lane & 31) * 80 + (8 * q + h4) * 2) = pq;
                         else pk[LEAN ? 0 : q] = pq;
                     }
@@ -1386,18 +1401,18 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     for (int h = 0; h < 2; h++) {
                         const int gr = qA.m0 + wrow + j * 32 + h * 16 + (lane >> 2);
                         if (AM) {
-                            f32x2 t[4] = {unpack_bf16x2(o[h].x), unpack_bf16x2(o[h].y), unpack_bf16x2(o[h].z), unpack_bf16x2(o[h].w)};
+                            f32x2 t[4] = {unpack16<F16>(o[h].x), unpack16<F16>(o[h].y), unpack16<F16>(o[h].z), unpack16<F16>(o[h].w)};
                             if (AM & 1) {
-                                t[0] += unpack_bf16x2(xs[j][h].x); t[1] += unpack_bf16x2(xs[j][h].y);
-                                t[2] += unpack_bf16x2(xs[j][h].z); t[3] += unpack_bf16x2(xs[j][h].w);
+                                t[0] += unpack16<F16>(xs[j][h].x); t[1] += unpack16<F16>(xs[j][h].y);
+                                t[2] += unpack16<F16>(xs[j][h].z); t[3] += unpack16<F16>(xs[j][h].w);
                             }
                             if ((AM & 2) && gr < lim)
-                                *(u32x4*)(accp + (long)gr * a.lda) = (u32x4){pack_bf16x2(t[0].x, t[0].y), pack_bf16x2(t[1].x, t[1].y),
-                                                                            pack_bf16x2(t[2].x, t[2].y), pack_bf16x2(t[3].x, t[3].y)};
+                                *(u32x4*)(accp + (long)gr * a.lda) = (u32x4){pack16<F16>(t[0].x, t[0].y), pack16<F16>(t[1].x, t[1].y),
+                                                                            pack16<F16>(t[2].x, t[2].y), pack16<F16>(t[3].x, t[3].y)};
                             if (HAS_OUT) {
 #pragma unroll
                                 for (int e = 0; e < 4; e++) t[e] = lrelu2(t[e] * oscale, slope);
-                                o[h] = make_uint4(pack_bf16x2(t[0].x, t[0].y), pack_bf16x2(t[1].x, t[1].y), pack_bf16x2(t[2].x, t[2].y), pack_bf16x2(t[3].x, t[3].y));
+                                o[h] = make_uint4(pack16<F16>(t[0].x, t[0].y), pack16<F16>(t[1].x, t[1].y), pack16<F16>(t[2].x, t[2].y), pack16<F16>(t[3].x, t[3].y));
                             }
                         }
                         if (HAS_OUT && gr < lim) *(uint4*)(outp + (long)gr * a.ldo) = o[h];
@@ -1425,12 +1440,12 @@ static bool launch_resfuse_persist_c(const GemmArgs& a, hipStream_t stream) {
     const size_t lds = 4 * sb + 2 * tb + 4 * 32 * 80 + 2 * C * 4 + 2 * 128 * 4;
     if (lds > 160 * 1024) return false;
     // the in-kernel epilogue covers exactly what the vocoder asks for
-    if (a.alpha != 1.f || a.bias_mode != 1 || a.post_scale || (a.out && a.out_dtype != DT_BF16) || a.res_mode != 2 || a.ldo % 8 || (a.accum && (a.lda % 8 || a.accum_dtype != DT_BF16))) return false;
+    if (a.alpha != 1.f || a.bias_mode != 1 || a.post_scale || (a.out && a.out_dtype != a.dtype) || a.res_mode != 2 || a.res_dtype != a.dtype || a.ldo % 8 || (a.accum && (a.lda % 8 || a.accum_dtype != a.dtype))) return false;
     if (a.act != ACT_NONE && a.act != ACT_LRELU) return false;
     if (!a.accum_mode && a.out_scale != 1.f) return false;
     const int am = a.accum ? a.accum_mode : 0;
     if (!a.out && !(am & 2)) return false;
-#define ZVX_RFP(NT_, AM_, HO_) ZVX_LAUNCH((resfuse_persist_kernel<C, NT_, AM_, HO_, TM>), grid, dim3(512), lds, stream, a, ntm, ntiles); return true
+#define ZVX_RFP(NT_, AM_, HO_) if (a.dtype == DT_F16) ZVX_LAUNCH((resfuse_persist_kernel<C, NT_, AM_, HO_, TM, true>), grid, dim3(512), lds, stream, a, ntm, ntiles); else ZVX_LAUNCH((resfuse_persist_kernel<C, NT_, AM_, HO_, TM>), grid, dim3(512), lds, stream, a, ntm, ntiles); return true
 #define ZVX_RFP_MODE(NT_) \
     if (a.out) { if (am == 0) { ZVX_RFP(NT_, 0, true); } if (am == 1) { ZVX_RFP(NT_, 1, true); } if (am == 2) { ZVX_RFP(NT_, 2, true); } ZVX_RFP(NT_, 3, true); } \
     else { if (am == 2) { ZVX_RFP(NT_, 2, false); } ZVX_RFP(NT_, 3, false); }
@@ -1454,6 +1469,14 @@ static bool launch_resfuse_c(const GemmArgs& a, hipStream_t stream) {
     dim3 grid((a.M + bmo - 1) / bmo, a.nbatch);
     const size_t pitch = C * 2 + 16;
     size_t lds = (((size_t)(BM + 2 * a.halo_l) * pitch + 15) & ~(size_t)15) + (size_t)(BM + 2 * h2 + 32) * pitch;
+    if (a.dtype == DT_F16) {
+        switch (a.ntaps) {
+            case 3: ZVX_LAUNCH((resfuse_kernel<C, 3, BM, WM, WN, MINW, true>), grid, dim3(256), lds, stream, a); return true;
+            case 7: ZVX_LAUNCH((resfuse_kernel<C, 7, BM, WM, WN, MINW, true>), grid, dim3(256), lds, stream, a); return true;
+            case 11: ZVX_LAUNCH((resfuse_kernel<C, 11, BM, WM, WN, MINW, true>), grid, dim3(256), lds, stream, a); return true;
+        }
+        return false;
+    }
     switch (a.ntaps) {
         case 3: ZVX_LAUNCH((resfuse_kernel<C, 3, BM, WM, WN, MINW>), grid, dim3(256), lds, stream, a); return true;
         case 7: ZVX_LAUNCH((resfuse_kernel<C, 7, BM, WM, WN, MINW>), grid, dim3(256), lds, stream, a); return true;
@@ -1464,7 +1487,7 @@ static bool launch_resfuse_c(const GemmArgs& a, hipStream_t stream) {
 
 // Fused ResBlock1 pair; returns the variant id or -1 when the shape is not covered (caller then issues the two convs).
 int launch_resfuse(GemmArgs a, hipStream_t stream) {
-    if (a.dtype != DT_BF16 || !a.Wp || !a.Wp2 || a.N != a.K || a.nheads != 1 || a.wout > 0) return -1;
+    if (a.dtype == DT_F32 || !a.Wp || !a.Wp2 || a.N != a.K || a.nheads != 1 || a.wout > 0) return -1;
     if (!(a.ntaps == 3 || a.ntaps == 7 || a.ntaps == 11)) return -1;
     int h1 = 0;
     for (int i = 0; i < a.ntaps; i++) { const int d = a.dv1[i] < 0 ? -a.dv1[i] : a.dv1[i]; if (d > h1) h1 = d; }
@@ -1474,8 +1497,8 @@ int launch_resfuse(GemmArgs a, hipStream_t stream) {
     if (a.N == 128 && a.no_pairstream != 1) {
         // C = 128: the streaming pair kernel (pairstream.hip); its epilogue covers exactly what the vocoder asks for
         const int h2 = (a.ntaps - 1) / 2, dil = a.dv1[1] - a.dv1[0];
-        bool ok = a.alpha == 1.f && a.bias_mode == 1 && !a.post_scale && (!a.out || a.out_dtype == DT_BF16) && a.res_mode == 2 && a.res_dtype == DT_BF16 &&
-                  a.res == a.X && a.r_bs == a.x_bs && a.ldr == a.ldx && (!a.accum || a.accum_dtype == DT_BF16) && (a.act == ACT_NONE || a.act == ACT_LRELU) &&
+        bool ok = a.alpha == 1.f && a.bias_mode == 1 && !a.post_scale && (!a.out || a.out_dtype == a.dtype) && a.res_mode == 2 && a.res_dtype == a.dtype &&
+                  a.res == a.X && a.r_bs == a.x_bs && a.ldr == a.ldx && (!a.accum || a.accum_dtype == a.dtype) && (a.act == ACT_NONE || a.act == ACT_LRELU) &&
                   (a.accum_mode || a.out_scale == 1.f) && a.in_len == a.out_len;
         for (int t = 0; t < a.ntaps; t++) ok = ok && a.dv[t] == t - h2 && a.dv1[t] == (t - h2) * dil;
         if (ok) {
@@ -1486,6 +1509,7 @@ int launch_resfuse(GemmArgs a, hipStream_t stream) {
             p.out = a.out; p.o_bs = a.o_bs; p.ldo = a.ldo;
             p.accum = a.accum; p.a_bs = a.a_bs; p.lda = a.lda; p.accum_mode = a.accum ? a.accum_mode : 0;
             p.slope1 = a.slope1; p.res_inv_slope = a.res_inv_slope; p.out_scale = a.out_scale; p.slope = a.act == ACT_LRELU ? a.slope : 1.f;
+            p.f16 = a.dtype == DT_F16;
             p.len = a.out_len; p.M = a.M; p.nbatch = a.nbatch; p.force = a.no_pairstream >= 2 ? a.no_pairstream - 1 : 0;       // 2 -> force, 3 -> force with short segments
             if (launch_pairstream(p, stream, g_dry_run, g_dry_run ? nullptr : g_ev_start, g_ev_stop)) return 23;
         }
@@ -1527,28 +1551,35 @@ int gemm_num_variants() { return (int)(sizeof(kVariants) / sizeof(kVariants[0]))
 template <int BM, int BN, int WM, int WN, int MINW, int R, int EPI = -1>
 static void launch_slab_variant(const GemmArgs& a, dim3 grid, size_t lds, hipStream_t stream) {
     const bool fullk = a.K % SLAB_KC == 0 && a.K2 == 0;            // (a second source rides the partial-chunk variants: its K2 is any multiple of 16)
-    if constexpr (EPI == -1 || EPI == ZVX_EPI(0, 0, 1)) {
-        if (a.dtype == DT_F16) {                                   // half operands: the run-time epilogue and the "bias + activation -> 16 bit" one (the decoders' launches)
+    // IEEE-half operands: every epilogue of the register-ring tiles (the vocoder's and the decoders' launches); on the other tile shapes the
+    // run-time epilogue and the "bias + activation -> 16 bit" one
+    if constexpr (R == 0 || EPI == -1 || EPI == ZVX_EPI(0, 0, 1)) {
+        if (a.dtype == DT_F16) {
             if (fullk) ZVX_LAUNCH((convslab_kernel<BM, BN, WM, WN, true, MINW, R, EPI, 64, true>), grid, dim3(256), lds, stream, a);
             else ZVX_LAUNCH((convslab_kernel<BM, BN, WM, WN, false, MINW, R, EPI, 64, true>), grid, dim3(256), lds, stream, a);
             return;
         }
     }
-    if (fullk) ZVX_LAUNCH((convslab_kernel<BM, BN, WM, WN, true, MINW, R, EPI>), grid, dim3(256), lds, stream, a);
-    else ZVX_LAUNCH((convslab_kernel<BM, BN, WM, WN, false, MINW, R, EPI>), grid, dim3(256), lds, stream, a);
+    if constexpr (EPI < 0 || !(EPI & 16)) {                        // (the decoders' compile-time form exists in half only)
+        if (fullk) ZVX_LAUNCH((convslab_kernel<BM, BN, WM, WN, true, MINW, R, EPI>), grid, dim3(256), lds, stream, a);
+        else ZVX_LAUNCH((convslab_kernel<BM, BN, WM, WN, false, MINW, R, EPI>), grid, dim3(256), lds, stream, a);
+    }
 }
 
-// compile-time epilogue mode of a launch (see ZVX_EPI), or -1 when it needs the run-time epilogue
+// compile-time epilogue mode of a launch (see ZVX_EPI / ZVX_EPI_DEC), or -1 when it needs the run-time epilogue
 static int epi_mode_of(const GemmArgs& a) {
-    if (a.alpha != 1.f || a.bias_mode != 1 || !a.bias || a.post_scale || (a.out && a.out_dtype != a.dtype) || a.dtype == DT_F32) return -1;
-    if (a.act != ACT_NONE && a.act != ACT_LRELU) return -1;
-    if (a.res_mode && (a.res_mode != 2 || a.res_dtype != DT_BF16)) return -1;
+    if (a.alpha != 1.f || a.post_scale || (a.out && a.out_dtype != a.dtype) || a.dtype == DT_F32 || a.out_split3 || a.bias_mode == 2) return -1;
     const int am = a.accum ? a.accum_mode : 0;
-    if (am && a.accum_dtype != DT_BF16) return -1;
+    // the mel decoders' residual form (half only): (conv [+ raw residual]) x out_scale, no activation, 16-bit output
+    if (a.dtype == DT_F16 && a.out && !am && a.act == ACT_NONE && a.res_mode <= 1 && (!a.res_mode || a.res_dtype == DT_F16) && (a.res_mode || a.out_scale != 1.f) &&
+        (a.bias_mode == 0 || a.bias)) return ZVX_EPI_DEC(a.res_mode ? 1 : 0);
+    if (a.bias_mode != 1 || !a.bias) return -1;
+    if (a.act != ACT_NONE && a.act != ACT_LRELU) return -1;
+    if (a.res_mode && (a.res_mode != 2 || a.res_dtype != a.dtype)) return -1;
+    if (am && a.accum_dtype != a.dtype) return -1;
     if (!am && a.out_scale != 1.f) return -1;
     if (!a.out && !(am & 2)) return -1;
     const int e = ZVX_EPI(a.res_mode ? 1 : 0, am, a.out ? 1 : 0);
-    if (a.dtype == DT_F16 && e != ZVX_EPI(0, 0, 1)) return -1;                     // half: only the read-nothing epilogue has a compile-time variant
     switch (e) {
         case ZVX_EPI(0, 0, 1): case ZVX_EPI(1, 0, 1): case ZVX_EPI(1, 2, 0): case ZVX_EPI(1, 3, 0): case ZVX_EPI(1, 1, 1): return e;
     }
@@ -1586,7 +1617,7 @@ static int launch_convslab(GemmArgs a, hipStream_t stream) {
         ZVX_LAUNCH((convslab_kernel<256, 128, 2, 2, true, 2, 0, -1, 160>), grid, dim3(256), lds, stream, a);
         return 7;
     }
-    if (a.dtype == DT_BF16 && a.N == a.K && (a.ntaps == 3 || a.ntaps == 7 || a.ntaps == 11)) {
+    if (a.dtype != DT_F32 && a.N == a.K && (a.ntaps == 3 || a.ntaps == 7 || a.ntaps == 11)) {
         if (a.N == 32 && launch_convreg_c<32, 512, 4, 1, 2>(a, stream)) return 14;
         if (a.N == 64 && launch_convreg_c<64, 256, 2, 2, 2>(a, stream)) return 15;
     }
@@ -1680,26 +1711,21 @@ static int launch_convslab(GemmArgs a, hipStream_t stream) {
     const int ntm = (a.M + bm - 1) / bm;
     dim3 grid(ntn * ntm, a.nbatch);
     const int tn = (bn >= 128) ? 2 : 1;
+    if (a.accum_mode && a.accum && a.accum_dtype == DT_F16 && tn == 2 && !(best == 1 && epi_mode_of(a) >= 0)) return -6;   // (see epilogue_rows: acc_f16; the small-tile shapes above take it)
     size_t lds = (((size_t)(bm + hl + hr) * SLAB_PITCH + 1023) & ~(size_t)1023) + (size_t)ring_slots * (bn / 32) * 1024;      // slab + weight ring (R slots x bn/32 KiB)
     const size_t stage = (size_t)4 * 32 * (tn * 128 + 16);
     if (lds < stage) lds = stage;
     switch (best) {
-        case 0: if (wreg) launch_slab_variant<128, 256, 1, 4, 2, 0>(a, grid, lds, stream); else launch_slab_variant<128, 256, 1, 4, 2, 4>(a, grid, lds, stream); break;
-        case 1: if (wreg) { switch (epi_mode_of(a)) {
+        case 0: launch_slab_variant<128, 256, 1, 4, 2, 0>(a, grid, lds, stream); break;      // (register-ring variant)
+        case 1: switch (epi_mode_of(a)) {                   // (always the register-ring variant: wreg)
                     case ZVX_EPI(0, 0, 1): launch_slab_variant<256, 128, 2, 2, 2, 0, ZVX_EPI(0, 0, 1)>(a, grid, lds, stream); break;
                     case ZVX_EPI(1, 0, 1): launch_slab_variant<256, 128, 2, 2, 2, 0, ZVX_EPI(1, 0, 1)>(a, grid, lds, stream); break;
                     case ZVX_EPI(1, 2, 0): launch_slab_variant<256, 128, 2, 2, 2, 0, ZVX_EPI(1, 2, 0)>(a, grid, lds, stream); break;
                     case ZVX_EPI(1, 3, 0): launch_slab_variant<256, 128, 2, 2, 2, 0, ZVX_EPI(1, 3, 0)>(a, grid, lds, stream); break;
                     case ZVX_EPI(1, 1, 1): launch_slab_variant<256, 128, 2, 2, 2, 0, ZVX_EPI(1, 1, 1)>(a, grid, lds, stream); break;
+                    case ZVX_EPI_DEC(0): launch_slab_variant<256, 128, 2, 2, 2, 0, ZVX_EPI_DEC(0)>(a, grid, lds, stream); break;
+                    case ZVX_EPI_DEC(1): launch_slab_variant<256, 128, 2, 2, 2, 0, ZVX_EPI_DEC(1)>(a, grid, lds, stream); break;
                     default: launch_slab_variant<256, 128, 2, 2, 2, 0>(a, grid, lds, stream);
-                } break; }
-                switch (epi_mode_of(a)) {
-                    case ZVX_EPI(0, 0, 1): launch_slab_variant<256, 128, 2, 2, 2, 8, ZVX_EPI(0, 0, 1)>(a, grid, lds, stream); break;
-                    case ZVX_EPI(1, 0, 1): launch_slab_variant<256, 128, 2, 2, 2, 8, ZVX_EPI(1, 0, 1)>(a, grid, lds, stream); break;
-                    case ZVX_EPI(1, 2, 0): launch_slab_variant<256, 128, 2, 2, 2, 8, ZVX_EPI(1, 2, 0)>(a, grid, lds, stream); break;
-                    case ZVX_EPI(1, 3, 0): launch_slab_variant<256, 128, 2, 2, 2, 8, ZVX_EPI(1, 3, 0)>(a, grid, lds, stream); break;
-                    case ZVX_EPI(1, 1, 1): launch_slab_variant<256, 128, 2, 2, 2, 8, ZVX_EPI(1, 1, 1)>(a, grid, lds, stream); break;
-                    default: launch_slab_variant<256, 128, 2, 2, 2, 8>(a, grid, lds, stream);
                 }
                 break;
         case 2: launch_slab_variant<256, 64, 2, 2, 2, 8>(a, grid, lds, stream); break;
@@ -1738,7 +1764,6 @@ int launch_gemm(const GemmArgs& a, hipStream_t stream) {
         if (hi - lo <= 64 && hi >= 0 && lo <= 0) return launch_convslab(a, stream);
     }
     if (a.out_split3 || a.K2) return -2;                        // only the conv-slab kernel writes split planes / takes a second source
-    if (a.dtype == DT_F16) return -2;                           // half operands exist on the conv-slab kernel only
     // tile choice: padded N weighted by the tile's MFMA efficiency, ties -> wider BN
     static const int bns[3] = {128, 64, 32};
     static const double eff[3] = {1.0, 0.75, 0.45};
@@ -1754,12 +1779,21 @@ int launch_gemm(const GemmArgs& a, hipStream_t stream) {
         bm = bn = 64; ntn = (a.N + 63) / 64; ntm = (a.M + 63) / 64;
         dim3 grid(ntn * ntm, a.nbatch * a.nheads), block(256);
         if (a.dtype == DT_BF16) { ZVX_LAUNCH((gemm_kernel<DT_BF16, 64, 64, 2, 2>), grid, block, 0, stream, a); return 18; }
+        if (a.dtype == DT_F16) { ZVX_LAUNCH((gemm_kernel<DT_F16, 64, 64, 2, 2>), grid, block, 0, stream, a); return 18; }
         ZVX_LAUNCH((gemm_kernel<DT_F32, 64, 64, 2, 2>), grid, block, 0, stream, a);
         return 19;
     }
     dim3 grid(ntn * ntm, a.nbatch * a.nheads), block(256);
-    const int base = (a.dtype == DT_BF16) ? 0 : 3;
+    const int base = (a.dtype != DT_F32) ? 0 : 3;
     const int id = base + best;
+    if (a.dtype == DT_F16) {                                    // IEEE-half operands (the vocoder's odd shapes): the bf16 tilings on the f16 MFMA
+        switch (id) {
+            case 0: ZVX_LAUNCH((gemm_kernel<DT_F16, 128, 128, 2, 2>), grid, block, 0, stream, a); break;
+            case 1: ZVX_LAUNCH((gemm_kernel<DT_F16, 256, 64, 4, 1>), grid, block, 0, stream, a); break;
+            case 2: ZVX_LAUNCH((gemm_kernel<DT_F16, 256, 32, 4, 1>), grid, block, 0, stream, a); break;
+        }
+        return id;
+    }
     switch (id) {
         case 0: ZVX_LAUNCH((gemm_kernel<DT_BF16, 128, 128, 2, 2>), grid, block, 0, stream, a); break;
         case 1: ZVX_LAUNCH((gemm_kernel<DT_BF16, 256, 64, 4, 1>), grid, block, 0, stream, a); break;

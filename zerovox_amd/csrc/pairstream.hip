@@ -65,7 +65,7 @@ namespace zvx {
 #endif
 
 // ROLE 0: conv1 (dilated; X ring -> T ring, issues the X DMA).  ROLE 1: conv2 (T ring -> HBM).
-template <int ROLE, int NT, int AM, bool HAS_OUT>
+template <int ROLE, int NT, int AM, bool HAS_OUT, bool H16>
 __device__ __forceinline__ void ps_role(const PairArgs& a, unsigned char* lds, const int lane, const int ct) {
     constexpr int R = PS_R, H2 = (NT - 1) / 2, NS = 8 * NT, WD = PS_WD;
     // DMA instructions per loop iteration: a fixed number (vmcnt counts stay uniform), enough for the real pieces to be issued
@@ -219,7 +219,7 @@ __device__ __forceinline__ void ps_role(const PairArgs& a, unsigned char* lds, c
 #pragma unroll
                         for (int j = 0; j < 4; j++) {
                             if (PS_EXP & 32) asm volatile("" : "+v"(acc[j]) : "v"(wreg[i]), "v"(xs[i & 3][j]));
-                            else acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, wreg[i]), __builtin_bit_cast(bf16x8, xs[i & 3][j]), acc[j], 0, 0, 0);
+                            else acc[j] = mfma16<H16>(wreg[i], xs[i & 3][j], acc[j]);
                             __builtin_amdgcn_sched_barrier(0);
                             if (kk + PD < 4) rd1(xs[(i + PD) & 3][j], bs[j], kk + PD); else rd1(xs[(i + PD) & 3][j], nbs[j], kk + PD - 4);
                             if (kk == 0 && j == 3) bases_common(un);
@@ -270,8 +270,8 @@ __device__ __forceinline__ void ps_role(const PairArgs& a, unsigned char* lds, c
                     const f32x2 v01 = lrelu2((f32x2){acc[j][4 * q], acc[j][4 * q + 1]} + (f32x2){bq[q].x, bq[q].y}, slope1);
                     const f32x2 v23 = lrelu2((f32x2){acc[j][4 * q + 2], acc[j][4 * q + 3]} + (f32x2){bq[q].z, bq[q].w}, slope1);
                     uint2 pk;
-                    pk.x = inside ? pack_bf16x2(v01.x, v01.y) : 0u;
-                    pk.y = inside ? pack_bf16x2(v23.x, v23.y) : 0u;
+                    pk.x = inside ? pack16<H16>(v01.x, v01.y) : 0u;
+                    pk.y = inside ? pack16<H16>(v23.x, v23.y) : 0u;
                     if (!(PS_EXP & 16)) *(uint2*)(dst + q * 16) = pk;
                     else asm volatile("" :: "v"(pk.x), "v"(pk.y), "v"(dst));
                 }
@@ -342,7 +342,7 @@ __device__ __forceinline__ void ps_role(const PairArgs& a, unsigned char* lds, c
                     v[4 * q] = acc[j][4 * q] + bq[q].x; v[4 * q + 1] = acc[j][4 * q + 1] + bq[q].y;
                     v[4 * q + 2] = acc[j][4 * q + 2] + bq[q].z; v[4 * q + 3] = acc[j][4 * q + 3] + bq[q].w;
                     if (PS_RES_LDS) {
-                        const f32x2 r01 = inv_lrelu2(unpack_bf16x2(rcur[j][q].x), rinv), r23 = inv_lrelu2(unpack_bf16x2(rcur[j][q].y), rinv);
+                        const f32x2 r01 = inv_lrelu2(unpack16<H16>(rcur[j][q].x), rinv), r23 = inv_lrelu2(unpack16<H16>(rcur[j][q].y), rinv);
                         v[4 * q] += r01.x; v[4 * q + 1] += r01.y; v[4 * q + 2] += r23.x; v[4 * q + 3] += r23.y;
                     }
                 }
@@ -357,15 +357,15 @@ __device__ __forceinline__ void ps_role(const PairArgs& a, unsigned char* lds, c
                     f32x2 t[4] = {(f32x2){w8[0], w8[1]}, (f32x2){w8[2], w8[3]}, (f32x2){w8[4], w8[5]}, (f32x2){w8[6], w8[7]}};
                     if (!PS_RES_LDS) {
                         const u32x4 rr = rx[j][pr];
-                        t[0] += inv_lrelu2(unpack_bf16x2(rr.x), rinv); t[1] += inv_lrelu2(unpack_bf16x2(rr.y), rinv);
-                        t[2] += inv_lrelu2(unpack_bf16x2(rr.z), rinv); t[3] += inv_lrelu2(unpack_bf16x2(rr.w), rinv);
+                        t[0] += inv_lrelu2(unpack16<H16>(rr.x), rinv); t[1] += inv_lrelu2(unpack16<H16>(rr.y), rinv);
+                        t[2] += inv_lrelu2(unpack16<H16>(rr.z), rinv); t[3] += inv_lrelu2(unpack16<H16>(rr.w), rinv);
                     }
                     if (AM & 1) {
                         const u32x4 ss = sx[j][pr];
-                        t[0] += unpack_bf16x2(ss.x); t[1] += unpack_bf16x2(ss.y); t[2] += unpack_bf16x2(ss.z); t[3] += unpack_bf16x2(ss.w);
+                        t[0] += unpack16<H16>(ss.x); t[1] += unpack16<H16>(ss.y); t[2] += unpack16<H16>(ss.z); t[3] += unpack16<H16>(ss.w);
                     }
                     if (AM & 2)
-                        __builtin_amdgcn_raw_buffer_store_b128((u32x4){pack_bf16x2(t[0].x, t[0].y), pack_bf16x2(t[1].x, t[1].y), pack_bf16x2(t[2].x, t[2].y), pack_bf16x2(t[3].x, t[3].y)},
+                        __builtin_amdgcn_raw_buffer_store_b128((u32x4){pack16<H16>(t[0].x, t[0].y), pack16<H16>(t[1].x, t[1].y), pack16<H16>(t[2].x, t[2].y), pack16<H16>(t[3].x, t[3].y)},
                                                                rsA, off[j] + 32 * pr, 0, 0);
                     if (HAS_OUT) {
                         if (AM) {
@@ -374,7 +374,7 @@ __device__ __forceinline__ void ps_role(const PairArgs& a, unsigned char* lds, c
                         }
 #pragma unroll
                         for (int e = 0; e < 4; e++) t[e] = lrelu2(t[e], oslope);
-                        __builtin_amdgcn_raw_buffer_store_b128((u32x4){pack_bf16x2(t[0].x, t[0].y), pack_bf16x2(t[1].x, t[1].y), pack_bf16x2(t[2].x, t[2].y), pack_bf16x2(t[3].x, t[3].y)},
+                        __builtin_amdgcn_raw_buffer_store_b128((u32x4){pack16<H16>(t[0].x, t[0].y), pack16<H16>(t[1].x, t[1].y), pack16<H16>(t[2].x, t[2].y), pack16<H16>(t[3].x, t[3].y)},
                                                                rsO, off[j] + 32 * pr, 0, 0);
                     }
                 }
@@ -439,8 +439,9 @@ __device__ __forceinline__ void ps_role(const PairArgs& a, unsigned char* lds, c
 #endif
 }
 
-template <int NT, int AM, bool HAS_OUT>
+template <int NT, int AM, bool HAS_OUT, bool H16>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void pairstream128_kernel(const PairArgs a) {
+    if (H16) f16_saturate_mode();                                             // f32 -> f16 converts clamp to +-65504 (mfma_util.h)
     extern __shared__ __attribute__((aligned(256))) unsigned char lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // biases [b1 | b2] live in LDS behind the rings (16 values per lane, re-read per block instead of held in registers)
@@ -448,8 +449,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     if (tid < 256) bias_l[tid] = tid < 128 ? a.b1[tid] : a.b2[tid - 128];
     __syncthreads();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                          // settled before any hidden load is in flight
-    if (wave < 4) ps_role<0, NT, AM, HAS_OUT>(a, lds, lane, wave);
-    else ps_role<1, NT, AM, HAS_OUT>(a, lds, lane, wave - 4);
+    if (wave < 4) ps_role<0, NT, AM, HAS_OUT, H16>(a, lds, lane, wave);
+    else ps_role<1, NT, AM, HAS_OUT, H16>(a, lds, lane, wave - 4);
 }
 
 static int ps_ncu() { return persistent_cus(); }
@@ -481,11 +482,12 @@ bool launch_pairstream(PairArgs a, hipStream_t stream, bool dry_run, hipEvent_t 
     if (dry_run) return true;
     const int nsegs = a.nseg * a.nbatch;
     const dim3 grid(nsegs < nwg ? nsegs : nwg), block(512);
-#define PS_GO(NT_, AM_, HO_) do { auto kfn = pairstream128_kernel<NT_, AM_, HO_>; \
+#define PS_GO1(NT_, AM_, HO_, H_) do { auto kfn = pairstream128_kernel<NT_, AM_, HO_, H_>; \
         static std::atomic<bool> attr_done{false}; \
         if (!attr_done) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_done = true; } \
         if (ev_start) hipExtLaunchKernelGGL(kfn, grid, block, lds, stream, ev_start, ev_stop, 0, a); \
         else hipLaunchKernelGGL(kfn, grid, block, lds, stream, a); return true; } while (0)
+#define PS_GO(NT_, AM_, HO_) do { if (a.f16) PS_GO1(NT_, AM_, HO_, true); else PS_GO1(NT_, AM_, HO_, false); } while (0)
 #define PS_MODE(NT_) do { if (a.out) { if (am == 0) PS_GO(NT_, 0, true); if (am == 1) PS_GO(NT_, 1, true); return false; } \
         if (am == 2) PS_GO(NT_, 2, false); if (am == 3) PS_GO(NT_, 3, false); return false; } while (0)
     if (a.ntaps == 3) PS_MODE(3);
@@ -493,6 +495,7 @@ bool launch_pairstream(PairArgs a, hipStream_t stream, bool dry_run, hipEvent_t 
     if (a.ntaps == 11) PS_MODE(11);
 #undef PS_MODE
 #undef PS_GO
+#undef PS_GO1
     return false;
 }
 

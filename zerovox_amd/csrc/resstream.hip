@@ -48,15 +48,15 @@ template <int I, int PD, int KS, int DIL, int P>
 __device__ __forceinline__ void rs_prefetch(uint4 (&xf)[PD + 1], unsigned base) {
     if constexpr (I < PD) { rs_read<I, PD, KS, DIL, P>(xf, base); rs_prefetch<I + 1, PD, KS, DIL, P>(xf, base); }
 }
-template <int I, int NW, int PD, int KS, int DIL, int P>
+template <int I, int NW, int PD, int KS, int DIL, int P, bool H16>
 __device__ __forceinline__ void rs_mma_steps(uint4 (&xf)[PD + 1], const uint4 (&w)[NW], unsigned base, f32x16& acc) {
     if constexpr (I < NW) {
         if constexpr (I + PD < NW) rs_read<I + PD, PD, KS, DIL, P>(xf, base);
         asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(NW - 1 - I >= PD ? PD : NW - 1 - I) : "memory");
         __builtin_amdgcn_sched_barrier(0);
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w[I]), __builtin_bit_cast(bf16x8, xf[I % (PD + 1)]), acc, 0, 0, 0);
+        acc = mfma16<H16>(w[I], xf[I % (PD + 1)], acc);
         __builtin_amdgcn_sched_barrier(0);
-        rs_mma_steps<I + 1, NW, PD, KS, DIL, P>(xf, w, base, acc);
+        rs_mma_steps<I + 1, NW, PD, KS, DIL, P, H16>(xf, w, base, acc);
     }
 }
 
@@ -101,7 +101,7 @@ struct RsGeom {
 // issues the DMA or owns the store phase -- is a compile-time constant here: the step loop of a generic body spent as many scalar
 // instructions on that bookkeeping (66 per step and wave) as vector instructions on the epilogue (76), and a SIMD issues about one
 // instruction per 4 cycles whatever its kind (SQ_ACTIVE_INST_ANY ~ 90 % of the kernel's cycles on the narrow stages).
-template <int C, int NT, int NPAIR, int RSPLIT, int AM, bool HAS_OUT, int DP, int ROLE>
+template <int C, int NT, int NPAIR, int RSPLIT, int AM, bool HAS_OUT, int DP, bool H16, int ROLE>
 __device__ __forceinline__ void rs_role(const StreamArgs& a, unsigned char* const lds, const int lane, const int sub, const int wave) {
     using G = RsGeom<C, NT, NPAIR, RSPLIT, DP>;
     constexpr int NR = 2 * NPAIR, NTL = C / 32, WPR = NTL * RSPLIT;
@@ -273,18 +273,18 @@ __device__ __forceinline__ void rs_role(const StreamArgs& a, unsigned char* cons
 #pragma unroll
             for (int h = 0; h < 2; h++) {
                 if (AM & 1 || HAS_OUT) {
-                    f32x2 t[4] = {unpack_bf16x2(o[h].x), unpack_bf16x2(o[h].y), unpack_bf16x2(o[h].z), unpack_bf16x2(o[h].w)};
+                    f32x2 t[4] = {unpack16<H16>(o[h].x), unpack16<H16>(o[h].y), unpack16<H16>(o[h].z), unpack16<H16>(o[h].w)};
                     if (AM & 1) {
-                        t[0] += unpack_bf16x2(xs[h].x); t[1] += unpack_bf16x2(xs[h].y);
-                        t[2] += unpack_bf16x2(xs[h].z); t[3] += unpack_bf16x2(xs[h].w);
-                        if (AM & 2) o[h] = make_uint4(pack_bf16x2(t[0].x, t[0].y), pack_bf16x2(t[1].x, t[1].y), pack_bf16x2(t[2].x, t[2].y), pack_bf16x2(t[3].x, t[3].y));
+                        t[0] += unpack16<H16>(xs[h].x); t[1] += unpack16<H16>(xs[h].y);
+                        t[2] += unpack16<H16>(xs[h].z); t[3] += unpack16<H16>(xs[h].w);
+                        if (AM & 2) o[h] = make_uint4(pack16<H16>(t[0].x, t[0].y), pack16<H16>(t[1].x, t[1].y), pack16<H16>(t[2].x, t[2].y), pack16<H16>(t[3].x, t[3].y));
                     }
                     if (AM & 2) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o[h]), rsA, row_off(pend_g0, h, a.lda), 0, 0);
                     if (HAS_OUT) {
                         if (AM) {
 #pragma unroll
                             for (int e = 0; e < 4; e++) t[e] = lrelu2(t[e] * oscale, oslope);
-                            o[h] = make_uint4(pack_bf16x2(t[0].x, t[0].y), pack_bf16x2(t[1].x, t[1].y), pack_bf16x2(t[2].x, t[2].y), pack_bf16x2(t[3].x, t[3].y));
+                            o[h] = make_uint4(pack16<H16>(t[0].x, t[0].y), pack16<H16>(t[1].x, t[1].y), pack16<H16>(t[2].x, t[2].y), pack16<H16>(t[3].x, t[3].y));
                         }
                         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o[h]), rsO, row_off(pend_g0, h, a.ldo), 0, 0);
                     }
@@ -334,7 +334,7 @@ __device__ __forceinline__ void rs_role(const StreamArgs& a, unsigned char* cons
                 else if (rem == 1) asm volatile("s_waitcnt lgkmcnt(1)" ::: "memory");
                 else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_sched_barrier(0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, w[i]), __builtin_bit_cast(bf16x8, xf[i % (PD + 1)]), acc, 0, 0, 0);
+                acc = mfma16<H16>(w[i], xf[i % (PD + 1)], acc);
                 __builtin_amdgcn_sched_barrier(0);
             }
         };
@@ -350,7 +350,7 @@ __device__ __forceinline__ void rs_role(const StreamArgs& a, unsigned char* cons
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
             rs_prefetch<0, PD, KS, DIL, P>(xf, base);
-            rs_mma_steps<0, NW, PD, KS, DIL, P>(xf, w, base, acc);
+            rs_mma_steps<0, NW, PD, KS, DIL, P, H16>(xf, w, base, acc);
         };
         auto mma_block = [&]() {
             constexpr int D0 = DP & 15, D1 = (DP >> 4) & 15, D2 = (DP >> 8) & 15;
@@ -391,11 +391,11 @@ __device__ __forceinline__ void rs_role(const StreamArgs& a, unsigned char* cons
             for (int q = 0; q < 4; q++) {
                 f32x2 v01 = (f32x2){acc[4 * q], acc[4 * q + 1]} + (f32x2){bq[q].x, bq[q].y};
                 f32x2 v23 = (f32x2){acc[4 * q + 2], acc[4 * q + 3]} + (f32x2){bq[q].z, bq[q].w};
-                if (KIND >= 1) { v01 += inv_lrelu2(unpack_bf16x2(rq[q].x), rinv); v23 += inv_lrelu2(unpack_bf16x2(rq[q].y), rinv); }
+                if (KIND >= 1) { v01 += inv_lrelu2(unpack16<H16>(rq[q].x), rinv); v23 += inv_lrelu2(unpack16<H16>(rq[q].y), rinv); }
                 if (KIND <= 1) { v01 = lrelu2(v01, slope1); v23 = lrelu2(v23, slope1); }                  // T, or the next pair's activated input
                 else if (!AM) { v01 = lrelu2(v01, oslope); v23 = lrelu2(v23, oslope); }                  // no running sum: the output activation is applied here
                 uint2 pk;
-                pk.x = pack_bf16x2(v01.x, v01.y); pk.y = pack_bf16x2(v23.x, v23.y);
+                pk.x = pack16<H16>(v01.x, v01.y); pk.y = pack16<H16>(v23.x, v23.y);
                 if (KIND <= 1 && MASKED && !inside) { pk.x = 0u; pk.y = 0u; }
                 *(uint2*)(dst + q * 16) = pk;
             }
@@ -446,9 +446,10 @@ __device__ __forceinline__ void rs_role(const StreamArgs& a, unsigned char* cons
 #endif
 }
 
-template <int C, int NT, int NPAIR, int RSPLIT, int AM, bool HAS_OUT, int DP>
+template <int C, int NT, int NPAIR, int RSPLIT, int AM, bool HAS_OUT, int DP, bool H16>
 __global__ __launch_bounds__(128 * NPAIR * (C / 32) * RSPLIT) void resstream_kernel(const StreamArgs a) {
     constexpr int NR = 2 * NPAIR, NTL = C / 32, WPR = NTL * RSPLIT;
+    if (H16) f16_saturate_mode();                                                  // f32 -> f16 converts clamp to +-65504 (mfma_util.h)
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -459,12 +460,12 @@ __global__ __launch_bounds__(128 * NPAIR * (C / 32) * RSPLIT) void resstream_ker
         const int pr = __builtin_amdgcn_readfirstlane(prio_of_wave<NR, WPR>(wave, (a.opt & 2) != 0));
         if (pr == 3) __builtin_amdgcn_s_setprio(3); else if (pr == 2) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(1);
     }
-    if (role == 0) rs_role<C, NT, NPAIR, RSPLIT, AM, HAS_OUT, DP, 0>(a, lds, lane, sub, wave);
-    else if (role == 1) rs_role<C, NT, NPAIR, RSPLIT, AM, HAS_OUT, DP, 1>(a, lds, lane, sub, wave);
-    else if (NR > 2 && role == 2) rs_role<C, NT, NPAIR, RSPLIT, AM, HAS_OUT, DP, (NR > 2 ? 2 : 0)>(a, lds, lane, sub, wave);
-    else if (NR > 2 && role == 3) rs_role<C, NT, NPAIR, RSPLIT, AM, HAS_OUT, DP, (NR > 2 ? 3 : 1)>(a, lds, lane, sub, wave);
-    else if (NR > 4 && role == 4) rs_role<C, NT, NPAIR, RSPLIT, AM, HAS_OUT, DP, (NR > 4 ? 4 : 0)>(a, lds, lane, sub, wave);
-    else if (NR > 4) rs_role<C, NT, NPAIR, RSPLIT, AM, HAS_OUT, DP, (NR > 4 ? 5 : 1)>(a, lds, lane, sub, wave);
+    if (role == 0) rs_role<C, NT, NPAIR, RSPLIT, AM, HAS_OUT, DP, H16, 0>(a, lds, lane, sub, wave);
+    else if (role == 1) rs_role<C, NT, NPAIR, RSPLIT, AM, HAS_OUT, DP, H16, 1>(a, lds, lane, sub, wave);
+    else if (NR > 2 && role == 2) rs_role<C, NT, NPAIR, RSPLIT, AM, HAS_OUT, DP, H16, (NR > 2 ? 2 : 0)>(a, lds, lane, sub, wave);
+    else if (NR > 2 && role == 3) rs_role<C, NT, NPAIR, RSPLIT, AM, HAS_OUT, DP, H16, (NR > 2 ? 3 : 1)>(a, lds, lane, sub, wave);
+    else if (NR > 4 && role == 4) rs_role<C, NT, NPAIR, RSPLIT, AM, HAS_OUT, DP, H16, (NR > 4 ? 4 : 0)>(a, lds, lane, sub, wave);
+    else if (NR > 4) rs_role<C, NT, NPAIR, RSPLIT, AM, HAS_OUT, DP, H16, (NR > 4 ? 5 : 1)>(a, lds, lane, sub, wave);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -507,15 +508,17 @@ static bool launch_rs(StreamArgs& a, hipStream_t stream, bool dry_run) {
     if (dry_run) return true;
     const dim3 grid(nsegs < nwg ? nsegs : nwg), block(64 * NR * WPR);
     const int am = a.accum ? a.accum_mode : 0;
-#define RS_GO(AM_, HO_) do { auto kfn = resstream_kernel<C, NT, NPAIR, RSPLIT, AM_, HO_, DP>; \
+#define RS_GO1(AM_, HO_, H_) do { auto kfn = resstream_kernel<C, NT, NPAIR, RSPLIT, AM_, HO_, DP, H_>; \
         static std::atomic<bool> attr_done{false}; \
         if (!attr_done) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_done = true; } \
         if (g_rs_ev_start) hipExtLaunchKernelGGL(kfn, grid, block, lds, stream, g_rs_ev_start, g_rs_ev_stop, 0, a); \
         else hipLaunchKernelGGL(kfn, grid, block, lds, stream, a); return true; } while (0)
+#define RS_GO(AM_, HO_) do { if (a.f16) RS_GO1(AM_, HO_, true); else RS_GO1(AM_, HO_, false); } while (0)
     if (a.out) { if (am == 0) RS_GO(0, true); if (am == 1) RS_GO(1, true); return false; }
     if (am == 2) RS_GO(2, false);
     if (am == 3) RS_GO(3, false);
 #undef RS_GO
+#undef RS_GO1
     return false;
 }
 

@@ -115,6 +115,7 @@ struct zvx_ctx {
     int norm_fuse_maxb = 1 << 20;          // zvx_set_int("norm_fuse_maxb", n): batches of at most n utterances may take the one-launch InstanceNorm of the StyleTTS decoder (0: never; A/B)
     int dec_sc_fuse = 1;                   // zvx_set_int("dec_sc_fuse", 0): the 1x1 shortcut of a StyleTTS residual block as its own launch (A/B; the fused form skips one 16-bit rounding of the conv2 result)
     int dec_flat = 1;                      // zvx_set_int("dec_flat", 0): the StyleTTS decoder's convolutions per utterance instead of batch-flattened (A/B, bit-identical)
+    int voc_f16 = 1;                       // zvx_set_int("voc_f16", 0): the vocoder's activations / weights / running sum in bf16 instead of IEEE half (A/B; round 5)
     int dec_f16 = 1;                       // zvx_set_int("dec_f16", 0): StyleTTS decoder activations / weights in bf16 instead of IEEE half (A/B)
     int use_attn_f32 = 1;                  // zvx_set_int("attn_f32", 0): the encoder's attention as V^T / score / P.V GEMMs + softmax (A/B)
     int use_flash = 1;                     // zvx_set_int("flash", 0): the decoder's attention as score GEMM + softmax + PV GEMM (A/B)
@@ -493,7 +494,8 @@ void upload_weights(zvx_ctx* c) {
         size_t htotal = 0;
         for (auto& kv : c->tensors) {
             const Tensor& t = kv.second;
-            if ((kv.first.rfind("sty.", 0) != 0 && kv.first.rfind("dec.", 0) != 0) || t.kind != 'w' || t.dtype != DT_BF16 || t.dims.size() != 3 || t.dim(2) % 8) continue;
+            // (round 5: the HiFi-GAN vocoder's weights too -- "voc.": its 16-bit tensors are IEEE half unless zvx_set_int("voc_f16", 0))
+            if ((kv.first.rfind("sty.", 0) != 0 && kv.first.rfind("dec.", 0) != 0 && kv.first.rfind("voc.", 0) != 0) || t.kind != 'w' || t.dtype != DT_BF16 || t.dims.size() != 3 || t.dim(2) % 8) continue;
             Tensor hcopy = t; hcopy.dtype = DT_F16; hcopy.kind = 'h';
             htotal += ((t.numel * 2 + 255) & ~(size_t)255) + ((packed_weight_elems(t.dim(0), t.dim(1), t.dim(2)) * 2 + 255) & ~(size_t)255);
             add16.emplace_back(kv.first + ".h16", hcopy);
@@ -1121,8 +1123,12 @@ void run_decode(zvx_ctx* c, const float* feats, const float* spk_d, const int* L
 // ------------------------------------------------------------------------------------------------
 void run_vocoder(zvx_ctx* c, const float* mel, int ldm, int Lmel_max, const int* mel_len_host, const int* P_host, int B,
                  void* wav_dev, long wav_stride, int pcm16) {
-    const int dt = c->dt, nm = c->n_mels;
-    const size_t es = c->es();
+    // 16-bit mode: IEEE half (round 5) -- f16 copies of the weights, f16 activations / running sum, the f16 MFMA at the bf16 rate and 8x
+    // less rounding error per tensor; every store saturates (MODE.FP16_OVFL inside the kernels).  zvx_set_int("voc_f16", 0): bf16 (A/B)
+    const int dt = (c->dt == DT_BF16 && c->voc_f16 && c->has("voc.pre_w.h16")) ? DT_F16 : c->dt, nm = c->n_mels;
+    const bool h16 = dt == DT_F16;
+    auto vt = [&](const std::string& n) -> const Tensor& { return c->t(h16 ? n + ".h16" : n); };      // a contraction weight in the vocoder's dtype
+    const size_t es = dtype_size(dt);
     int Pmax = 0; for (int b = 0; b < B; b++) Pmax = std::max(Pmax, P_host[b]);
     if (Pmax <= 0) return;
     const int ns = (int)c->voc_rates.size(), nk = (int)c->voc_rb_k.size();
@@ -1163,7 +1169,7 @@ void run_vocoder(zvx_ctx* c, const float* mel, int ldm, int Lmel_max, const int*
     }
     {   // conv_pre, stored as leaky_relu(x, 0.1) (its only consumer, hifigan.py:115-117)
         GemmArgs a = gemm_base(dt);
-        a.X = vin; a.x_bs = (long)Pmax * nm; a.ldx = nm; a.W = c->t("voc.pre_w").dev; a.ldw = nm; a.w_ts = (long)c->voc_c0 * nm;
+        a.X = vin; a.x_bs = (long)Pmax * nm; a.ldx = nm; a.W = vt("voc.pre_w").dev; a.ldw = nm; a.w_ts = (long)c->voc_c0 * nm;
         a.M = Pmax; a.N = c->voc_c0; a.K = nm; a.nbatch = B; a.in_len = P_d; a.out_len = P_d;
         set_taps_1d(a, c->t("voc.pre_w").dim(0), 1);
         a.bias = c->pf("voc.pre_b"); a.bias_mode = 1; a.act = ACT_LRELU; a.slope = 0.1f;
@@ -1183,19 +1189,19 @@ void run_vocoder(zvx_ctx* c, const float* mel, int ldm, int Lmel_max, const int*
             a.M = rows_in; a.K = Cin; a.nbatch = B; a.in_len = len_in; a.out_len = len_in;
             a.bias_mode = 1; a.act = ACT_LRELU; a.slope = 0.1f;
             a.o_bs = (long)rows_in * u * Cout; a.ldo = u * Cout;
-            if (dt == DT_BF16 && c->has(up + "_wlo")) {
+            if (dt != DT_F32 && c->has(up + "_wlo")) {
                 // k = 2u: two 2-tap GEMMs over half the phases each (rows t-1, t / rows t, t+1) instead of one 3-tap GEMM
                 const int hc = (u / 2) * Cout;
                 a.N = hc; a.ntaps = 2; a.w_ts = (long)hc * Cin; a.flops = 2.0 * B * (double)rows_in * Cin * Cout * ku / 2;
-                a.W = c->t(up + "_wlo").dev; a.dv[0] = -1; a.dv[1] = 0;
+                a.W = vt(up + "_wlo").dev; a.dv[0] = -1; a.dv[1] = 0;
                 a.bias = c->pf(up + "_b"); a.out = X0;
                 c->gemm(a);
                 a.Wp = nullptr;
-                a.W = c->t(up + "_whi").dev; a.dv[0] = 0; a.dv[1] = 1;
+                a.W = vt(up + "_whi").dev; a.dv[0] = 0; a.dv[1] = 1;
                 a.bias = c->pf(up + "_b") + hc; a.out = (char*)X0 + (size_t)hc * es;
                 c->gemm(a);
             } else {
-                a.W = c->t(up + "_w").dev; a.w_ts = (long)u * Cout * Cin; a.N = u * Cout;
+                a.W = vt(up + "_w").dev; a.w_ts = (long)u * Cout * Cin; a.N = u * Cout;
                 a.ntaps = 3; a.dv[0] = -1; a.dv[1] = 0; a.dv[2] = 1;
                 a.bias = c->pf(up + "_b"); a.out = X0;
                 a.flops = 2.0 * B * (double)rows_in * Cin * Cout * ku;
@@ -1253,22 +1259,22 @@ void run_vocoder(zvx_ctx* c, const float* mel, int ldm, int Lmel_max, const int*
                 const void* cur = X0s;
                 int pp = 0;
                 int t_first = 0;
-                if (c->voc_resblock == 1 && dt == DT_BF16 && c->use_resstream && nd >= 1 && nd <= 3) {
+                if (c->voc_resblock == 1 && dt != DT_F32 && c->use_resstream && nd >= 1 && nd <= 3) {
                     // whole ResBlock (or its first two pairs + the last one) as streaming launches: the stage tensor crosses HBM once
                     bool packed_ok = true;
                     for (int t = 0; t < nd; t++)
-                        packed_ok = packed_ok && c->packed.count(c->t(rb + ".c1_" + std::to_string(t) + "_w").dev) && c->packed.count(c->t(rb + ".c2_" + std::to_string(t) + "_w").dev);
+                        packed_ok = packed_ok && c->packed.count(vt(rb + ".c1_" + std::to_string(t) + "_w").dev) && c->packed.count(vt(rb + ".c2_" + std::to_string(t) + "_w").dev);
                     auto chain = [&](int t0, int np, const void* in, bool closes) {
                         StreamArgs sa;
                         memset(&sa, 0, sizeof sa);
                         sa.X = in; sa.x_bs = (long)rows * Cout; sa.ldx = Cout; sa.C = Cout; sa.ntaps = k; sa.npair = np;
                         for (int q = 0; q < np; q++) {
                             const std::string ts = std::to_string(t0 + q);
-                            sa.W1[q] = c->packed[c->t(rb + ".c1_" + ts + "_w").dev]; sa.W2[q] = c->packed[c->t(rb + ".c2_" + ts + "_w").dev];
+                            sa.W1[q] = c->packed[vt(rb + ".c1_" + ts + "_w").dev]; sa.W2[q] = c->packed[vt(rb + ".c2_" + ts + "_w").dev];
                             sa.b1[q] = c->pf(rb + ".c1_" + ts + "_b"); sa.b2[q] = c->pf(rb + ".c2_" + ts + "_b");
                             sa.dil[q] = dil[t0 + q];
                         }
-                        sa.opt = c->rs_opt; sa.seg_min = c->rs_seg_min;
+                        sa.opt = c->rs_opt; sa.seg_min = c->rs_seg_min; sa.f16 = h16;
                         if (c->rs_prof) sa.prof = (long long*)c->buf("rs.prof." + rb + "." + std::to_string(t0), 16 * 16 * 8);   // RS_PROFILE builds only
                         sa.slope1 = 0.1f; sa.res_inv_slope = 10.0f; sa.out_scale = 1.f; sa.slope = 0.1f;
                         sa.len = lens; sa.M = rows; sa.nbatch = Bs; sa.o_bs = (long)rows * Cout; sa.ldo = Cout; sa.a_bs = (long)rows * Cout; sa.lda = Cout;
@@ -1332,9 +1338,9 @@ void run_vocoder(zvx_ctx* c, const float* mel, int ldm, int Lmel_max, const int*
                     GemmArgs a = rb_base();
                     if (c->voc_resblock == 1) {
                         const std::string ts = std::to_string(t);
-                        const Tensor& w1 = c->t(rb + ".c1_" + ts + "_w");
-                        const Tensor& w2 = c->t(rb + ".c2_" + ts + "_w");
-                        bool fuse = dt == DT_BF16 && c->packed.count(w1.dev) && c->packed.count(w2.dev);
+                        const Tensor& w1 = vt(rb + ".c1_" + ts + "_w");
+                        const Tensor& w2 = vt(rb + ".c2_" + ts + "_w");
+                        bool fuse = dt != DT_F32 && c->packed.count(w1.dev) && c->packed.count(w2.dev);
                         if (fuse) {
                             // one launch: xt = lrelu(c1(x_act)+b1) stays in LDS; x' = c2(xt) + b2 + x      hifigan.py:51-55
                             a.X = cur; a.W = w2.dev; a.Wp = c->packed[w2.dev]; a.Wp2 = c->packed[w1.dev];
@@ -1370,7 +1376,7 @@ void run_vocoder(zvx_ctx* c, const float* mel, int ldm, int Lmel_max, const int*
                         }
                     } else {
                         // x = c(lrelu(x)) + x                                          hifigan.py:78-81
-                        a.X = cur; a.W = c->t(rb + ".c_" + std::to_string(t) + "_w").dev;
+                        a.X = cur; a.W = vt(rb + ".c_" + std::to_string(t) + "_w").dev;
                         set_taps_1d(a, k, dil[t]);
                         a.bias = c->pf(rb + ".c_" + std::to_string(t) + "_b");
                         rb_tail(a);
@@ -1731,6 +1737,7 @@ zvx_status zvx_set_int(zvx_ctx* c, const char* key, int64_t value) {
         else if (std::string(key) == "flash") c->use_flash = (int)value;
         else if (std::string(key) == "attn_f32") c->use_attn_f32 = (int)value;
         else if (std::string(key) == "dec_f16") c->dec_f16 = (int)value;
+        else if (std::string(key) == "voc_f16") c->voc_f16 = (int)value;
         else if (std::string(key) == "dec_flat") c->dec_flat = (int)value;
         else if (std::string(key) == "dec_sc_fuse") c->dec_sc_fuse = (int)value;
         else if (std::string(key) == "norm_fuse_maxb") c->norm_fuse_maxb = (int)value;

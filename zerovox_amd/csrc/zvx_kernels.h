@@ -131,6 +131,7 @@ struct StreamArgs {
     double flops;                                  // filled by the launcher
     long long* prof;                               // RS_PROFILE builds: per-wave cycle counters of workgroup 0
     int seg_min;                                   // 0: segments as short as 256 rows when the job cannot fill the chip; < 0: never below 2048 (A/B)
+    int f16;                                       // the 16-bit tensors (x, rings, weights, xs, output) are IEEE half instead of bf16
     int opt;                                       // bit 0: staggered wave priorities, bit 1: balanced role -> SIMD table (zvx_set_int("rs_opt", v): A/B switch)
 };
 // variant id (index into gemm_variant_name) or -1 when the shape is not covered; dry_run: decide only, launch nothing
@@ -152,6 +153,7 @@ struct PairArgs {
     float slope1, res_inv_slope, out_scale, slope; // slope 1 = no output activation
     const int* len; int M, nbatch;
     int force;                                     // 1: also for jobs below the size where the kernel pays (tests); 2: and with 256-row segments
+    int f16;                                       // the 16-bit tensors (x, T, weights, xs, output) are IEEE half instead of bf16
     int S, nseg, DX, DT, G0;                       // filled by the launcher: segment rows, segments per utterance, ring rows
     long long* prof;                               // PS_PROFILE builds: [8 waves][main, epilogue, barrier, -] cycle totals of workgroup 0
 };
@@ -170,6 +172,7 @@ struct FlashArgs {
     const int* len; int L, D, nheads, nbatch;
     float scale;                                         // 1 / sqrt(D)   (fs2.py:49-50)
     int f16;                                             // the 16-bit tensors are IEEE half instead of bf16
+    long long* prof;                                     // FA_PROFILE builds (tools/micro/fa_bench.hip): per-phase cycle totals of workgroup 0, wave 0
 };
 bool launch_flash_attention(const FlashArgs& a, hipStream_t stream, bool dry_run);
 // exact-f32 fused attention of the phoneme encoder: Q | K | V columns of one projection buffer, head h at column off + h*D
