@@ -40,6 +40,7 @@ void flash_profile_events(hipEvent_t start, hipEvent_t stop) { g_fa_ev_start = s
 #define FA_BQ 128
 #define FA_BK 64
 #define FA_NKB (FA_BK / 32)      // 32-key blocks per tile
+#define FA_TAU 8.0f              // log2 units the running maximum may outgrow the softmax reference before the accumulators are rescaled
 
 // F16: Q / K / V^T / output (and the probabilities fed to the second product) are IEEE half instead of bf16 (the FS2 decoder in
 // the 16-bit mode, like the StyleTTS decoder: same MFMA rate, 8x smaller rounding error)
@@ -206,15 +207,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     for (int t = 0; t < ntiles; t++) {
         const int k0 = t * FA_BK;
         // the next tile's K rows and V^T rows go into the other buffer (last read before the previous tile's closing barrier); their NDMA
-        // requests per wave are issued BETWEEN the matrix steps of the score product (one per ~2 steps: the rate at which the CU's
-        // vector-memory path takes 1-KiB requests from four waves) and land under the softmax and the second product
+        // requests per wave are issued BETWEEN the matrix steps of the score product and of the first half of the second product (one per
+        // ~2.7 steps: the CU's vector-memory path takes a 1-KiB request per ~16 cycles, four waves feed it; closer spacing stalls the issue)
         const bool more = !(FA_EXP & 2) && t + 1 < ntiles;
         const i32x4 rk = k_rsrc(more ? k0 + FA_BK : k0), rv = v_rsrc(more ? k0 + FA_BK : k0);
         const int nbuf = (t + 1) & 1;
-        auto hook = [&](auto ic) __attribute__((always_inline)) {
-            constexpr int I = decltype(ic)::value, NS = FA_NKB * KS;
-            constexpr int j = I * NDMA / NS;
-            if constexpr (((I + 1) * NDMA) / NS > j) { if (more) dma_req(std::integral_constant<int, j>{}, rk, rv, nbuf); }
+        // step g of the tile's 34 + 36 matrix steps carries request j when the ramp j = g NDMA / NSPREAD steps up there; the last NDMA-free
+        // steps of the second product (and the closing barrier) cover the latency of the last requests
+        constexpr int NS1 = FA_NKB * KS, NSPREAD = NS1 + NDB * 2 * FA_NKB / 2;
+        auto hook1 = [&](auto ic) __attribute__((always_inline)) {
+            constexpr int g = decltype(ic)::value, j = g * NDMA / NSPREAD;
+            if constexpr (g < NSPREAD && ((g + 1) * NDMA) / NSPREAD > j) { if (more) dma_req(std::integral_constant<int, j>{}, rk, rv, nbuf); }
+        };
+        auto hook2 = [&](auto ic) __attribute__((always_inline)) {
+            constexpr int g = NS1 + decltype(ic)::value, j = g * NDMA / NSPREAD;
+            if constexpr (g < NSPREAD && ((g + 1) * NDMA) / NSPREAD > j) { if (more) dma_req(std::integral_constant<int, j>{}, rk, rv, nbuf); }
         };
         const unsigned char* const kb = lds + (t & 1) * (KBYTES + VBYTES);
         const unsigned char* const vb = kb + KBYTES;
@@ -226,7 +233,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
             for (int e = 0; e < 16; e++) s[kbk][e] = 0.f;
         FA_STAMP(0);
-        if (!(FA_EXP & 8)) fa_chain<3, KS, 32 * KP, F16, FA_NKB>(lds_base + (unsigned)(kb - lds) + (unsigned)(l32 * KP + hi * 16), s, qf, hook);
+        if (!(FA_EXP & 8)) fa_chain<3, KS, 32 * KP, F16, FA_NKB>(lds_base + (unsigned)(kb - lds) + (unsigned)(l32 * KP + hi * 16), s, qf, hook1);
         // the other buffer's K half: last read in tile t-1's score product, behind that tile's closing barrier
         FA_STAMP(1);
         FA_STAMP(2);
@@ -247,11 +254,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
 #pragma unroll
             for (int e = 0; e < 16; e++) mt = fmaxf(mt, s[kbk][e]);
         mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
-        const float m_new = fmaxf(m_run, mt * sc);                  // finite: every tile has at least one valid key (sc > 0)
-        // the running max moves in the first tiles and rarely afterwards: when it has moved for NO query of the wave the rescale
-        // factor is exactly 1 for all of them and the 144 accumulator multiplies are skipped (identical results)
-        const bool moved = __builtin_amdgcn_ballot_w64(m_new != m_run) != 0;
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);  // first tile: exp2(-inf) = 0
+        const float m_cand = fmaxf(m_run, mt * sc);                 // finite: every tile has at least one valid key (sc > 0)
+        // The reference point of the exponentials only has to be NEAR the running maximum: p = exp2(s sc - m_run) stays below 2^FA_TAU as long
+        // as the true maximum has not grown past m_run + FA_TAU, and softmax is a ratio -- the final division by the row sum makes any common
+        // reference exact.  So the reference (and with it the 144 accumulator rescales per lane, each a trip through the accumulation
+        // registers: ~1500 cycles of a ~7000-cycle tile) moves only when some query of the wave has outgrown it by more than FA_TAU; with
+        // FA_TAU = 8 that is the first tile and almost never again.  f32 row sums and f16 / bf16 probabilities up to 256 are far inside range.
+        const bool moved = __builtin_amdgcn_ballot_w64(m_cand > m_run + FA_TAU) != 0;      // wave-uniform (first tile: m_run = -inf)
+        const float m_new = moved ? m_cand : m_run;
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);  // first tile: exp2(-inf) = 0; not moved: exactly 1 (unused)
         m_run = m_new;
         float rs = 0.f;
         unsigned pk[FA_NKB][8];                                      // probabilities as bf16 pairs: pk[kbk][2 g + (0: e 0,1 | 1: e 2,3)]
@@ -288,7 +299,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             }
         // ---- O^T += V^T.P^T ----
         FA_STAMP(3);
-        if (!(FA_EXP & 4)) fa_chain<3, 2 * FA_NKB, 32 * VP, F16, NDB>(lds_base + (unsigned)(vb - lds) + (unsigned)(l32 * VP + hi * 16), o, pf);
+        if (!(FA_EXP & 4)) fa_chain<3, 2 * FA_NKB, 32 * VP, F16, NDB>(lds_base + (unsigned)(vb - lds) + (unsigned)(l32 * VP + hi * 16), o, pf, hook2);
         FA_STAMP(4);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the next tile's pieces have landed (requested a whole softmax + second product ago)
         FA_STAMP(5);

@@ -1617,7 +1617,7 @@ static int launch_convslab(GemmArgs a, hipStream_t stream) {
         ZVX_LAUNCH((convslab_kernel<256, 128, 2, 2, true, 2, 0, -1, 160>), grid, dim3(256), lds, stream, a);
         return 7;
     }
-    if (a.dtype != DT_F32 && a.N == a.K && (a.ntaps == 3 || a.ntaps == 7 || a.ntaps == 11)) {
+    if (a.dtype != DT_F32 && a.N == a.K && !a.K2 && (a.ntaps == 3 || a.ntaps == 7 || a.ntaps == 11)) {   // (a second source exists on the slab kernel only: round 5, found on a reduced-width model whose fused shortcut convolutions are square with C = 32 / 64)
         if (a.N == 32 && launch_convreg_c<32, 512, 4, 1, 2>(a, stream)) return 14;
         if (a.N == 64 && launch_convreg_c<64, 256, 2, 2, 2>(a, stream)) return 15;
     }

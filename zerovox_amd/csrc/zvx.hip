@@ -1051,6 +1051,10 @@ void decoder_styletts(zvx_ctx* c, const float* feats, const float* spk_d, const 
     sty_conv(s, "sty.enc0.c1", t0, H, H, t1, H, dt, H, nullptr, 0, 1.f);
     sty_norm(s, t1, H, H, t0, H, c->pf("sty.enc0.norm2_g"), c->pf("sty.enc0.norm2_b"), 0, 0, ACT_LRELU);
     auto can_fuse_shortcut = [&](const std::string& blk) {
+        if (c->dec_sc_fuse >= 2) {                            // development: bits 1.. select the blocks (enc0, dec0, dec1, dec2) that may fuse
+            const int bi = blk == "sty.enc0" ? 0 : (blk.size() == 8 ? 1 + (blk[7] - '0') : 9);
+            if (!((c->dec_sc_fuse >> (1 + bi)) & 1)) return false;
+        }
         return c->dec_sc_fuse && dt != DT_F32 && c->has(blk + ".c2") && c->pair_packed.count(c->t(dt == DT_F16 ? blk + ".c2.h16" : blk + ".c2").dev) != 0;
     };
     if (can_fuse_shortcut("sty.enc0")) {
