@@ -361,7 +361,10 @@ def main(argv=None, ctx_factory=default_ctx_factory):
                      "front_overlap": ("off" if overrides.get("front_overlap") == 0 else
                                        "one context, two streams: the encoder / variance adaptor / mel decoder of step i+1 are queued on the context's front stream and run under the vocoder of step i (every step is a whole batch, all complete at the closing fence; bit-identical to the serial schedule)"),
                      "decoder_arithmetic": ("f32" if args.precision == "f32" else
-                                            "IEEE half weights + activations on the f16 MFMA (log-mel within 2e-2 of the f32 reference); vocoder: bf16"),
+                                            "IEEE half weights + activations on the f16 MFMA (log-mel within 2e-2 of the f32 reference)"),
+                     "vocoder_arithmetic": ("f32" if args.precision == "f32" else
+                                            ("bf16 weights + activations + running sum (rounds 1-4; A/B: --set voc_f16=0)" if overrides.get("voc_f16", 1) == 0 else
+                                             "IEEE half weights + activations + running sum on the f16 MFMA, saturating stores (round 5 default: waveform error 8x below bf16's, ~3 % more time at the board's power limit)")),
                      "wav_delivery": "host (synchronous D2H copy of every step's waveform inside the timed region)" if args.host_out else
                                      "device (rows stay in HBM for the gather / the caller; --host-out times the D2H copy too)"}
     elif args.config == 4:
@@ -457,6 +460,14 @@ def main(argv=None, ctx_factory=default_ctx_factory):
         w = (host_wav[0] if (args.config == 2 and args.host_out) else ctx.dev_to_host(wav[0], (B, N), wdt))[0].astype(np.float32) / (32760.0 if args.pcm16 else 1.0)
         ok = ok and bool(np.isfinite(w).all()) and 0 < float(np.abs(w).max()) <= 1.0
 
+    # the arithmetic type of the workload's dominant stage: the 16-bit mode ("--precision bf16", the manifest's name for it) computes the
+    # vocoder and both mel decoders on the IEEE-half MFMA since round 5 (zvx_set_int voc_f16 / dec_f16 0: bf16), the speaker encoder in bf16
+    if args.precision == "f32":
+        dtype_name = "f32"
+    elif args.config == 5:
+        dtype_name = "bf16"
+    else:
+        dtype_name = "bf16" if overrides.get("voc_f16", 1) == 0 else "f16"
     if rank == 0:
         total = float(world) * units_per_step * args.steps
         value = total / elapsed
@@ -466,7 +477,7 @@ def main(argv=None, ctx_factory=default_ctx_factory):
                        "speaker embeddings/sec, ResNetSE34V2 on 3 s reference mels (BASELINE configs[4])"),
             "value": value, "unit": unit, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "timed_region_s": elapsed, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+            "vs_baseline": None, "dtype": dtype_name, "data": "synthetic",
             "config": {"workload": workload, **cfg_extra, **({"overrides": overrides} if overrides else {})},
             "stage_ms_last_step": stage_ms, "output_ok": ok, "src_sha16": src_sha16(), "untimed_busy_tail_steps": busy_steps,
         }

@@ -5,7 +5,7 @@ set -eu
 TAG=$1; R=$2
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 S=$ROOT/gpurun_out/prof_$TAG; D=$ROOT/profiles
-for f in $S/bench_*.json $S/kernel_trace_*.txt $S/rocprofv3_kernel_stats_*.csv $S/pmc_*.txt; do
+for f in $S/bench_*.json $S/kernel_trace_*.txt $S/rocprofv3_kernel_stats_*.csv $S/pmc_*.txt $S/power_*.txt; do
   [ -s "$f" ] && cp $f $D/${R}_$(basename $f)
 done
 for f in $S/traffic*.json; do [ -s "$f" ] && cp $f $D/$(basename $f); done

@@ -21,6 +21,7 @@ ap.add_argument("--seconds", type=float, default=15.0)
 ap.add_argument("--what", default="step", choices=["step", "vocoder"])
 ap.add_argument("--pairstream", type=int, default=2)
 ap.add_argument("--zeros", action="store_true")
+ap.add_argument("--voc-f16", type=int, default=1, help="0: the bf16 vocoder kernels of rounds 1-4 (A/B of the round-5 IEEE-half default)")
 args = ap.parse_args()
 
 
@@ -59,7 +60,8 @@ if args.zeros:
     hsd = {k: (np.zeros_like(v) if "bias" in k else v) for k, v in hsd.items()}
 man, blob = pack.pack_model(cfg, sd, h, hsd, "bf16")
 ctx = _lib.Context(man, blob, 0)
-ctx.set_int("pairstream", args.pairstream)
+ctx.set_int("pairstream", 1 if args.pairstream == 2 else args.pairstream)
+ctx.set_int("voc_f16", args.voc_f16)
 B, T = 32, 128
 if args.what == "step" and not args.zeros:
     ph, pu, Tlen, spk, dur = synthetic.batch(B, T, first_utt=0, dur_mode="const7")
@@ -98,7 +100,7 @@ dt = time.time() - t0
 stop[0] = True; th.join()
 after = flat(smi(["-E", "-v", "-p"]))
 
-print(f"# tools/power_readout.py  --what {args.what} --pairstream {args.pairstream}{' --zeros' if args.zeros else ''}")
+print(f"# tools/power_readout.py  --what {args.what} --pairstream {args.pairstream} --voc-f16 {args.voc_f16}{' --zeros' if args.zeros else ''}")
 print(f"workload: {what}")
 print(f"{n} steps in {dt:.2f} s = {1e3 * dt / n:.3f} ms per step (host loop, synchronised every 10 steps)")
 ek = [k for k in before if "energy" in k.lower() and isinstance(before[k], (int, float)) and isinstance(after.get(k), (int, float))]

@@ -64,6 +64,10 @@ python $ROOT/bench.py --host-out --no-cpu-baseline > $OUT/bench_n1_host_out.json
 python $ROOT/bench.py --set front_overlap=0 --no-cpu-baseline > $OUT/bench_n1_serial.json 2> $OUT/bench_n1_serial.err                 # A/B: every call's front end behind the previous vocoder
 python $ROOT/bench.py --set enc_split=1 --no-cpu-baseline > $OUT/bench_n1_bf16_planes.json 2> $OUT/bench_n1_bf16_planes.err          # A/B: the encoder's split products on bf16 planes (rounds 2-3)
 python $ROOT/bench.py --in-flight 2 --no-cpu-baseline > $OUT/bench_n1_in_flight2.json 2> $OUT/bench_n1_in_flight2.err
+python $ROOT/bench.py --set voc_f16=0 --no-cpu-baseline > $OUT/bench_n1_voc_bf16.json 2> $OUT/bench_n1_voc_bf16.err                    # A/B (round 5): the bf16 vocoder kernels of rounds 1-4
+python $ROOT/bench.py --no-cpu-baseline > $OUT/bench_n1_again.json 2> $OUT/bench_n1_again.err                                         # ... and the default once more right behind it (same box, minutes apart)
+for V in 1 0; do timeout 120 python $ROOT/tools/power_readout.py --what vocoder --voc-f16 $V > $OUT/power_vocoder_f16_$V.txt 2>&1; done   # J per vocoder pass, half against bf16
+timeout 120 python $ROOT/tools/power_readout.py --what step > $OUT/power_step.txt 2>&1
 if [ -z "$QUICK" ]; then
   profile_workload cfg4 --config 4
   python $ROOT/bench.py --config 4 > $OUT/bench_cfg4.json 2> $OUT/bench_cfg4.err

@@ -6,11 +6,11 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libzvx.so")
-SOURCES = ["gemm.hip", "resstream.hip", "pairstream.hip", "attention.hip", "ops.hip", "zvx.hip"]
+SOURCES = ["gemm.hip", "resstream.hip", "pairstream.hip", "narrowstage.hip", "attention.hip", "ops.hip", "zvx.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-inline-asm"]
 # gemm.hip: no NaN is ever a legitimate operand of its epilogue min/max (leaky-relu and its inverse); without this flag every
 # fminf/fmaxf input coming from a bit operation (bf16 unpack) gets a canonicalising `v_max x, x, x` in front (IEEE mode)
-EXTRA_FLAGS = {"gemm.hip": ["-fno-honor-nans"], "pairstream.hip": ["-fno-honor-nans"], "resstream.hip": ["-fno-honor-nans"] + (["-DRS_PROFILE"] if os.environ.get("ZVX_RS_PROFILE_BUILD") else [])}
+EXTRA_FLAGS = {"gemm.hip": ["-fno-honor-nans"], "pairstream.hip": ["-fno-honor-nans"], "narrowstage.hip": ["-fno-honor-nans"], "resstream.hip": ["-fno-honor-nans"] + (["-DRS_PROFILE"] if os.environ.get("ZVX_RS_PROFILE_BUILD") else [])}
 
 
 def _stale(target, deps):

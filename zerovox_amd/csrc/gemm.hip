@@ -1543,6 +1543,7 @@ static const Variant kVariants[] = {
     {"resstream_bf16_c32", DT_BF16, 64, 32},      {"resstream_bf16_c64", DT_BF16, 32, 64},
     {"convslab_bf16_128x128", DT_BF16, 128, 128},
     {"pairstream_bf16_c128", DT_BF16, 128, 128},
+    {"narrowstage_c16", DT_BF16, 256, 16}, {"narrowstage_c8", DT_BF16, 512, 8},      // whole narrow stages in one launch (narrowstage.hip)
 };
 const char* gemm_variant_name(int id) { return kVariants[id].name; }
 int gemm_num_variants() { return (int)(sizeof(kVariants) / sizeof(kVariants[0])); }

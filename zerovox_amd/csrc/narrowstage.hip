@@ -1,0 +1,265 @@
+// narrowstage.hip -- a WHOLE HiFi-GAN stage of narrow width (C = 16 / 8: the last two stages of HiFi-GAN V2, the reference's default
+// vocoder, model.py:84) in ONE launch:  hifigan.py:116-125
+//
+//     out = lrelu( ( rb_k0(x) + rb_k1(x) + rb_k2(x) ) / nk , slope )          rb_k = three times  x += conv_1(lrelu(conv_d(lrelu(x))))
+//
+// Rounds 1-4 ran these stages as 9 launches each (one per ResBlock pair on resfuse_persist): the 117 MB stage tensor crossed HBM ~20
+// times per stage and the 32 x 32 x 16 matrix instruction worked at 1/2 (C = 16) resp. 1/8 (C = 8) of its width -- 0.03-0.09 of the
+// matrix roof, 0.18-0.29 of HBM, 2.7 ms of the V2 step.  Here the stage tensor is read once and written once:
+//   * a persistent workgroup walks tiles of R rows of one utterance; the tile (+ 64 halo rows either side: 3 h + (d0 + d1 + d2) h = 60
+//     for k = 11, dilations 1 / 3 / 5) and every intermediate of the 18 convolutions live in LDS (X | T | Ya | Yb), the running sum over
+//     the ResBlocks in f32 REGISTERS (rounds 1-4 kept it in a 16-bit tensor in HBM: two roundings fewer per output);
+//   * matrix shape 16 x 16 x 32 with the taps STACKED into the contraction: K = 32 = 2 taps x 16 channels (C = 16) resp. 4 taps x 8
+//     channels (C = 8), M = output channels, N = 16 time rows.  A lane's B operand is 16 contiguous bytes of one LDS row (row n +
+//     tap offset, half-row kb % 2 resp. the whole 8-channel row), its four accumulators are 4 consecutive channels of one row: 8-byte
+//     LDS / HBM stores in the time-major layout.  k = 3 / 7 / 11 take 2 / 4 / 6 matrix steps per 16 rows at C = 16 (1 / 2 / 3 at C = 8);
+//   * all weight fragments of the stage (72 KiB at C = 16, 36 KiB at C = 8) and the biases sit in LDS for the workgroup's lifetime;
+//   * every convolution computes exactly the rows later convolutions need (the halo shrinks along the chain), in 16-row blocks dealt
+//     round-robin to the waves; one barrier per convolution.
+// Rows outside the utterance are zeros in every stream (each convolution zero-pads ITS input, hifigan.py:39-44), so an utterance's
+// result does not depend on the batch or on where tile boundaries fall: streamed and whole-utterance vocoding stay bit-identical.
+#include "mfma_util.h"
+#include "zvx_kernels.h"
+
+#include <hip/hip_ext.h>
+
+#include <type_traits>
+
+namespace zvx {
+
+static thread_local hipEvent_t g_ns_ev_start = nullptr, g_ns_ev_stop = nullptr;
+void narrowstage_profile_events(hipEvent_t start, hipEvent_t stop) { g_ns_ev_start = start; g_ns_ev_stop = stop; }
+
+#define NS_HB 64          // halo rows kept either side of a tile (a multiple of the 16-row block)
+#define NS_GUARD 16       // rows in front of / behind the halo that block-rounded convolutions may touch (never consumed)
+
+template <int I, int N, class F>
+__device__ __forceinline__ void ns_static_for(F&& f) {
+    if constexpr (I < N) { f(std::integral_constant<int, I>{}); ns_static_for<I + 1, N>(f); }
+}
+template <bool H>
+__device__ __forceinline__ f32x4 ns_mfma(const uint4& a, const uint4& b, const f32x4& c) {
+    if constexpr (H) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+// fragment order of one convolution's weights for this kernel: step s, lane (m = lane % 16, kb = lane / 16) holds
+//   C = 16: W[tap 2 s + kb / 2][out m][in (kb % 2) 8 .. + 8]        C = 8: W[tap 4 s + kb][out m][in 0 .. 8]   (zeros past the last tap / channel)
+__global__ void k_pack_narrow(const unsigned short* w /*[k][C][C]*/, int k, int C, uint4* out, int nsteps) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= nsteps * 64) return;
+    const int lane = idx & 63, s = idx >> 6, m = lane & 15, kb = lane >> 4;
+    const int tap = C == 16 ? 2 * s + (kb >> 1) : 4 * s + kb, ch0 = C == 16 ? (kb & 1) * 8 : 0;
+    unsigned short v[8];
+    for (int e = 0; e < 8; e++) v[e] = (tap < k && m < C && ch0 + e < C) ? w[((long)tap * C + m) * C + ch0 + e] : (unsigned short)0;
+    out[idx] = make_uint4(v[0] | ((unsigned)v[1] << 16), v[2] | ((unsigned)v[3] << 16), v[4] | ((unsigned)v[5] << 16), v[6] | ((unsigned)v[7] << 16));
+}
+int narrowstage_steps(int C, int k) { const int tpm = 32 / C; return (k + tpm - 1) / tpm; }
+void launch_pack_narrow(const void* w16, int k, int C, void* out, hipStream_t s) {
+    const int n = narrowstage_steps(C, k) * 64;
+    hipLaunchKernelGGL(k_pack_narrow, dim3((n + 255) / 256), dim3(256), 0, s, (const unsigned short*)w16, k, C, (uint4*)out, narrowstage_steps(C, k));
+}
+
+template <int C, int R, int NW, bool H16>
+struct NsKernel {
+    static constexpr int P = C == 16 ? 48 : 16;                        // LDS row pitch: 32 B + 16 B pad (16 rows x 12 dwords cover the 64 banks once) / 16 B
+    static constexpr int TPM = 32 / C;                                 // taps per matrix step
+    static constexpr int ROWS = R + 2 * NS_HB + 2 * NS_GUARD;          // rows of an LDS stream buffer
+    static constexpr int NBT = R / 16;                                 // output blocks of a tile
+    static constexpr int NBW = (NBT + NW - 1) / NW;                    // ... per wave
+    static constexpr int QN = C == 16 ? 4 : 2;                         // 4-channel groups that exist
+
+    const StageArgs& a;
+    unsigned char* const X; unsigned char* const T; unsigned char* const Ya; unsigned char* const Yb;
+    const uint4* const wl; const float* const bias_l;
+    const int lane, wave, n, grp, kb;
+    int m0, len;
+    f32x4 sum[NBW];
+
+    __device__ __forceinline__ NsKernel(const StageArgs& a_, unsigned char* lds, int wbytes)
+        : a(a_), X(lds), T(lds + ROWS * P), Ya(lds + 2 * ROWS * P), Yb(lds + 3 * ROWS * P), wl((const uint4*)(lds + 4 * ROWS * P)),
+          bias_l((const float*)(lds + 4 * ROWS * P + wbytes)), lane(threadIdx.x & 63), wave(__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)),
+          n(lane & 15), grp(lane >> 4), kb(lane >> 4), m0(0), len(0) {}
+
+    // KIND 0: conv1 (dilated; T = lrelu(. + b1)), 1: conv2 feeding the next pair (Y = lrelu(. + b2 + x)), 2: a ResBlock's last conv2 (-> sum)
+    template <int K, int KIND>
+    __device__ __forceinline__ void conv(int ci, const unsigned char* src, unsigned char* dst, const unsigned char* res, int dil, int E) {
+        constexpr int S = (K + TPM - 1) / TPM, h = (K - 1) / 2;
+        uint4 wf[S];
+        const uint4* const wq = wl + (long)a.woff[ci] * 64 + lane;
+#pragma unroll
+        for (int s = 0; s < S; s++) wf[s] = wq[s * 64];
+        float4 bq = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (grp < QN) bq = *(const float4*)(bias_l + ci * C + 4 * grp);
+        // this lane's B-operand offsets (bytes, relative to its row of the block) per matrix step: tap - h rows of `dil`, half-row kb % 2 at C = 16
+        int boff[S];
+#pragma unroll
+        for (int s = 0; s < S; s++) {
+            int tap = C == 16 ? 2 * s + (kb >> 1) : 4 * s + kb;
+            if (tap > K - 1) tap = K - 1;                               // (a slot past the last tap multiplies zeros of A: any in-range row will do)
+            boff[s] = (tap - h) * dil * P + (C == 16 ? (kb & 1) * 16 : 0);
+        }
+        const float slope1 = a.slope1, rinv = a.res_inv_slope;
+        auto block = [&](int blk, auto ic) __attribute__((always_inline)) {
+            constexpr int i = decltype(ic)::value;
+            const int row = NS_GUARD + blk * 16 + n;                     // this lane's row of the LDS streams
+            const int g = m0 - NS_HB + blk * 16 + n;                     // ... of the utterance
+            const unsigned char* const bp = src + row * P;
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+            uint4 xf[S];
+#pragma unroll
+            for (int s = 0; s < S; s++) xf[s] = *(const uint4*)(bp + boff[s]);
+            uint2 rq = make_uint2(0, 0);
+            if (KIND >= 1 && grp < QN) rq = *(const uint2*)(res + row * P + grp * 8);
+#pragma unroll
+            for (int s = 0; s < S; s++) acc = ns_mfma<H16>(wf[s], xf[s], acc);
+            f32x2 v01 = (f32x2){acc[0], acc[1]} + (f32x2){bq.x, bq.y}, v23 = (f32x2){acc[2], acc[3]} + (f32x2){bq.z, bq.w};
+            if (KIND >= 1) { v01 += inv_lrelu2(unpack16<H16>(rq.x), rinv); v23 += inv_lrelu2(unpack16<H16>(rq.y), rinv); }
+            if constexpr (KIND == 2) {
+                sum[i] += (f32x4){v01.x, v01.y, v23.x, v23.y};
+            } else {
+                v01 = lrelu2(v01, slope1); v23 = lrelu2(v23, slope1);
+                uint2 pk;
+                const bool inside = g >= 0 && g < len;                  // streams are zero outside the utterance
+                pk.x = inside ? pack16<H16>(v01.x, v01.y) : 0u; pk.y = inside ? pack16<H16>(v23.x, v23.y) : 0u;
+                if (grp < QN) *(uint2*)(dst + row * P + grp * 8) = pk;
+            }
+        };
+        if constexpr (KIND == 2) {                                       // the tile's own rows: block wave + NW i <-> sum[i] for every ResBlock
+            ns_static_for<0, NBW>([&](auto ic) { const int blk = wave + NW * decltype(ic)::value; if (blk < NBT) block(NS_HB / 16 + blk, ic); });
+        } else {
+            const int lo = (NS_HB - E) / 16, hi = (NS_HB + R + E + 15) / 16;
+            for (int blk = lo + wave; blk < hi; blk += NW) block(blk, std::integral_constant<int, 0>{});
+        }
+        __syncthreads();
+    }
+
+    template <int K>
+    __device__ __forceinline__ void resblock(int j) {
+        constexpr int h = (K - 1) / 2;
+        const int d0 = a.dil[j][0], d1 = a.dil[j][1], d2 = a.dil[j][2], ci = 6 * j;
+        const int E4 = h, E3 = h + d2 * h, E2 = 2 * h + d2 * h, E1 = 2 * h + (d1 + d2) * h, E0 = 3 * h + (d1 + d2) * h;
+        conv<K, 0>(ci + 0, X, T, nullptr, d0, E0);
+        conv<K, 1>(ci + 1, T, Ya, X, 1, E1);
+        conv<K, 0>(ci + 2, Ya, T, nullptr, d1, E2);
+        conv<K, 1>(ci + 3, T, Yb, Ya, 1, E3);
+        conv<K, 0>(ci + 4, Yb, T, nullptr, d2, E4);
+        conv<K, 2>(ci + 5, T, nullptr, Yb, 1, 0);
+    }
+
+    __device__ __forceinline__ void tile(int b, int mt) {
+        const int tid = threadIdx.x;
+        m0 = mt * R;
+        const unsigned short* const Xb = (const unsigned short*)a.X + (long)b * a.x_bs;
+        // stage input rows [m0 - HB, m0 + R + HB) -> X (zeros outside the utterance); 16-byte chunks, coalesced
+        constexpr int CPR = C / 8, TOT = (R + 2 * NS_HB) * CPR;
+        for (int i0 = 0; i0 < TOT; i0 += 64 * NW * 4) {
+            uint4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int i = i0 + tid + u * 64 * NW, r = i / CPR, q = i - r * CPR, g = m0 - NS_HB + r;
+                v[u] = make_uint4(0, 0, 0, 0);
+                if (i < TOT && g >= 0 && g < len) v[u] = *(const uint4*)(Xb + (long)g * a.ldx + q * 8);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int i = i0 + tid + u * 64 * NW, r = i / CPR, q = i - r * CPR;
+                if (i < TOT) *(uint4*)(X + (NS_GUARD + r) * P + q * 16) = v[u];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NBW; i++) sum[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        __syncthreads();
+        for (int j = 0; j < a.nk; j++) {
+            const int k = a.ks[j];
+            if (k == 3) resblock<3>(j);
+            else if (k == 7) resblock<7>(j);
+            else if (k == 11) resblock<11>(j);
+            else resblock<5>(j);
+        }
+        // out = lrelu(sum / nk, slope): 8 bytes per lane (4 channels of one row); a wave's store covers 16 consecutive rows
+        const float inv = 1.0f / (float)a.nk, oslope = a.slope;
+        unsigned short* const Ob = (unsigned short*)a.out + (long)b * a.o_bs;
+#pragma unroll
+        for (int i = 0; i < NBW; i++) {
+            const int blk = wave + NW * i, g = m0 + blk * 16 + n;
+            if (blk < NBT && g < len && grp < QN) {
+                const f32x2 v01 = lrelu2((f32x2){sum[i][0], sum[i][1]} * inv, oslope), v23 = lrelu2((f32x2){sum[i][2], sum[i][3]} * inv, oslope);
+                *(uint2*)(Ob + (long)g * a.ldo + grp * 4) = make_uint2(pack16<H16>(v01.x, v01.y), pack16<H16>(v23.x, v23.y));
+            }
+        }
+    }
+};
+
+template <int C, int R, int NW, bool H16>
+__global__ __launch_bounds__(64 * NW) void narrowstage_kernel(const StageArgs a, int wbytes, int ntm, int ntiles) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    using KN = NsKernel<C, R, NW, H16>;
+    if (H16) f16_saturate_mode();
+    KN kn(a, lds, wbytes);
+    const int tid = threadIdx.x;
+    // the stage's weight fragments and biases: once per workgroup
+    {
+        uint4* const wd = (uint4*)(lds + 4 * KN::ROWS * KN::P);
+        const uint4* const ws = (const uint4*)a.W;
+        for (int i = tid; i < wbytes / 16; i += 64 * NW) wd[i] = ws[i];
+        float* const bd = (float*)(lds + 4 * KN::ROWS * KN::P + wbytes);
+        for (int i = tid; i < 6 * a.nk * C; i += 64 * NW) bd[i] = a.bias[i];
+        // the streams start as zeros: block-rounded convolutions read a few rows nothing has written yet (never consumed, but a stale
+        // NaN pattern there would not stay a NaN-free zero in 0 x garbage products of the padded matrix slots)
+        for (int i = tid; i < 4 * KN::ROWS * KN::P / 16; i += 64 * NW) ((uint4*)lds)[i] = make_uint4(0, 0, 0, 0);
+    }
+    __syncthreads();
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int b = t / ntm, mt = t - b * ntm;
+        int len = a.len ? a.len[b] : a.M;
+        len = __builtin_amdgcn_readfirstlane(len);
+        if (mt * R >= len) continue;
+        kn.len = len;
+        kn.tile(b, mt);
+        __syncthreads();
+    }
+}
+
+template <int C, int R, int NW>
+static bool launch_ns(const StageArgs& a, hipStream_t stream, bool dry_run) {
+    using KN = NsKernel<C, R, NW, false>;
+    int wfrags = 0;
+    for (int j = 0; j < a.nk; j++) wfrags += 6 * narrowstage_steps(C, a.ks[j]);
+    const int wbytes = wfrags * 1024;
+    const size_t lds = (size_t)4 * KN::ROWS * KN::P + wbytes + (size_t)6 * a.nk * C * 4;
+    if (lds > 160 * 1024) return false;
+    if (dry_run) return true;
+    const int ntm = (a.M + R - 1) / R, ntiles = ntm * a.nbatch;
+    const int ncu = persistent_cus();
+    const dim3 grid(ntiles < ncu ? ntiles : ncu), block(64 * NW);
+#define NS_GO(H_) do { auto kfn = narrowstage_kernel<C, R, NW, H_>; \
+        static std::atomic<bool> attr_done{false}; \
+        if (!attr_done) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_done = true; } \
+        if (g_ns_ev_start) hipExtLaunchKernelGGL(kfn, grid, block, lds, stream, g_ns_ev_start, g_ns_ev_stop, 0, a, wbytes, ntm, ntiles); \
+        else hipLaunchKernelGGL(kfn, grid, block, lds, stream, a, wbytes, ntm, ntiles); } while (0)
+    if (a.f16) NS_GO(true); else NS_GO(false);
+#undef NS_GO
+    return true;
+}
+
+// true when the stage is covered (and, unless dry_run, launched): C = 16 / 8, ResBlock1 with three pairs per block, kernel sizes in
+// {3, 5, 7, 11}, halo 3 h + (d0 + d1 + d2) h <= 64 rows, dense rows
+bool launch_narrowstage(const StageArgs& a, hipStream_t stream, bool dry_run) {
+    if ((a.C != 16 && a.C != 8) || a.nk < 1 || a.nk > 3 || a.ldx != a.C || a.ldo != a.C || !a.W || !a.bias || !a.X || !a.out) return false;
+    for (int j = 0; j < a.nk; j++) {
+        const int k = a.ks[j], h = (k - 1) / 2, d0 = a.dil[j][0], d1 = a.dil[j][1], d2 = a.dil[j][2];
+        if (!(k == 3 || k == 5 || k == 7 || k == 11) || d0 < 1 || d1 < 1 || d2 < 1) return false;
+        // every convolution's block-rounded row range, plus the rows its taps reach, must stay inside halo + guard
+        const int E[3] = {3 * h + (d1 + d2) * h, 2 * h + d2 * h, h}, d[3] = {d0, d1, d2};
+        for (int t = 0; t < 3; t++) {
+            if (E[t] + d[t] * h > NS_HB) return false;                                             // what the tile needs is inside the halo
+            const int lo = (NS_HB - E[t]) / 16 * 16;                                              // first row of the first block (stream rows, guard excluded)
+            if (lo - d[t] * h < -NS_GUARD || (NS_HB - lo) + d[t] * h > NS_HB + NS_GUARD) return false;
+        }
+    }
+    if (a.C == 16) return launch_ns<16, 256, 8>(a, stream, dry_run);
+    return launch_ns<8, 512, 8>(a, stream, dry_run);
+}
+
+}  // namespace zvx

@@ -124,6 +124,9 @@ struct zvx_ctx {
     int rs_seg_min = 0;                    // zvx_set_int("rs_seg_min", -1): streaming ResBlock segments never shorter than 2048 rows (A/B of the single-request sizing)
     int rs_opt = 3;                        // zvx_set_int("rs_opt", v): StreamArgs.opt of the streaming ResBlock kernels (bit 0: staggered wave priorities)
     int slab_small = 2, slab_flat = 1;     // zvx_set_int("slab_small" / "slab_flat", v): conv-slab tile choice for single requests / whole-grid XCD remap (A/B; per context)
+    int use_stagefuse = 1;                 // zvx_set_int("stagefuse", 0): narrow vocoder stages (C = 16 / 8) as per-pair launches instead of ONE launch per stage (narrowstage.hip; A/B)
+    struct NsWeights { void* W = nullptr; float* bias = nullptr; int woff[18] = {0}; };
+    std::map<std::string, NsWeights> ns_weights;   // narrowstage.hip fragment order, per (stage, dtype), built on first use
     int use_pairstream = 1;                // zvx_set_int("pairstream", v): C = 128 ResBlock pairs on pairstream.hip: 1 = every k (default; jobs under ~200 k rows run the bit-identical two-launch path), 3 = every k and every job size (tests), 4 = like 3 with 256-row segments for small jobs, 2 = k >= 7 only (k = 3 on the register-resident resfuse kernel, which adds the running sum after rounding to bf16), 0 = none, -1 = no fused kernel at all for C = 128 (two conv-slab launches per pair: the bit-equality reference)
     int shape_log = 0;                     // zvx_set_int("shape_log", 1): one stderr line per timed launch (profile 2)
     int max_frames = 1 << 18;              // hard cap on a predicted mel length (guards the allocation, fs2.py:678-681 has none)
@@ -1220,6 +1223,62 @@ void run_vocoder(zvx_ctx* c, const float* mel, int ldm, int Lmel_max, const int*
         // MFMA issue, not by HBM -- so the default is the whole batch.  Results are bit-identical for any sub-batch size.
         const size_t utt_bytes = (size_t)rows * Cout * es;
         const int CH = (c->voc_chunk > 0 && c->voc_chunk < B) ? c->voc_chunk : B;
+        // narrow stages (C = 16 / 8: HiFi-GAN V2's last two): all ResBlocks of the stage, their mean and the next stage's activation in ONE
+        // launch -- the stage tensor crosses HBM once in, once out (narrowstage.hip)
+        if (c->use_stagefuse && c->voc_resblock == 1 && dt != DT_F32 && (Cout == 16 || Cout == 8) && nk >= 1 && nk <= 3 && CH == B) {
+            bool ok = true;
+            for (int j = 0; j < nk; j++) ok = ok && c->voc_rb_d[j].size() == 3;
+            StageArgs sa;
+            memset(&sa, 0, sizeof sa);
+            if (ok) {
+                const std::string key = "voc.ns." + std::to_string(i) + (h16 ? ".h16" : "");
+                auto it = c->ns_weights.find(key);
+                if (it == c->ns_weights.end()) {
+                    zvx_ctx::NsWeights nw;
+                    int nfrag = 0;
+                    for (int j = 0; j < nk; j++) for (int q = 0; q < 6; q++) { nw.woff[6 * j + q] = nfrag; nfrag += narrowstage_steps(Cout, c->voc_rb_k[j]); }
+                    nw.W = c->buf(key + ".w", (size_t)nfrag * 1024);
+                    nw.bias = c->fbuf(key + ".b", (size_t)6 * nk * Cout);
+                    for (int j = 0; j < nk; j++)
+                        for (int t = 0; t < 3; t++)
+                            for (int q = 0; q < 2; q++) {
+                                const std::string nm = "voc.rb" + std::to_string(i * nk + j) + (q ? ".c2_" : ".c1_") + std::to_string(t);
+                                const Tensor& w = vt(nm + "_w");
+                                if (w.dims.size() != 3 || w.dim(0) != c->voc_rb_k[j] || w.dim(1) != Cout || w.dim(2) != Cout) fail(ZVX_E_MANIFEST, "weights: '%s' has an unexpected shape", nm.c_str());
+                                const int ci = 6 * j + 2 * t + q;
+                                launch_pack_narrow(w.dev, c->voc_rb_k[j], Cout, (char*)nw.W + (size_t)nw.woff[ci] * 1024, c->stream);
+                                HIPCHK(hipMemcpyAsync(nw.bias + (size_t)ci * Cout, c->pf(nm + "_b"), (size_t)Cout * 4, hipMemcpyDeviceToDevice, c->stream));
+                            }
+                    it = c->ns_weights.emplace(key, nw).first;
+                }
+                sa.X = X0; sa.x_bs = (long)rows * Cout; sa.ldx = Cout; sa.W = it->second.W; sa.bias = it->second.bias;
+                memcpy(sa.woff, it->second.woff, sizeof sa.woff);
+                sa.C = Cout; sa.nk = nk;
+                for (int j = 0; j < nk; j++) { sa.ks[j] = c->voc_rb_k[j]; for (int t = 0; t < 3; t++) sa.dil[j][t] = c->voc_rb_d[j][t]; }
+                sa.out = A; sa.o_bs = (long)rows * Cout; sa.ldo = Cout;
+                sa.slope1 = 0.1f; sa.res_inv_slope = 10.0f; sa.slope = next_slope;
+                sa.len = len; sa.M = rows; sa.nbatch = B; sa.f16 = h16;
+                ok = launch_narrowstage(sa, c->stream, true);
+            }
+            if (ok) {
+                GemmEvent ev{};
+                const int vid = Cout == 16 ? 24 : 25;
+                const bool prof = c->profile >= 2 && (c->profile_only < 0 || c->profile_only == vid);
+                if (prof) { ev.a = c->new_event(); ev.b = c->new_event(); narrowstage_profile_events(ev.a, ev.b); }
+                const bool launched = launch_narrowstage(sa, c->stream, false);
+                if (prof) narrowstage_profile_events(nullptr, nullptr);
+                if (!launched) fail(ZVX_E_INVALID, "launch_narrowstage rejected a stage its dry run accepted (C=%d)", Cout);
+                if (prof) {
+                    double ksum = 0; for (int j = 0; j < nk; j++) ksum += c->voc_rb_k[j];
+                    const double rws = (double)rows * B;
+                    ev.variant = vid; ev.flops = 2.0 * rws * Cout * Cout * 6.0 * ksum; ev.rows = (long)rws; ev.N = Cout; ev.K = Cout; ev.taps = (int)ksum; ev.fused = 100 + nk;
+                    ev.bytes = rws * Cout * 2.0 * 2.0; ev.tag = c->tag;
+                    c->pending.push_back(ev);
+                }
+                Cin = Cout; mul *= u;
+                continue;
+            }
+        }
         for (int b0 = 0; b0 < B; b0 += CH) {
             const int Bs = std::min(CH, B - b0);
             const size_t boff = (size_t)b0 * utt_bytes;
@@ -1742,6 +1801,7 @@ zvx_status zvx_set_int(zvx_ctx* c, const char* key, int64_t value) {
         else if (std::string(key) == "attn_f32") c->use_attn_f32 = (int)value;
         else if (std::string(key) == "dec_f16") c->dec_f16 = (int)value;
         else if (std::string(key) == "voc_f16") c->voc_f16 = (int)value;
+        else if (std::string(key) == "stagefuse") c->use_stagefuse = (int)value;
         else if (std::string(key) == "dec_flat") c->dec_flat = (int)value;
         else if (std::string(key) == "dec_sc_fuse") c->dec_sc_fuse = (int)value;
         else if (std::string(key) == "norm_fuse_maxb") c->norm_fuse_maxb = (int)value;

@@ -161,6 +161,27 @@ struct PairArgs {
 bool launch_pairstream(PairArgs a, hipStream_t stream, bool dry_run, hipEvent_t ev_start, hipEvent_t ev_stop);
 
 // ------------------------------------------------------------------------------------------------
+// A whole narrow HiFi-GAN stage (narrowstage.hip): the nk ResBlock1 blocks (three dilated pairs each) of a stage with C = 16 / 8
+// channels, their sum / nk and the next stage's input activation in ONE launch; every intermediate lives in LDS, the stage tensor
+// crosses HBM once in and once out (hifigan.py:116-125; HiFi-GAN V2's last two stages).
+// ------------------------------------------------------------------------------------------------
+struct StageArgs {
+    const void* X; long x_bs; int ldx;             // stage input [b][M][C] 16-bit, activated domain (lrelu(x, 0.1))
+    const void* W;                                 // weight fragments in this kernel's own order (launch_pack_narrow): conv 6 j + 2 t + {0: conv1, 1: conv2}
+    int woff[18];                                  // first 1-KiB fragment of each convolution in W
+    const float* bias;                             // [6 nk][C], same convolution order
+    int C, nk, ks[3], dil[3][3];
+    void* out; long o_bs; int ldo;                 // lrelu(mean over the ResBlocks, slope) [b][M][C] 16-bit
+    float slope1, res_inv_slope, slope;
+    const int* len; int M, nbatch;
+    int f16;                                       // the 16-bit tensors are IEEE half instead of bf16
+};
+bool launch_narrowstage(const StageArgs& a, hipStream_t stream, bool dry_run);
+int narrowstage_steps(int C, int k);               // 1-KiB fragments per convolution
+void launch_pack_narrow(const void* w16 /*[k][C][C] 16-bit*/, int k, int C, void* out, hipStream_t s);
+void narrowstage_profile_events(hipEvent_t start, hipEvent_t stop);
+
+// ------------------------------------------------------------------------------------------------
 // Fused attention of the FS2 / SCLN decoder (attention.hip): out = softmax(Q K^T * scale, keys < len) V per (utterance, head),
 // bf16 operands, no [L][L] tensor in HBM.  Q and K live in one projection buffer (K at element offset k_off of a row), V
 // arrives TRANSPOSED ([head*D + j][key], key-contiguous) from its projection GEMM.
