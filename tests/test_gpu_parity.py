@@ -1147,6 +1147,35 @@ def test_half_vocoder_saturates_instead_of_overflowing(voc):
         assert not w[1, P[1] * 256:].any()
 
 
+def test_vocoder_v2_full_size_ragged_batch_against_the_oracle():
+    """HiFi-GAN V2 (the reference's default vocoder, model.py:84) at the benchmark's utterance length on a ragged batch, every utterance
+    against its own batch-1 oracle call.  Its last two stages (C = 16 / 8) run as ONE launch per stage (narrowstage.hip: tiles of 384 /
+    512 rows with 64 halo rows, utterance ends inside / at / just past tile boundaries here); zvx_set_int("stagefuse", 0) -- the per-pair
+    kernels of rounds 1-4 -- must agree with it to rounding (the stage kernel keeps the running sum in f32 registers instead of a
+    16-bit tensor: not bit-identical by design) and lands no closer to the oracle."""
+    h, hsd = voc_sd("v2")
+    ctx = ctx_for("styletts", "v2", "bf16")
+    P = np.array([896, 513, 384 // 2, 3 * 512 // 4 + 1, 57], np.int32)
+    rng = np.random.default_rng(61)
+    mel = np.zeros((len(P), int(P.max()), 80), np.float32)
+    for b in range(len(P)):
+        mel[b, :P[b]] = rng.standard_normal((P[b], 80)).astype(np.float32)
+    wav = ctx.vocode_mel(mel, P)
+    try:
+        ctx.set_int("stagefuse", 0); pairs = ctx.vocode_mel(mel, P)
+    finally:
+        ctx.set_int("stagefuse", 1)
+    for b in range(len(P)):
+        ref = O.hifigan_generator(mel[b, :P[b]].T, hsd, h)
+        check_wav(wav[b, :P[b] * 256], ref, "bf16", f"v2 utt {b} (stage kernel)", e2e=False)
+        check_wav(pairs[b, :P[b] * 256], ref, "bf16", f"v2 utt {b} (pair kernels)", e2e=False)
+        assert not wav[b, P[b] * 256:].any()
+        es, ep = stats(wav[b, :P[b] * 256], ref), stats(pairs[b, :P[b] * 256], ref)
+        assert es[1] <= ep[1] * 1.05, f"utt {b}: stage kernel rms {es[1]:.3e} vs pair kernels {ep[1]:.3e}"
+    alone = ctx.vocode_mel(mel[1:2, :P[1]], P[1:2])
+    assert np.array_equal(alone[0], wav[1, :P[1] * 256])                 # an utterance alone == inside the batch, bit for bit
+
+
 def test_non_finite_mel_values_stay_inside_their_utterance():
     """zvx_vocode_mel with a NaN / Inf in ONE utterance of a batch (gemm.hip, pairstream.hip and resstream.hip are compiled with
     -fno-honor-nans: min / max of the leaky-relu forms do not propagate NaN the IEEE way).  Defined behaviour (include/zvx.h): no fault,
