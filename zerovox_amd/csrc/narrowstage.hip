@@ -68,6 +68,7 @@ struct NsKernel {
     static constexpr int NBT = R / 16;                                 // output blocks of a tile
     static constexpr int NBW = (NBT + NW - 1) / NW;                    // ... per wave
     static constexpr int QN = C == 16 ? 4 : 2;                         // 4-channel groups that exist
+    static constexpr bool PAIRS = C == 16;                             // two 16-row blocks per loop iteration (two accumulation chains in flight); C = 8 runs 4 waves per SIMD on 128 registers instead
 
     const StageArgs& a;
     unsigned char* const A; unsigned char* const T; unsigned char* const B;    // LDS streams: x0 / x2 | T | x1
@@ -141,15 +142,19 @@ struct NsKernel {
         constexpr std::integral_constant<int, 2> two{};
         if constexpr (KIND == 2) {                                       // the tile's own rows: blocks wave NBW + i <-> sum[i] for every ResBlock
             static_assert(NBT == NBW * NW, "the tile's blocks divide evenly over the waves");
-            ns_static_for<0, NBW / 2>([&](auto ic) { constexpr int i = 2 * decltype(ic)::value; blocks(NS_HB / 16 + wave * NBW + i, two, std::integral_constant<int, i>{}); });
-            if constexpr (NBW & 1) blocks(NS_HB / 16 + wave * NBW + NBW - 1, one, std::integral_constant<int, NBW - 1>{});
+            if constexpr (PAIRS) {
+                ns_static_for<0, NBW / 2>([&](auto ic) { constexpr int i = 2 * decltype(ic)::value; blocks(NS_HB / 16 + wave * NBW + i, two, std::integral_constant<int, i>{}); });
+                if constexpr (NBW & 1) blocks(NS_HB / 16 + wave * NBW + NBW - 1, one, std::integral_constant<int, NBW - 1>{});
+            } else {
+                ns_static_for<0, NBW>([&](auto ic) { blocks(NS_HB / 16 + wave * NBW + decltype(ic)::value, one, ic); });
+            }
         } else {
             // the rows later convolutions need, rounded to blocks, dealt to the waves in contiguous runs of equal length
             const int lo = (NS_HB - E) / 16, hi = (NS_HB + R + E + 15) / 16, per = (hi - lo + NW - 1) / NW;
             const int b0 = lo + wave * per, b1 = min(b0 + per, hi);
             int blk = b0;
-            for (; blk + 1 < b1; blk += 2) blocks(blk, two, std::integral_constant<int, 0>{});
-            if (blk < b1) blocks(blk, one, std::integral_constant<int, 0>{});
+            if constexpr (PAIRS) for (; blk + 1 < b1; blk += 2) blocks(blk, two, std::integral_constant<int, 0>{});
+            for (; blk < b1; blk++) blocks(blk, one, std::integral_constant<int, 0>{});
         }
         __syncthreads();
     }
@@ -157,7 +162,8 @@ struct NsKernel {
     // stage input rows [m0 - HB, m0 + R + HB) -> A (zeros outside the utterance); 16-byte chunks, coalesced.  Every ResBlock starts from
     // it again (A is the chain's x0 and later its x2): re-read per ResBlock from L2 instead of a fourth LDS stream
     __device__ __forceinline__ void load_x(const unsigned short* Xb) {
-        const int tid = threadIdx.x;
+        int tid = threadIdx.x;
+        asm volatile("" : "+v"(tid));                                  // the per-thread addresses below are recomputed here, not carried (as spills) through the whole tile loop
         constexpr int CPR = C / 8, TOT = (R + 2 * NS_HB) * CPR;
         for (int i0 = 0; i0 < TOT; i0 += 64 * NW * 4) {
             uint4 v[4];
@@ -298,8 +304,8 @@ bool launch_narrowstage(const StageArgs& a, hipStream_t stream, bool dry_run) {
         const int k = a.ks[j];
         if (!(k == 3 || k == 5 || k == 7 || k == 11) || a.dil[j][0] != 1 || a.dil[j][1] != 3 || a.dil[j][2] != 5) return false;   // the dilations are template constants (HiFi-GAN's ResBlock1 set)
     }
-    if (a.C == 16) return launch_ns<16, 384, 8, 1>(a, stream, dry_run);            // 3 x 544 rows x 48 B + 72 KiB of weights = 150 KiB
-    return launch_ns<8, 512, 8, 2>(a, stream, dry_run);                               // 3 x 672 x 16 B + 36 KiB = 68 KiB: two workgroups per CU
+    if (a.C == 16) return launch_ns<16, 384, 8, 1>(a, stream, dry_run);            // 3 x 544 rows x 48 B + 72 KiB of weights = 150 KiB: one workgroup of 8 waves per CU
+    return launch_ns<8, 512, 8, 2>(a, stream, dry_run);                               // 3 x 672 x 16 B + 36 KiB = 68 KiB: two workgroups of 8 waves per CU (4 waves per SIMD)
 }
 
 }  // namespace zvx
