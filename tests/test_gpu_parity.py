@@ -459,6 +459,32 @@ def test_batch_flattened_decoder_convolutions_equal_per_utterance_launches(kind)
         ctx.set_int("dec_flat", 1); ctx.set_int("dec_f16", 1); ctx.set_int("dec_sc_fuse", 1)
 
 
+@pytest.mark.parametrize("kind", ["styletts", "fastspeech2"])
+def test_decoder_padding_rows_never_reach_a_result(kind):
+    """batch-flattened decoder launches write every row of the flattened axis (padding rows and rows past an utterance's
+    length receive junk) and later launches read them; correctness rests on every consumer masking by select, never multiplying by
+    zero.  zvx_set_int("poison_pads", 1) fills every decoder work buffer with NaN bit patterns before each decode: a ragged batch must
+    come out bit-identical to the clean run (and finite), twice in a row, in the 16-bit mode and in f32."""
+    for prec in ("bf16", "f32"):
+        ctx = ctx_for(kind, "tiny", prec)
+        rng = np.random.default_rng(23)
+        L = np.array([255, 256, 257, 130, 31], np.int32)
+        feats = np.zeros((len(L), int(L.max()), 528), np.float32)
+        for b in range(len(L)):
+            feats[b, :L[b]] = rng.standard_normal((L[b], 528)).astype(np.float32)
+        spk = rng.standard_normal((len(L), 528)).astype(np.float32); spk /= np.linalg.norm(spk, axis=1, keepdims=True)
+        clean = ctx.decode_features(feats, L, spk)
+        try:
+            ctx.set_int("poison_pads", 1)
+            p1 = ctx.decode_features(feats, L, spk)
+            p2 = ctx.decode_features(feats, L, spk)
+        finally:
+            ctx.set_int("poison_pads", 0)
+        for b in range(len(L)):
+            assert np.isfinite(p1[b, :L[b]]).all(), f"{kind} {prec}: NaN reached utterance {b}"
+            assert np.array_equal(p1[b, :L[b]], clean[b, :L[b]]) and np.array_equal(p2[b, :L[b]], clean[b, :L[b]]), f"{kind} {prec}: utterance {b} depends on padding rows"
+
+
 def test_streaming_pair_kernel_on_a_ragged_batch_against_the_oracle():
     """pairstream.hip forced for every job size (`pairstream 3`) on a ragged HiFi-GAN V1 batch, DIRECTLY against the oracle's
     batch-1 generator calls (the bit-equality test below ties it to the two-launch path; this one does not lean on that chain)."""

@@ -388,7 +388,7 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(const AttnF32Args a) {
     if (q0 >= len) return;
     const float* const base = a.qkv + (long)b * a.bs + (long)h * D;
 
-    // rows [row0, row0 + NROWS) x columns [0, NCOLS) of a row-major f32 matrix -> LDS tile (rows at or beyond L: zeros).  Every
+    // rows [row0, row0 + NROWS) x columns [0, NCOLS) of a row-major f32 matrix -> LDS tile (rows at or beyond the utterance's length: zeros).  Every
     // load of the tile is in flight before the first LDS store (a load -> store loop pays one L2 round trip per iteration).
     auto tile_fetch = [&](const float* src, int row0, auto nrows_c, auto ncols_c) {
         constexpr int NROWS = decltype(nrows_c)::value, NCOLS = decltype(ncols_c)::value;
@@ -398,7 +398,7 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(const AttnF32Args a) {
         for (int it = 0; it < IT; it++) {
             const int i = tid + it * 256, r = i / C4N, c4 = i - r * C4N, row = row0 + r;
             t.v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (i < N && row < a.L) t.v[it] = *(const float4*)(src + (long)row * a.ld + c4 * 4);
+            if (i < N && row < len) t.v[it] = *(const float4*)(src + (long)row * a.ld + c4 * 4);     // rows past the utterance's OWN length are zeros: a V row there meets a probability of exactly 0, and 0 x (stale NaN) is not 0 (it read `row < a.L` until round 5)
         }
         return t;
     };

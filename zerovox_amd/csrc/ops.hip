@@ -666,6 +666,21 @@ void launch_zero_tail_rows(float* x, int ldx, int B, int rows_max, const int* ro
     hipLaunchKernelGGL(k_zero_tail_rows, dim3(rows_max, B), dim3(128), 0, s, x, ldx, rows_max, rows, C);
 }
 
+// x[b][r][c] = 0 for len[b] <= c < cols (element size es = 2 / 4 bytes): the key-contiguous V^T of the unfused attention path, whose
+// columns past an utterance's length come from rows nothing has defined (0 x NaN would not be 0 in the P.V product)
+__global__ void k_zero_tail_cols(unsigned char* x, int es, long ld, long bs, int rows, int cols, const int* len) {
+    const int b = blockIdx.z, r = blockIdx.y;
+    const int l0 = len[b];
+    for (int c = l0 + blockIdx.x * blockDim.x + threadIdx.x; c < cols; c += gridDim.x * blockDim.x) {
+        unsigned char* p = x + ((long)b * bs + (long)r * ld + c) * es;
+        if (es == 4) *(unsigned*)p = 0u; else *(unsigned short*)p = (unsigned short)0;
+    }
+}
+void launch_zero_tail_cols(void* x, int es, long ld, long bs, int B, int rows, int cols, const int* len, hipStream_t s) {
+    if (rows <= 0 || cols <= 0) return;
+    hipLaunchKernelGGL(k_zero_tail_cols, dim3(1, rows, B), dim3(256), 0, s, (unsigned char*)x, es, ld, bs, rows, cols, len);
+}
+
 // ---------------------------------------------------------------- conv_post (C -> 1) + tanh      hifigan.py:127-128
 // x is the activated last stage [b][Nmax][ldx]; one thread per output sample, weights broadcast from LDS.
 // conv_post (C -> 1, k taps) + tanh: a block of 256 samples stages its (256 + k - 1) input rows in LDS once (coalesced

@@ -124,6 +124,7 @@ struct zvx_ctx {
     int rs_seg_min = 0;                    // zvx_set_int("rs_seg_min", -1): streaming ResBlock segments never shorter than 2048 rows (A/B of the single-request sizing)
     int rs_opt = 3;                        // zvx_set_int("rs_opt", v): StreamArgs.opt of the streaming ResBlock kernels (bit 0: staggered wave priorities)
     int slab_small = 2, slab_flat = 1;     // zvx_set_int("slab_small" / "slab_flat", v): conv-slab tile choice for single requests / whole-grid XCD remap (A/B; per context)
+    int poison_pads = 0;                   // zvx_set_int("poison_pads", 1): every work buffer of the mel decoders is filled with NaN bit patterns before a decode (tests: padding rows / stale rows must never reach a result -- ADVICE r4)
     int use_stagefuse = 1;                 // zvx_set_int("stagefuse", 0): narrow vocoder stages (C = 16 / 8) as per-pair launches instead of ONE launch per stage (narrowstage.hip; A/B)
     struct NsWeights { void* W = nullptr; float* bias = nullptr; int woff[18] = {0}; };
     std::map<std::string, NsWeights> ns_weights;   // narrowstage.hip fragment order, per (stage, dtype), built on first use
@@ -686,6 +687,9 @@ void fft_block(zvx_ctx* c, void* x, int dt, int B, int Lmax, const int* len_dev,
         // as Inf / NaN in the other, and 0 * NaN = NaN in the P.V product): zero them
         if (Lp > Lmax) HIPCHK(hipMemset2DAsync((char*)vt + (size_t)Lmax * es, (size_t)Lp * es, 0, (size_t)(Lp - Lmax) * es, (size_t)B * H, c->stream));
         c->gemm(a);
+        // ... and round 5: the columns [len, Lmax) as well -- "finite junk" held only as long as every row of x past an
+        // utterance's length had been defined by something; nothing guarantees that (tests: zvx_set_int("poison_pads", 1))
+        launch_zero_tail_cols(vt, (int)es, Lp, (long)H * Lp, B, H, Lmax, len_dev, c->stream);
     }
     FlashArgs fa;
     memset(&fa, 0, sizeof fa);
@@ -1114,6 +1118,16 @@ void run_decode(zvx_ctx* c, const float* feats, const float* spk_d, const int* L
     c->stage_begin(ZVX_T_DECODER);
     c->tag = "decoder";
     float* mel = c->fbuf("mel", (size_t)B * std::max(Lmax, 1) * c->n_mels);
+    if (c->poison_pads) {
+        // every work buffer of the decoders starts as NaN patterns (0xFF bytes: NaN as f32, half and bf16): batch-flattened launches write
+        // junk into padding rows and read rows past an utterance's length by design -- every consumer must MASK them (select), never
+        // multiply them by zero.  With this switch a violation shows up as NaN in the mel (the test compares with the clean run bit for bit).
+        for (auto& kv : c->bufs) {
+            const std::string& nm = kv.first;
+            const bool mine = nm.rfind("sty.", 0) == 0 || nm.rfind("fft.", 0) == 0 || nm == "dec.x";
+            if (mine && kv.second.p && kv.second.base == kv.second.p && nm != "sty.adain_h" && nm != "dec.bg") HIPCHK(hipMemsetAsync(kv.second.p, 0xFF, kv.second.cap, c->stream));
+        }
+    }
     if (Lmax > 0) {
         if (c->dec_kind == 0) decoder_fs2(c, feats, spk_d, L_d, B, Lmax, mel);
         else decoder_styletts(c, feats, spk_d, L_d, B, Lmax, mel);
@@ -1802,6 +1816,7 @@ zvx_status zvx_set_int(zvx_ctx* c, const char* key, int64_t value) {
         else if (std::string(key) == "dec_f16") c->dec_f16 = (int)value;
         else if (std::string(key) == "voc_f16") c->voc_f16 = (int)value;
         else if (std::string(key) == "stagefuse") c->use_stagefuse = (int)value;
+        else if (std::string(key) == "poison_pads") c->poison_pads = (int)value;
         else if (std::string(key) == "dec_flat") c->dec_flat = (int)value;
         else if (std::string(key) == "dec_sc_fuse") c->dec_sc_fuse = (int)value;
         else if (std::string(key) == "norm_fuse_maxb") c->norm_fuse_maxb = (int)value;

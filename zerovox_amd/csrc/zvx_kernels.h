@@ -217,6 +217,8 @@ void launch_instnorm_fused(const void* x, int x_dt, int ldx, void* y, int y_dt, 
                            float* mean, float* rstd, const float* gamma, const float* beta, long g_bs, int one_plus, int act, float slope, hipStream_t s);
 void launch_transpose16(const void* in, int ld_in, void* out, int ld_out, int B, int rows, int C, hipStream_t s, const int* len = nullptr);   // rows >= len[b] read as zeros
 void launch_f32_to_bf16(const float* in, bf16_t* out, size_t n, hipStream_t s);
+// x[b][r][c] = 0 for len[b] <= c < cols; es = element size (2 / 4), ld / bs = row / batch strides in elements
+void launch_zero_tail_cols(void* x, int es, long ld, long bs, int B, int rows, int cols, const int* len, hipStream_t s);
 void launch_cast(const void* in, int in_dt, void* out, int out_dt, size_t n, hipStream_t s);
 
 // f32 -> three 16-bit planes [hi | hi | lo] per row (out [b][rows_max][3C]; rows >= rows[b] -> zeros) and weights
