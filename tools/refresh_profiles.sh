@@ -47,6 +47,8 @@ if [ "$QUICK" = "extra" ]; then
   python $ROOT/bench.py --decoder fastspeech2 --no-cpu-baseline > $OUT/bench_fs2dec.json 2> $OUT/bench_fs2dec.err
   profile_workload v2 --vocoder v2
   python $ROOT/bench.py --vocoder v2 --no-cpu-baseline > $OUT/bench_v2.json 2> $OUT/bench_v2.err
+  python $ROOT/bench.py --vocoder v2 --set stagefuse=0 --no-cpu-baseline > $OUT/bench_v2_pair_kernels.json 2> $OUT/bench_v2_pair_kernels.err     # A/B (round 5): V2's narrow stages on the per-pair kernels of rounds 1-4
+  python $ROOT/bench.py --vocoder v2 --set front_overlap=0 --no-cpu-baseline > $OUT/bench_v2_serial.json 2> $OUT/bench_v2_serial.err
   profile_workload v3 --vocoder v3
   python $ROOT/bench.py --vocoder v3 --no-cpu-baseline > $OUT/bench_v3.json 2> $OUT/bench_v3.err
   profile_workload b1_t64 --batch 1 --phonemes 64
