@@ -66,7 +66,8 @@ int64_t    zvx_get_int(const zvx_ctx* ctx, const char* key);
  * "shape_log" 0/1 (one stderr line per timed launch); "max_frames" hard cap on a predicted mel length (default 2^18:
  * the reference has none, fs2.py:678-681 -- a garbage log-duration must not drive an allocation -> ZVX_E_BUFFER).
  * Every other key is an A/B switch of a scheduling / tiling / arithmetic choice (INTEGRATION.md has the table: "enc_split",
- * "front_overlap", "front_prio", "dec_flat", "dec_sc_fuse", "dec_f16", "pairstream", "resstream", "slab_small", "slab_flat", ...);
+ * "front_overlap", "front_prio", "dec_flat", "dec_sc_fuse", "dec_f16", "voc_f16", "stagefuse", "pairstream", "resstream", "slab_small", "slab_flat",
+ * "poison_pads", ...);
  * all of them live in the context.  Unknown keys: ZVX_E_INVALID. */
 zvx_status zvx_set_int(zvx_ctx* ctx, const char* key, int64_t value);
 
@@ -110,7 +111,13 @@ zvx_status zvx_decode_features(zvx_ctx* ctx, const float* features, const int32_
  * Replaces hifigan.Generator.forward (hifigan.py:114-130). */
 zvx_status zvx_vocode(zvx_ctx* ctx, const int32_t* pad_to, void* wav, int64_t wav_stride, int flags);
 
-/* Stand-alone vocoder: mel [B][Pmax][n_mels], P[B] frames -> wav rows of P[b]*hop samples. */
+/* Stand-alone vocoder: mel [B][Pmax][n_mels], P[B] frames -> wav rows of P[b]*hop samples.
+ * Arithmetic of the 16-bit mode (round 5): weights, activations and the running sum of the generator are IEEE half on the f16 MFMA;
+ * every 16-bit store SATURATES at +-65504 (MODE.FP16_OVFL in the kernels) -- a mel scaled far past the trained range gives a finite,
+ * clipped waveform, never Inf / NaN (zvx_set_int "voc_f16" 0: the bf16 kernels of rounds 1-4).
+ * Non-finite input (NaN / Inf in a mel): the call succeeds and nothing faults; the samples of THAT utterance are unspecified (finite or
+ * not -- the leaky-relu forms are compiled without NaN propagation guarantees); every other utterance of the batch and every later call
+ * are bit for bit what they are without it.  The reference would propagate the NaN through that utterance as well. */
 zvx_status zvx_vocode_mel(zvx_ctx* ctx, const float* mel, const int32_t* P, int B, int Pmax,
                           void* wav, int64_t wav_stride, int flags);
 
