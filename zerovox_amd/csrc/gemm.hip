@@ -1591,6 +1591,7 @@ static int epi_mode_of(const GemmArgs& a) {
 // a.slab_small (zvx_set_int "slab_small", default 2): single-request tile choice: 0 none, 1 small row tiles, 2 + 32-channel tiles for one-row-tile launches
 // Both are the CONTEXT's switches (zvx_ctx::gemm fills them): no process-wide state.
 static int launch_convslab(GemmArgs a, hipStream_t stream) {
+    const bool bflat_hint = a.bflat != 0;                              // the mel decoders' launches (their buffers carry padding rows)
     if (a.K2) {
         if (!a.X2 || a.K2 % 16 || a.ldx2 % 8 || a.flat_win || (a.bflat && a.x2_bs != (long)a.bflat * a.ldx2)) return -5;
     }
@@ -1708,6 +1709,28 @@ static int launch_convslab(GemmArgs a, hipStream_t stream) {
         // (slab_small bit 4: A/B switch, flatten whenever possible)
         if ((a.slab_small & 16) || (wg_flat + slots - 1) / slots < (wg_utt + slots - 1) / slots) { a.flat_win = a.bflat; a.flat_rows = a.nbatch * a.bflat; a.M = a.flat_rows; a.nbatch = 1; }
         else a.bflat = 0;
+    }
+    // 256 x 128 tiles whose count quantises badly over the chip's 2 x CUs workgroup slots (N = 528 over 32 x 896 frames: 565 flattened
+    // tiles = one full round and a tenth of a second one; per utterance 640 tiles, every utterance ending in a half-empty tile): 128-row
+    // tiles of the same kernel (same K order per output row: bit-identical) where they take less time by the slot count -- a round of
+    // 128-row tiles counts half a round of 256-row ones.  (slab_small bit 3: A/B switch, off)
+    if (best == 1 && bflat_hint && !(a.slab_small & 8) && a.M > 256 && hl + hr <= 64) {   // (the mel decoders' launches: the vocoder's 256 x 128 launches are power-, not slot-limited)
+        const long slots = 2L * ncu;
+        const long t256 = (long)ntn * ((a.M + 255) / 256) * a.nbatch, t128 = (long)ntn * ((a.M + 127) / 128) * a.nbatch;
+        const long eff256 = 2 * ((t256 + slots - 1) / slots), eff128 = (t128 + slots - 1) / slots;
+        if (eff128 < eff256) {
+            dim3 g128(ntn * ((a.M + 127) / 128), a.nbatch);
+            size_t lds128 = ((size_t)(128 + hl + hr) * SLAB_PITCH + 1023) & ~(size_t)1023;
+            const size_t stage128 = (size_t)4 * 32 * (2 * 128 + 16);
+            if (lds128 < stage128) lds128 = stage128;
+            switch (epi_mode_of(a)) {
+                case ZVX_EPI(0, 0, 1): launch_slab_variant<128, 128, 2, 2, 2, 0, ZVX_EPI(0, 0, 1)>(a, g128, lds128, stream); break;
+                case ZVX_EPI_DEC(0): launch_slab_variant<128, 128, 2, 2, 2, 0, ZVX_EPI_DEC(0)>(a, g128, lds128, stream); break;
+                case ZVX_EPI_DEC(1): launch_slab_variant<128, 128, 2, 2, 2, 0, ZVX_EPI_DEC(1)>(a, g128, lds128, stream); break;
+                default: launch_slab_variant<128, 128, 2, 2, 2, 0>(a, g128, lds128, stream);
+            }
+            return 22;
+        }
     }
     const int ntm = (a.M + bm - 1) / bm;
     dim3 grid(ntn * ntm, a.nbatch);
