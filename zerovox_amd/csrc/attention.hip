@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
     constexpr int KBYTES = FA_BK * KP, VBYTES = DO * VP;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];   // [2][K tile | V^T tile]
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l32 = lane & 31, hi = lane >> 5;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l32 = lane & 31, hi = lane >> 5;   // wave: an SGPR (the DMA requests' LDS addresses are scalar arithmetic)
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)lds;   // LDS byte address of the window
     // workgroups reach the 8 XCDs round-robin in launch order: remap so that each XCD walks a CONTIGUOUS range of (utterance, head,
     // query tile) -- the <= 7 query tiles of one (utterance, head) then share that XCD's L2 for the 0.95 MB of K / V^T they all stream
@@ -209,19 +209,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
         // the next tile's K rows and V^T rows go into the other buffer (last read before the previous tile's closing barrier); their NDMA
         // requests per wave are issued BETWEEN the matrix steps of the score product and of the first half of the second product (one per
         // ~2.7 steps: the CU's vector-memory path takes a 1-KiB request per ~16 cycles, four waves feed it; closer spacing stalls the issue)
-        const bool more = !(FA_EXP & 2) && t + 1 < ntiles;
-        const i32x4 rk = k_rsrc(more ? k0 + FA_BK : k0), rv = v_rsrc(more ? k0 + FA_BK : k0);
+        // (the requests are unconditional -- no branch per request: behind an utterance's last tile the K descriptor's range is empty, so
+        // its pieces arrive as zeros, and the V^T pieces are in-range junk; both land in the buffer nobody reads any more)
+        const i32x4 rk = k_rsrc(k0 + FA_BK), rv = v_rsrc(k0 + FA_BK);
         const int nbuf = (t + 1) & 1;
         // step g of the tile's 34 + 36 matrix steps carries request j when the ramp j = g NDMA / NSPREAD steps up there; the last NDMA-free
         // steps of the second product (and the closing barrier) cover the latency of the last requests
         constexpr int NS1 = FA_NKB * KS, NSPREAD = NS1 + NDB * 2 * FA_NKB / 2;
         auto hook1 = [&](auto ic) __attribute__((always_inline)) {
             constexpr int g = decltype(ic)::value, j = g * NDMA / NSPREAD;
-            if constexpr (g < NSPREAD && ((g + 1) * NDMA) / NSPREAD > j) { if (more) dma_req(std::integral_constant<int, j>{}, rk, rv, nbuf); }
+            if constexpr (!(FA_EXP & 2) && g < NSPREAD && ((g + 1) * NDMA) / NSPREAD > j) dma_req(std::integral_constant<int, j>{}, rk, rv, nbuf);
         };
         auto hook2 = [&](auto ic) __attribute__((always_inline)) {
             constexpr int g = NS1 + decltype(ic)::value, j = g * NDMA / NSPREAD;
-            if constexpr (g < NSPREAD && ((g + 1) * NDMA) / NSPREAD > j) { if (more) dma_req(std::integral_constant<int, j>{}, rk, rv, nbuf); }
+            if constexpr (!(FA_EXP & 2) && g < NSPREAD && ((g + 1) * NDMA) / NSPREAD > j) dma_req(std::integral_constant<int, j>{}, rk, rv, nbuf);
         };
         const unsigned char* const kb = lds + (t & 1) * (KBYTES + VBYTES);
         const unsigned char* const vb = kb + KBYTES;
