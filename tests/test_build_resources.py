@@ -43,3 +43,17 @@ def test_pair_kernel_keeps_two_waves_per_simd_without_spills(resources):
     assert len(ps) == 24                                                              # k = 3 / 7 / 11 x four epilogue modes x {bf16, IEEE half}
     for k, v in ps.items():
         assert v.get("vgpr_spill", 0) == 0 and v.get("scratch", 0) == 0 and v["occupancy"] >= 2, (k, v)   # 8 waves per workgroup: conv1 + conv2 on every SIMD
+
+
+def test_narrow_stage_and_attention_kernels_do_not_spill(resources):
+    """narrowstage.hip runs 4 waves per SIMD at C = 8 (a 128-register budget: hoisted load addresses once cost it 14-19 spilled
+    registers) and 2-3 at C = 16; the fused attention kernels own a whole SIMD's register file."""
+    ns = {k: v for k, v in resources.items() if "narrowstage_kernel" in k}
+    assert len(ns) == 4                                                               # C = 16 / 8 x {bf16, IEEE half}
+    for k, v in ns.items():
+        assert v.get("vgpr_spill", 0) == 0 and v.get("scratch", 0) == 0, (k, v)
+        assert v["occupancy"] >= (4 if "ILi8E" in k else 2), (k, v)
+    fa = {k: v for k, v in resources.items() if "flash_attn_kernel" in k}
+    assert len(fa) == 2
+    for k, v in fa.items():
+        assert v.get("vgpr_spill", 0) == 0 and v.get("scratch", 0) == 0, (k, v)

@@ -776,64 +776,76 @@ void launch_conv_post_tanh(const void* x, int x_dt, int ldx, long x_bs, const fl
 
 // ---------------------------------------------------------------- speaker encoder pieces
 // first layer: InstanceNorm1d(F) over time folded in (mean/rstd given) + Conv2d(1->C0,3x3,p1) + ReLU + BN affine
-// one thread = 8 output channels x SF_T consecutive time positions of one frequency row: its 72 weights + 24 bias / BN values are loaded
-// once and the normalised 3 x (SF_T + 2) input window slides along time (round 5: one position per thread re-loaded all of them per
-// position -- 123 loads for 8 outputs -- and the launch ran at 0.85 TB/s of its 333 MB of output; same arithmetic order per output)
-#define SF_T 4
+// One workgroup = one clip x SF_TB consecutive time positions x ALL frequency rows.  The normalised input patch [F + 2][SF_TB + 2] is
+// staged in LDS with COALESCED reads of the [time][F] log-mel (a row of F floats per time step); round 4's kernel gathered it with one
+// thread per (f, t): consecutive lanes read 320 bytes apart, 4 useful bytes per 128-byte line, every frequency row's workgroups pulling
+// the whole mel through L2 again -- ~3 GB of L2 traffic for a 21 MB input, and the launch wrote its 333 MB of output at 0.85 TB/s.
+// A thread owns 8 output channels (72 weights + 24 bias / BN values in registers) of one time position and walks the frequency rows;
+// a wave's store covers 16 consecutive positions x 64 bytes.  Same arithmetic order per output as before (bit-identical).
+#define SF_TB 64
 __global__ __launch_bounds__(256) void k_spk_front(const float* mels, int Tmax, const int* lens, int F, const float* mean, const float* rstd,
                             const float* w, const float* bias, const float* bs, const float* bt, int C0, void* out, int odt, int Wout) {
-    const int b = blockIdx.z, f = blockIdx.y, cpp = C0 >> 3;
-    const int id = blockIdx.x * blockDim.x + threadIdx.x, t0 = (id / cpp) * SF_T, c0 = (id % cpp) * 8;
+    extern __shared__ float patch[];                             // [F + 2][SF_TB + 2]: frequency rows -1 .. F, times t0 - 1 .. t0 + SF_TB
+    constexpr int PW = SF_TB + 2;
+    const int b = blockIdx.y, t0 = blockIdx.x * SF_TB, cpp = C0 >> 3;
     const int Tb = lens[b];
     if (t0 >= Tb) return;
-    float wk[9][8], bb[8], sc[8], sh[8];
-#pragma unroll
-    for (int e = 0; e < 8; e++) { bb[e] = bias[c0 + e]; sc[e] = bs[c0 + e]; sh[e] = bt[c0 + e]; }
-#pragma unroll
-    for (int k = 0; k < 9; k++)
-#pragma unroll
-        for (int e = 0; e < 8; e++) wk[k][e] = w[k * C0 + c0 + e];
-    float xw[3][SF_T + 2];                                       // normalised inputs: frequency rows f - 1 .. f + 1, times t0 - 1 .. t0 + SF_T
-#pragma unroll
-    for (int i = 0; i < 3; i++) {
-        const int ff = f + i - 1;
-        const bool fok = ff >= 0 && ff < F;
-        const float mu = fok ? mean[b * F + ff] : 0.f, rs = fok ? rstd[b * F + ff] : 0.f;
-#pragma unroll
-        for (int j = 0; j < SF_T + 2; j++) {
-            const int tt = t0 + j - 1;
-            xw[i][j] = (fok && tt >= 0 && tt < Tb) ? (mels[((long)b * Tmax + tt) * F + ff] - mu) * rs : 0.f;
-        }
+    for (int i = threadIdx.x; i < (F + 2) * PW; i += blockDim.x) patch[i] = 0.f;
+    __syncthreads();
+    // coalesced: consecutive threads read consecutive frequencies of one time step
+    for (int i = threadIdx.x; i < PW * F; i += blockDim.x) {
+        const int j = i / F, ff = i - j * F, tt = t0 + j - 1;
+        if (tt >= 0 && tt < Tb) patch[(ff + 1) * PW + j] = (mels[((long)b * Tmax + tt) * F + ff] - mean[b * F + ff]) * rstd[b * F + ff];
     }
+    __syncthreads();
+    for (int id = threadIdx.x; id < SF_TB * cpp; id += blockDim.x) {
+        const int tl = id / cpp, c0 = (id - tl * cpp) * 8, t = t0 + tl;
+        if (t >= Tb) continue;
+        float wk[9][8], bb[8], sc[8], sh[8];
 #pragma unroll
-    for (int u = 0; u < SF_T; u++) {
-        const int t = t0 + u;
-        if (t >= Tb) break;
-        float r[8];
+        for (int e = 0; e < 8; e++) { bb[e] = bias[c0 + e]; sc[e] = bs[c0 + e]; sh[e] = bt[c0 + e]; }
 #pragma unroll
-        for (int e = 0; e < 8; e++) {
-            float a = bb[e];
+        for (int k = 0; k < 9; k++)
 #pragma unroll
-            for (int k = 0; k < 9; k++) a += xw[k / 3][u + k % 3] * wk[k][e];
-            r[e] = fmaxf(a, 0.f) * sc[e] + sh[e];               // conv -> ReLU -> BN  (ResNetSE34V2.py:184-186)
-        }
-        const long o = (((long)b * F + f) * Wout + t) * C0 + c0;      // output map rows are Wout >= Tmax positions wide
-        if (odt == DT_BF16) {
-            uint4 pk;
-            pk.x = tobf(r[0]) | ((unsigned)tobf(r[1]) << 16); pk.y = tobf(r[2]) | ((unsigned)tobf(r[3]) << 16);
-            pk.z = tobf(r[4]) | ((unsigned)tobf(r[5]) << 16); pk.w = tobf(r[6]) | ((unsigned)tobf(r[7]) << 16);
-            *(uint4*)((unsigned short*)out + o) = pk;
-        } else {
-            *(float4*)((float*)out + o) = make_float4(r[0], r[1], r[2], r[3]);
-            *(float4*)((float*)out + o + 4) = make_float4(r[4], r[5], r[6], r[7]);
+            for (int e = 0; e < 8; e++) wk[k][e] = w[k * C0 + c0 + e];
+        float x0[3], x1[3], x2[3];                               // rows f - 1, f, f + 1 of the patch at times t - 1 .. t + 1
+#pragma unroll
+        for (int j = 0; j < 3; j++) { x0[j] = patch[0 * PW + tl + j]; x1[j] = patch[1 * PW + tl + j]; }
+        for (int f = 0; f < F; f++) {
+#pragma unroll
+            for (int j = 0; j < 3; j++) x2[j] = patch[(f + 2) * PW + tl + j];
+            float r[8];
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                float a = bb[e];
+#pragma unroll
+                for (int j = 0; j < 3; j++) a += x0[j] * wk[j][e];
+#pragma unroll
+                for (int j = 0; j < 3; j++) a += x1[j] * wk[3 + j][e];
+#pragma unroll
+                for (int j = 0; j < 3; j++) a += x2[j] * wk[6 + j][e];
+                r[e] = fmaxf(a, 0.f) * sc[e] + sh[e];           // conv -> ReLU -> BN  (ResNetSE34V2.py:184-186)
+            }
+            const long o = (((long)b * F + f) * Wout + t) * C0 + c0;      // output map rows are Wout >= Tmax positions wide
+            if (odt == DT_BF16) {
+                uint4 pk;
+                pk.x = tobf(r[0]) | ((unsigned)tobf(r[1]) << 16); pk.y = tobf(r[2]) | ((unsigned)tobf(r[3]) << 16);
+                pk.z = tobf(r[4]) | ((unsigned)tobf(r[5]) << 16); pk.w = tobf(r[6]) | ((unsigned)tobf(r[7]) << 16);
+                *(uint4*)((unsigned short*)out + o) = pk;
+            } else {
+                *(float4*)((float*)out + o) = make_float4(r[0], r[1], r[2], r[3]);
+                *(float4*)((float*)out + o + 4) = make_float4(r[4], r[5], r[6], r[7]);
+            }
+#pragma unroll
+            for (int j = 0; j < 3; j++) { x0[j] = x1[j]; x1[j] = x2[j]; }
         }
     }
 }
 void launch_spk_front(const float* mels, int Tmax, const int* lens, int F, const float* mean, const float* rstd,
                       const float* w, const float* bias, const float* bn_scale, const float* bn_shift, int C0,
                       void* out, int o_dt, int B, int Wout, hipStream_t s) {
-    const int threads = ((Tmax + SF_T - 1) / SF_T) * (C0 >> 3);  // C0 % 8 == 0
-    hipLaunchKernelGGL(k_spk_front, dim3((threads + 255) / 256, F, B), dim3(256), 0, s, mels, Tmax, lens, F, mean, rstd, w, bias,
+    const size_t lds = (size_t)(F + 2) * (SF_TB + 2) * sizeof(float);                 // C0 % 8 == 0
+    hipLaunchKernelGGL(k_spk_front, dim3((Tmax + SF_TB - 1) / SF_TB, B), dim3(256), lds, s, mels, Tmax, lens, F, mean, rstd, w, bias,
                        bn_scale, bn_shift, C0, out, o_dt, Wout);
 }
 
