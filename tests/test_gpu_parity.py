@@ -611,6 +611,39 @@ def test_speaker_encoder_short_and_odd_lengths():
         check_f32(e[b], O.resnet_se34v2(mels[b, :lens[b]], sd, cfg), f"embed[{b}]", 5e-5)
 
 
+def test_speaker_encoder_persistent_convolutions_and_fused_se_pool():
+    """Round 5: the C = 32 / 64 levels' 3 x 3 convolutions run as persistent workgroups (conv2d_persist_kernel) whose second
+    convolution of a block leaves the squeeze-excite pool's partial sums itself.  A ragged batch with widths either side of the tile
+    and staging-step boundaries: every clip against the oracle, and the three launch sets (default / pool as its own pass / the
+    per-tile kernels of rounds 1-4) against each other -- they differ by the order of f32 additions in the pool and nothing else."""
+    ctx = ctx_for("styletts", "tiny", "bf16")
+    cfg, sd = tts_sd("styletts")
+    r = np.random.default_rng(23)
+    lens = np.array([258, 200, 97, 64, 131], np.int32)
+    mels = r.standard_normal((5, 258, 80)).astype(np.float32)
+    try:
+        e_new = ctx.spkemb(mels, lens)
+        ctx.set_int("spk_pool_fuse", 0)
+        e_pass = ctx.spkemb(mels, lens)
+        ctx.set_int("slab_small", 2 | 32)
+        e_old = ctx.spkemb(mels, lens)
+    finally:
+        ctx.set_int("spk_pool_fuse", 1)
+        ctx.set_int("slab_small", 2)
+    for b in range(5):
+        ref = O.resnet_se34v2(mels[b, :lens[b]], sd, cfg)
+        check_embed16(e_new[b], ref, f"persistent convolutions + fused pool, clip {b} ({lens[b]} frames)")
+        check_embed16(e_pass[b], ref, f"persistent convolutions + pool pass, clip {b}")
+    # The persistent kernels run the per-tile kernels' matrix steps and arithmetic: bit-identical (measured: 0).  The fused pool sums
+    # the f32 results BEFORE their bf16 rounding (the pass sums the rounded tensor): the gates move by bf16-rounding noise, the
+    # embedding by <= 6.3e-4 (measured), the same size as the bf16 path's distance to the f32 oracle (<= 6.7e-4 on these clips).
+    d1, d2 = float(np.abs(e_new - e_pass).max()), float(np.abs(e_pass - e_old).max())
+    _errlog("embed-variants", "fused pool vs pool pass / persistent vs per-tile kernels", d1, d2)
+    assert d1 <= 1.5e-3 and d2 <= 1e-6, f"launch sets disagree: fused pool vs pass {d1:.3e}, persistent vs per-tile {d2:.3e}"
+    # the same call twice: bit-identical (the pool's partial sums are folded in a fixed order, no atomics)
+    assert np.array_equal(e_new, ctx.spkemb(mels, lens))
+
+
 def test_stage_times_and_kernel_stats_are_reported():
     ctx = ctx_for("styletts", "tiny", "bf16")
     ph, pu, T, spk, dur = synthetic.batch(2, 16, 0, "uniform")

@@ -12,6 +12,7 @@ NAMES = {  # rocprof kernel name pattern -> bench variant name
     r"resfuse_persist_kernel<64,": "resfuse_bf16_c64", r"resfuse_persist_kernel<32,": "resfuse_bf16_c32",
     r"resfuse_persist_kernel<128,": "resfuse_bf16_c128", r"gemm_kernel<0, 64, 64": "gemm_f32_64x64", r"gemm_kernel<1, 64, 64": "gemm_bf16_64x64",
     r"convreg_kernel<64,": "convreg_bf16_c64", r"convreg_kernel<32,": "convreg_bf16_c32",
+    r"conv2d_persist_kernel<64,": "conv2d_persist_c64", r"conv2d_persist_kernel<32,": "conv2d_persist_c32",
     r"gemm_kernel<1, 128, 128": "gemm_bf16_128x128", r"gemm_kernel<0, 128, 128": "gemm_f32_128x128",
     r"resstream_kernel<32,": "resstream_bf16_c32", r"resstream_kernel<64,": "resstream_bf16_c64",
     r"pairstream128_kernel<": "pairstream_bf16_c128", r"gemm_kernel<1, 256, 64": "gemm_bf16_256x64", r"gemm_kernel<1, 256, 32": "gemm_bf16_256x32",

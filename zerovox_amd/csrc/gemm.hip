@@ -951,6 +951,202 @@ __global__ __launch_bounds__(256, MINW) void convreg_kernel(const GemmArgs a) {
     epilogue_rows<TM, 1>(a, acc, b, m0 + wr * (BM / WM), wc * 32, out_len, lane, slab + wave * (32 * (32 * 4 + 16)));
 }
 
+// ================================================================================================
+// conv2d-persist kernel (round 5): the 3 x 3 convolutions over flattened [H][W] maps with C = 32 / 64 channels (the speaker encoder's
+// first two levels, ResNetSE34V2.py:74-76) as PERSISTENT workgroups.  convreg_kernel above spends a tile on serial latencies -- 72 KB of
+// weight fragments per workgroup from L2, then the slab rows in two rounds of loads, then 0.8 us of matrix steps, then an epilogue
+// through the LDS transpose -- with two workgroups per CU to hide them behind: 1.7 TB/s and 330 TFLOP/s at C = 32.  Here
+//  * a workgroup keeps its weight fragments for ALL its tiles;
+//  * the rows of its next tile are requested (branch-free raw buffer loads, out-of-range offset = masked) right after the current
+//    tile's rows are committed to LDS: they are in flight under the matrix steps and the epilogue;
+//  * results leave in the MFMA layout: a lane holds 4 x 4 consecutive channels of ONE row -> 4 stores of 8 bytes (lanes l and l + 32
+//    write adjacent halves of a 16-byte piece; the 4 stores of a row block fill whole rows in L2).  The LDS transpose of
+//    epilogue_rows measured 12 k of 25 k cycles per 768-row tile (cut-outs, tools/experiments/README.md);
+//  * tiles are dealt round by round, in contiguous runs per XCD (a tile's halo rows are its neighbours' centre rows: same L2);
+//  * MODE 0 (conv2, the block's second convolution) also leaves the squeeze-excite pool's partial sums (GemmArgs::se_part): one
+//    [32-channel] partial per (tile, wave) in a fixed slot, folded by k_se_fc in a fixed order -- no pass over the output for the pool.
+// C = 32: 4 waves, two workgroups per CU (246-250 registers).  C = 64 (144 registers of weights per wave): 8 waves of 64 rows, one
+// workgroup per CU, so that the requests of a tile spread over twice the lanes; the epilogue constants live in LDS there.
+// ================================================================================================
+template <int C, int BM, int WM, int WN, int MAXH, int MODE, int WGPC>
+__global__ __launch_bounds__(WM * WN * 64, WM * WN * WGPC / 4) void conv2d_persist_kernel(const GemmArgs a, const int ntm, const int ntiles) {
+    constexpr int NTHR = WM * WN * 64;
+    constexpr int NT = 9, TM = BM / WM / 32, KS = C / 16, PITCH_ = C * 2 + 16, CPR = C / 8, RSTEP = NTHR / CPR;
+    constexpr int NIT = ((BM + MAXH) * CPR + NTHR - 1) / NTHR;
+    constexpr bool EC_LDS = NTHR > 256;
+    static_assert(WN * 32 == C && BM % (WM * 32) == 0, "wave layout");
+    extern __shared__ __attribute__((aligned(16))) unsigned char slab[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave % WM, wc = wave / WM;
+    const int G = gridDim.x, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;      // G is a multiple of 8
+    auto tile_of = [&](int r) {                                                 // this workgroup's tile of round r (or ntiles: none)
+        const int base = r * G, n = ntiles - base < G ? ntiles - base : G;
+        if (n <= 0) return ntiles;
+        const int per = (n + 7) >> 3, t = xcd * per + slot;
+        return (slot < per && t < n) ? base + t : ntiles;
+    };
+    const int HL = a.halo_l, SR = BM + a.halo_l + a.halo_r, win = a.flat_win, in_rows = a.flat_rows;
+
+    uint4 w[NT][KS];
+    {
+        const uint4* Wq = (const uint4*)a.Wp + ((long)wc * NT * 4) * 64 + lane;
+#pragma unroll
+        for (int t = 0; t < NT; t++)
+#pragma unroll
+            for (int kk = 0; kk < KS; kk++) w[t][kk] = Wq[(t * 4 + kk) * 64];
+    }
+    // epilogue constants of this lane's 16 channels (MFMA layout: 4 groups of 4 consecutive channels, 8 g + 4 (lane >> 5) + e):
+    // MODE 0: + bias (conv2 with its folded BatchNorm); MODE 1: ReLU, then x scale + shift (conv1 -> ReLU -> BatchNorm)
+    float* const ecl = (float*)(slab + ((SR * PITCH_ + 15) & ~15));            // EC_LDS: [C] bias / scale, [C] shift behind the slab
+    float4 ec0[EC_LDS ? 1 : 4], ec1[(MODE == 1 && !EC_LDS) ? 4 : 1];
+    if (EC_LDS) {
+        if (tid < C) { ecl[tid] = MODE == 0 ? a.bias[tid] : a.post_scale[tid]; if (MODE == 1) ecl[C + tid] = a.post_shift[tid]; }
+    } else {
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            const int ch = wc * 32 + 8 * g + 4 * (lane >> 5);
+            if (MODE == 0) ec0[g] = *(const float4*)(a.bias + ch);
+            else { ec0[g] = *(const float4*)(a.post_scale + ch); ec1[g] = *(const float4*)(a.post_shift + ch); }
+        }
+    }
+    u32x4 sv[NIT];
+    const int row_t = tid / CPR, q8 = (tid % CPR) * 8;
+    auto request = [&](int t) __attribute__((always_inline)) {
+        const int b = t / ntm, m0 = (t - b * ntm) * BM;
+        const int in_len = a.in_len[b];
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)((const unsigned short*)a.X + (long)b * a.x_bs), 0, in_rows * a.ldx * 2, 0x00020000);
+        int g = m0 - HL + row_t;
+        int col = (g + 2 * win) % win;                    // (HL = win + 1: g >= -2 win; the launcher guarantees win >= RSTEP)
+#pragma unroll
+        for (int it = 0; it < NIT; it++) {
+            const bool ok = tid + it * NTHR < SR * CPR && g >= 0 && g < in_rows && col < in_len;
+            sv[it] = __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? (g * a.ldx + q8) * 2 : (int)0x80000000, 0, 0);
+            g += RSTEP; col += RSTEP; if (col >= win) col -= win;
+        }
+    };
+    int r = 0, t = tile_of(0);
+    if (t < ntiles) request(t);
+    const int xrow0 = HL + wr * (BM / WM) + (lane & 31);
+    const int koff = (lane >> 5) * 16;
+    const bool pool = MODE == 0 && a.se_part != nullptr;
+    while (t < ntiles) {
+        const int b = t / ntm, mt = t - b * ntm, m0 = mt * BM;
+        // (barriers as bare s_barrier behind an LDS-only wait: __syncthreads() would also wait for the requests in flight)
+        if (r) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // every wave is done with the previous tile's rows
+#pragma unroll
+        for (int it = 0; it < NIT; it++) {
+            const int c = tid + it * NTHR;
+            if (c < SR * CPR) *(u32x4*)(slab + (c / CPR) * PITCH_ + (c % CPR) * 16) = sv[it];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        const int tn = tile_of(++r);
+#ifdef C2D_CUT
+        if (tn < ntiles && !(a.slab_small & 64)) request(tn);
+#else
+        if (tn < ntiles) request(tn);
+#endif
+
+        f32x16 acc[1][TM];
+#pragma unroll
+        for (int j = 0; j < TM; j++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[0][j][e] = 0.f;
+#ifdef C2D_CUT
+        if (!(a.slab_small & 128))
+#endif
+#pragma unroll
+        for (int tp = 0; tp < NT; tp++) {
+            const unsigned char* rowp = slab + (xrow0 + a.dv[tp]) * PITCH_ + koff;
+#pragma unroll
+            for (int kk = 0; kk < KS; kk++)
+#pragma unroll
+                for (int j = 0; j < TM; j++) {
+                    const uint4 xf = *(const uint4*)(rowp + j * 32 * PITCH_ + kk * 32);
+                    acc[0][j] = mfma16<false>(w[tp][kk], xf, acc[0][j]);
+                }
+        }
+#ifdef C2D_CUT
+        if (!(a.slab_small & 256))
+#endif
+        {
+            unsigned short* const ob = (unsigned short*)a.out + (long)b * a.o_bs + wc * 32 + 4 * (lane >> 5);
+            const int row0 = m0 + wr * (BM / WM) + (lane & 31);
+            // squeeze-excite pool (MODE 0): this lane's sums over its valid rows (positions of the utterance's true width) of the
+            // f32 results BEFORE the bias (k_se_fc adds it to the mean: every valid position carries it once)
+            // (a block's sums are taken AFTER its stores: the running sums take over the registers of the first block's accumulators)
+            float ps[16];
+            int col = 0, wlen = 0;
+            if (pool) { col = row0 % win; wlen = a.in_len[b]; }
+#pragma unroll
+            for (int j = 0; j < TM; j++) {
+                const int row = row0 + j * 32;
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    float v0 = acc[0][j][4 * g], v1 = acc[0][j][4 * g + 1], v2 = acc[0][j][4 * g + 2], v3 = acc[0][j][4 * g + 3];
+                    float4 e0, e1 = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (EC_LDS) {
+                        const int ch = wc * 32 + 8 * g + 4 * (lane >> 5);
+                        e0 = *(const float4*)(ecl + ch); if (MODE == 1) e1 = *(const float4*)(ecl + C + ch);
+                    } else { e0 = ec0[EC_LDS ? 0 : g]; if (MODE == 1) e1 = ec1[(MODE == 1 && !EC_LDS) ? g : 0]; }
+                    if (MODE == 0) { v0 += e0.x; v1 += e0.y; v2 += e0.z; v3 += e0.w; }
+                    else {
+                        v0 = fmaxf(v0, 0.f) * e0.x + e1.x; v1 = fmaxf(v1, 0.f) * e0.y + e1.y;
+                        v2 = fmaxf(v2, 0.f) * e0.z + e1.z; v3 = fmaxf(v3, 0.f) * e0.w + e1.w;
+                    }
+                    if (row < a.M) *(uint2*)(ob + (long)row * a.ldo + 8 * g) = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
+                }
+                if (pool) {
+                    const bool pv = row < a.M && col < wlen;
+#pragma unroll
+                    for (int e = 0; e < 16; e++) ps[e] = (j ? ps[e] : 0.f) + (pv ? acc[0][j][e] : 0.f);
+                    col += 32; if (col >= win) col -= win;
+                }
+            }
+            if (pool) {
+                // fold the 32 rows of each half-wave (lanes 0-31 and 32-63 hold different channels) with DPP adds: xor 1, xor 2 (quad
+                // permutes), half-row mirror, row mirror -> every lane of a 16-lane row holds the row's sum; row_bcast:15 adds row 0's
+                // to row 1 and row 2's to row 3.  Lanes 16 and 48 write 16 sums each.
+#pragma unroll
+                for (int e = 0; e < 16; e++) {
+                    float v = ps[e];
+                    v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xf, 0xf, true));
+                    v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xf, 0xf, true));
+                    v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x141, 0xf, 0xf, true));
+                    v += __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x140, 0xf, 0xf, true));
+                    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x142, 0xa, 0xf, false));
+                    ps[e] = v;
+                }
+                if ((lane & 31) == 16) {
+                    float* pp = a.se_part + ((long)b * (ntm * WM) + mt * WM + wr) * C + wc * 32 + 4 * (lane >> 5);
+#pragma unroll
+                    for (int g = 0; g < 4; g++) *(float4*)(pp + 8 * g) = make_float4(ps[4 * g], ps[4 * g + 1], ps[4 * g + 2], ps[4 * g + 3]);
+                }
+            }
+        }
+        t = tn;
+    }
+}
+
+template <int C, int BM, int WM, int WN, int MAXH, int WGPC>
+static void launch_conv2d_persist(const GemmArgs& a, hipStream_t stream) {
+    const size_t lds = (((size_t)(BM + a.halo_l + a.halo_r) * (C * 2 + 16) + 15) & ~(size_t)15) + 2 * C * sizeof(float);
+    const int ntm = (a.M + BM - 1) / BM, ntiles = ntm * a.nbatch;
+    int G = (WGPC * persistent_cus()) & ~7;
+    if (ntiles < G) G = (ntiles + 7) & ~7;
+    static std::atomic<bool> attr_done{false};
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)conv2d_persist_kernel<C, BM, WM, WN, MAXH, 0, WGPC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)conv2d_persist_kernel<C, BM, WM, WN, MAXH, 1, WGPC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_done = true;
+    }
+    if (a.post_scale) ZVX_LAUNCH((conv2d_persist_kernel<C, BM, WM, WN, MAXH, 1, WGPC>), dim3(G), dim3(WM * WN * 64), lds, stream, a, ntm, ntiles);
+    else {
+        ZVX_LAUNCH((conv2d_persist_kernel<C, BM, WM, WN, MAXH, 0, WGPC>), dim3(G), dim3(WM * WN * 64), lds, stream, a, ntm, ntiles);
+        if (a.se_part && a.se_part_S) *a.se_part_S = ntm * WM;          // tells the caller that (and in how many partials) the pool was written
+    }
+}
+
 template <int C, int BM, int WM, int WN, int MINW>
 static bool launch_convreg_c(const GemmArgs& a, hipStream_t stream) {
     dim3 grid((a.M + BM - 1) / BM, a.nbatch);
@@ -1544,6 +1740,7 @@ static const Variant kVariants[] = {
     {"convslab_bf16_128x128", DT_BF16, 128, 128},
     {"pairstream_bf16_c128", DT_BF16, 128, 128},
     {"narrowstage_c16", DT_BF16, 256, 16}, {"narrowstage_c8", DT_BF16, 512, 8},      // whole narrow stages in one launch (narrowstage.hip)
+    {"conv2d_persist_c32", DT_BF16, 384, 32}, {"conv2d_persist_c64", DT_BF16, 256, 64},   // persistent 3 x 3 convolutions of the speaker encoder (26, 27)
 };
 const char* gemm_variant_name(int id) { return kVariants[id].name; }
 int gemm_num_variants() { return (int)(sizeof(kVariants) / sizeof(kVariants[0])); }
@@ -1611,6 +1808,16 @@ static int launch_convslab(GemmArgs a, hipStream_t stream) {
     if (a.flat_win && !a.bflat) {
         // stride-1 3 x 3 convolution over flattened [H][W] maps (ResNetSE34V2.py:74-76): weights in registers for C = 32 / 64, the
         // 256 x 128 register-ring tile with a 160-row halo budget for C = 128 / 256
+        // persistent form (slab_small bit 5: A/B switch, off): needs the per-utterance widths, the symmetric one-row halo and a map at
+        // least one staging step wide
+        if (a.N == a.K && (a.N == 32 || a.N == 64) && !(a.slab_small & 32) && a.dtype == DT_BF16 && a.ntaps == 9 && a.in_len && !a.out_len && hl == a.flat_win + 1 && hr == hl &&
+            a.flat_win >= 64 && (long)a.flat_rows * a.ldx * 2 < 0x7fffffffL &&
+            // ... and one of the block's two epilogue forms: conv1 -> ReLU -> BatchNorm (no bias), or conv2 + bias (folded BatchNorm)
+            a.out && a.out_dtype == DT_BF16 && a.alpha == 1.f && a.out_scale == 1.f && !a.res_mode && !a.accum_mode && !a.out_split3 && a.ldo % 4 == 0 &&
+            ((a.post_scale && a.post_shift && a.bias_mode == 0 && a.act == ACT_RELU) || (!a.post_scale && a.bias_mode == 1 && a.bias && a.act == ACT_NONE))) {
+            if (a.N == 32 && hl + hr <= 544) { launch_conv2d_persist<32, 384, 4, 1, 544, 2>(a, stream); return 26; }
+            if (a.N == 64 && hl + hr <= 288) { launch_conv2d_persist<64, 256, 4, 2, 288, 1>(a, stream); return 27; }
+        }
         if (a.N == a.K && a.N == 32 && launch_convreg_c<32, 384, 4, 1, 2>(a, stream)) return 14;      // 384 rows: 2.35x halo over-read instead of 3x, two workgroups per CU still fit
         if (a.N == a.K && a.N == 64 && launch_convreg_c<64, 256, 2, 2, 2>(a, stream)) return 15;
         if (a.N % 128 || a.K % SLAB_KC || hl + hr > 160) return -4;

@@ -849,15 +849,40 @@ void launch_spk_front(const float* mels, int Tmax, const int* lens, int F, const
                        bn_scale, bn_shift, C0, out, o_dt, Wout);
 }
 
-__global__ void k_se_fc(const float* partial, int S, int H, const int* W, const float* w1, const float* b1, const float* w2, const float* b2, int C, int Cr, float* scale) {
-    extern __shared__ float hbuf[];                           // [Cr] hidden + [C] mean
+// pool_bias (optional): the partial sums were taken BEFORE the convolution's per-channel bias (the pool fused into conv2d_persist_kernel): the
+// mean over the valid positions carries it once
+__global__ void k_se_fc(const float* partial, int S, int H, const int* W, const float* w1, const float* b1, const float* w2, const float* b2, int C, int Cr, float* scale,
+                        const float* pool_bias) {
+    extern __shared__ float hbuf[];                           // [Cr] hidden + [C] mean + [256] partial folds
     const int b = blockIdx.x;
     float* m = hbuf + Cr;
+    float* red = m + C;
     const float cnt = (float)H * (float)W[b];
-    for (int c = threadIdx.x; c < C; c += blockDim.x) {
-        float a = 0.f;
-        for (int i = 0; i < S; i++) a += partial[((long)b * S + i) * C + c];
-        m[c] = a / cnt;
+    // fold the S partial sums in a FIXED order (deterministic) with all 256 threads: thread (g, c) takes partials g, g + G, ... of channel
+    // c (four independent loads in flight: the fused pool of the persistent convolution leaves ~200 partials per utterance, and one
+    // dependent L2 round trip per partial was 60 us of a 10 us kernel), then channel c's G folds are added in order
+    if (C <= (int)blockDim.x) {
+        const int G = blockDim.x / C, g = threadIdx.x / C, c = threadIdx.x % C;
+        if (g < G) {
+            const float* pp = partial + (long)b * S * C + c;
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+            int i = g;
+            for (; i + 3 * G < S; i += 4 * G) { a0 += pp[(long)i * C]; a1 += pp[(long)(i + G) * C]; a2 += pp[(long)(i + 2 * G) * C]; a3 += pp[(long)(i + 3 * G) * C]; }
+            for (; i < S; i += G) a0 += pp[(long)i * C];
+            red[g * C + c] = (a0 + a1) + (a2 + a3);
+        }
+        __syncthreads();
+        if (threadIdx.x < C) {
+            float a = 0.f;
+            for (int q = 0; q < G; q++) a += red[q * C + threadIdx.x];
+            m[threadIdx.x] = a / cnt + (pool_bias ? pool_bias[threadIdx.x] : 0.f);
+        }
+    } else {
+        for (int c = threadIdx.x; c < C; c += blockDim.x) {
+            float a = 0.f;
+            for (int i = 0; i < S; i++) a += partial[((long)b * S + i) * C + c];
+            m[c] = a / cnt + (pool_bias ? pool_bias[c] : 0.f);
+        }
     }
     __syncthreads();
     for (int j = threadIdx.x; j < Cr; j += blockDim.x) {
@@ -873,8 +898,8 @@ __global__ void k_se_fc(const float* partial, int S, int H, const int* W, const 
     }
 }
 void launch_se_fc(const float* partial, int S, int H, const int* W, const float* w1, const float* b1, const float* w2, const float* b2, int C,
-                  int Cr, float* scale, int B, hipStream_t s) {
-    hipLaunchKernelGGL(k_se_fc, dim3(B), dim3(256), (Cr + C) * sizeof(float), s, partial, S, H, W, w1, b1, w2, b2, C, Cr, scale);
+                  int Cr, float* scale, int B, hipStream_t s, const float* pool_bias) {
+    hipLaunchKernelGGL(k_se_fc, dim3(B), dim3(256), (Cr + C + 256) * sizeof(float), s, partial, S, H, W, w1, b1, w2, b2, C, Cr, scale, pool_bias);
 }
 
 // y = relu(x * scale[b][c] + res): 8 channels (16 bytes of bf16) per thread, grid-stride over the map's vectors

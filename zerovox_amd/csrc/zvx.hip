@@ -123,6 +123,7 @@ struct zvx_ctx {
     int use_resstream = 1;                 // zvx_set_int("resstream", 0): ResBlocks of the narrow stages as per-pair launches (A/B, bit-equal)
     int rs_seg_min = 0;                    // zvx_set_int("rs_seg_min", -1): streaming ResBlock segments never shorter than 2048 rows (A/B of the single-request sizing)
     int rs_opt = 3;                        // zvx_set_int("rs_opt", v): StreamArgs.opt of the streaming ResBlock kernels (bit 0: staggered wave priorities)
+    int spk_pool_fuse = 1;                 // zvx_set_int("spk_pool_fuse", 0): the speaker encoder's SE pool as its own pass everywhere (A/B)
     int slab_small = 2, slab_flat = 1;     // zvx_set_int("slab_small" / "slab_flat", v): conv-slab tile choice for single requests / whole-grid XCD remap (A/B; per context)
     int poison_pads = 0;                   // zvx_set_int("poison_pads", 1): every work buffer of the mel decoders is filled with NaN bit patterns before a decode (tests: padding rows / stale rows must never reach a result -- ADVICE r4)
     int use_stagefuse = 1;                 // zvx_set_int("stagefuse", 0): narrow vocoder stages (C = 16 / 8) as per-pair launches instead of ONE launch per stage (narrowstage.hip; A/B)
@@ -1527,8 +1528,9 @@ void run_spkemb(zvx_ctx* c, const float* ref_mels, const int32_t* lens, int B, i
             const int lin = lvl, lout = (stride == 2) ? lvl + 1 : lvl;
             const int Hin = Fh[lin], Win = WS[lin], Hout = Fh[lout], Wout = WS[lout];
             const int* win_d = W_d + (size_t)lin * B; const int* wout_d = W_d + (size_t)lout * B;
+            int pool_S = 0;                                                   // > 0: conv2's launch wrote the SE pool's partial sums itself
             auto conv3 = [&](const std::string& wn, const void* in, int cin, int hin, int win, const int* inlen, int st, void* out,
-                             const float* bias, int act, const float* ps, const float* pt, int ksz) {
+                             const float* bias, int act, const float* ps, const float* pt, int ksz, float* se_part = nullptr) {
                 GemmArgs a = gemm_base(dt);
                 a.X = in; a.x_bs = (long)hin * win * cin; a.ldx = cin; a.W = c->t(wn).dev; a.ldw = cin; a.w_ts = (long)planes * cin;
                 a.M = Hout * Wout; a.N = planes; a.K = cin; a.nbatch = B; a.in_len = inlen; a.out_len = wout_d;
@@ -1538,17 +1540,26 @@ void run_spkemb(zvx_ctx* c, const float* ref_mels, const int32_t* lens, int B, i
                 if (bias) { a.bias = bias; a.bias_mode = 1; }
                 a.act = act; a.post_scale = ps; a.post_shift = pt;
                 a.out = out; a.o_bs = (long)Hout * Wout * planes; a.ldo = planes;
+                if (se_part) { a.se_part = se_part; a.se_part_S = &pool_S; }
                 c->gemm(a);
             };
             // conv1 -> ReLU -> BN1                                          ResNetSE34V2.py:86-88
             conv3(p + ".c1", x, Cin, Hin, Win, win_d, stride, o1, nullptr, ACT_RELU, c->pf(p + ".bn1_s"), c->pf(p + ".bn1_t"), 3);
             // conv2 (+ folded BN2)                                           :90-91
-            conv3(p + ".c2", o1, planes, Hout, Wout, wout_d, 1, o2, c->pf(p + ".c2_b"), ACT_NONE, nullptr, nullptr, 3);
             // SE: global average pool -> fc -> relu -> fc -> sigmoid        :63-67
+            // (the persistent 2-D convolution of the C = 32 / 64 levels leaves the pool's partial sums itself -- one per (row tile, wave):
+            // at most ceil(H W / 256) x 4 of them; every other launch is followed by the pool pass)
             const int nsplit = se_pool_splits(Hout, Wout);
-            float* separt = c->fbuf("spk.separt", (size_t)B * nsplit * planes);
-            launch_se_pool(o2, dt, B, Hout, Wout, wout_d, planes, separt, c->stream);
-            launch_se_fc(separt, nsplit, Hout, wout_d, c->pf(p + ".se_w1"), c->pf(p + ".se_b1"), c->pf(p + ".se_w2"), c->pf(p + ".se_b2"), planes, planes / 8, sescale, B, c->stream);
+            const size_t part_max = std::max((size_t)nsplit, (size_t)((Hout * Wout + 255) / 256) * 4);
+            float* separt = c->fbuf("spk.separt", (size_t)B * part_max * planes);
+            conv3(p + ".c2", o1, planes, Hout, Wout, wout_d, 1, o2, c->pf(p + ".c2_b"), ACT_NONE, nullptr, nullptr, 3, c->spk_pool_fuse ? separt : nullptr);
+            if (pool_S > 0) {
+                if ((size_t)pool_S > part_max) fail(ZVX_E_STATE, "fused SE pool wrote %d partials, %zu allocated", pool_S, part_max);
+                launch_se_fc(separt, pool_S, Hout, wout_d, c->pf(p + ".se_w1"), c->pf(p + ".se_b1"), c->pf(p + ".se_w2"), c->pf(p + ".se_b2"), planes, planes / 8, sescale, B, c->stream, c->pf(p + ".c2_b"));
+            } else {
+                launch_se_pool(o2, dt, B, Hout, Wout, wout_d, planes, separt, c->stream);
+                launch_se_fc(separt, nsplit, Hout, wout_d, c->pf(p + ".se_w1"), c->pf(p + ".se_b1"), c->pf(p + ".se_w2"), c->pf(p + ".se_b2"), planes, planes / 8, sescale, B, c->stream);
+            }
             const void* resid = x;
             if (c->has(p + ".ds")) {                                          // 1x1 stride-s conv + folded BN   :94-95
                 conv3(p + ".ds", x, Cin, Hin, Win, win_d, stride, rs, c->pf(p + ".ds_b"), ACT_NONE, nullptr, nullptr, 1);
@@ -1840,6 +1851,7 @@ zvx_status zvx_set_int(zvx_ctx* c, const char* key, int64_t value) {
         else if (std::string(key) == "rs_opt") c->rs_opt = (int)value;
         else if (std::string(key) == "rs_seg_min") c->rs_seg_min = (int)value;
         else if (std::string(key) == "slab_small") c->slab_small = (int)value;
+        else if (std::string(key) == "spk_pool_fuse") c->spk_pool_fuse = (int)value;
         else if (std::string(key) == "slab_flat") c->slab_flat = (int)value;
         else if (std::string(key) == "max_frames") { if (value < 1 || value > (1 << 24)) fail(ZVX_E_INVALID, "max_frames out of range"); c->max_frames = (int)value; }
         else fail(ZVX_E_INVALID, "unknown option '%s'", key);

@@ -90,6 +90,10 @@ struct GemmArgs {
     int act; float slope;
     const float* post_scale; const float* post_shift;
     void* out; long o_bs, o_hs; int ldo; int out_dtype;   // out may be NULL (accum only)
+    // squeeze-excite pool fused into the persistent 2-D convolution (conv2d_persist_kernel, MODE 0): partial sums over the valid
+    // positions of the f32 results before the bias, [nbatch][S][N]; the launcher writes S to *se_part_S (a HOST int the caller
+    // zeroed) when the launch it chose fills them -- otherwise the caller runs the pool pass (launch_se_pool)
+    float* se_part; int* se_part_S;
     // accounting
     double flops;              // algorithmic FLOPs of this launch (filled by the launcher)
 };
@@ -299,7 +303,7 @@ int se_pool_splits(int H, int Wmax);
 void launch_se_pool(const void* x, int x_dt, int B, int H, int Wmax, const int* W, int C, float* partial, hipStream_t s);
 // second half + MLP: m = sum_s partial / (H * W[b]);  scale = sigmoid(W2 relu(W1 m + b1) + b2) per clip
 void launch_se_fc(const float* partial, int S, int H, const int* W, const float* w1, const float* b1, const float* w2, const float* b2, int C,
-                  int Cr, float* scale, int B, hipStream_t s);
+                  int Cr, float* scale, int B, hipStream_t s, const float* pool_bias = nullptr);
 // y = relu(x * scale[b][c] + res)
 void launch_se_apply(const void* x, const void* res, void* y, int dt, const float* scale, int B, int H, int Wmax,
                      const int* W, int C, hipStream_t s);
