@@ -627,9 +627,13 @@ def test_speaker_encoder_persistent_convolutions_and_fused_se_pool():
         e_pass = ctx.spkemb(mels, lens)
         ctx.set_int("slab_small", 2 | 32)
         e_old = ctx.spkemb(mels, lens)
+        ctx.set_int("slab_small", 2)
+        ctx.set_int("spk_s2_fuse", 0)                                       # level transition as two launches of the gathered-row GEMM
+        e_s2 = ctx.spkemb(mels, lens)
     finally:
         ctx.set_int("spk_pool_fuse", 1)
         ctx.set_int("slab_small", 2)
+        ctx.set_int("spk_s2_fuse", 1)
     for b in range(5):
         ref = O.resnet_se34v2(mels[b, :lens[b]], sd, cfg)
         check_embed16(e_new[b], ref, f"persistent convolutions + fused pool, clip {b} ({lens[b]} frames)")
@@ -640,6 +644,11 @@ def test_speaker_encoder_persistent_convolutions_and_fused_se_pool():
     d1, d2 = float(np.abs(e_new - e_pass).max()), float(np.abs(e_pass - e_old).max())
     _errlog("embed-variants", "fused pool vs pool pass / persistent vs per-tile kernels", d1, d2)
     assert d1 <= 1.5e-3 and d2 <= 1e-6, f"launch sets disagree: fused pool vs pass {d1:.3e}, persistent vs per-tile {d2:.3e}"
+    # the fused level transition (conv2d_s2_kernel: stride-2 conv1 + shortcut in one launch) against the two gathered-row launches:
+    # same products, another order of f32 additions
+    d3 = float(np.abs(e_s2 - e_pass).max())
+    _errlog("embed-variants", "fused level transition vs two gathered-row launches", d3)
+    assert d3 <= 1.5e-3, f"fused level transition disagrees with the gathered-row launches: {d3:.3e}"
     # the same call twice: bit-identical (the pool's partial sums are folded in a fixed order, no atomics)
     assert np.array_equal(e_new, ctx.spkemb(mels, lens))
 

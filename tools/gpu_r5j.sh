@@ -1,21 +1,22 @@
 #!/bin/bash
-# round 5, GPU call J: persistent 2-D convolution (+ fused SE pool), tests + A/B: slab_small bit 5 = previous kernels, spk_pool_fuse=0 = pool pass
+# round 5, GPU call J: speaker encoder launch sets, tests + A/B: slab_small bit 5 = previous kernels, spk_pool_fuse=0 = pool pass, spk_s2_fuse=0 = gathered-row level transitions
 set -u
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/r5j; mkdir -p $OUT; rm -f $OUT/*
 cd $ROOT
-timeout 1200 python -m pytest tests -m gpu -x -q -k "speaker or spk or embed or resnet or refckpt or reference_written or determin" > $OUT/pytest_sel.txt 2>&1; tail -4 $OUT/pytest_sel.txt
+ZVX_ERR_LOG=$OUT/errlog.txt timeout 1200 python -m pytest tests -m gpu -x -q -k "speaker or spk or embed or resnet or refckpt or reference_written or determin" > $OUT/pytest_sel.txt 2>&1; tail -4 $OUT/pytest_sel.txt
+grep -h "variants" $OUT/errlog.txt
 for i in 1 2; do
   timeout 300 python bench.py --no-cpu-baseline --config 5 > $OUT/bench_cfg5_new_$i.json 2>> $OUT/err.txt
-  timeout 300 python bench.py --no-cpu-baseline --config 5 --set spk_pool_fuse=0 > $OUT/bench_cfg5_nopool_$i.json 2>> $OUT/err.txt
-  timeout 300 python bench.py --no-cpu-baseline --config 5 --set slab_small=34 > $OUT/bench_cfg5_old_$i.json 2>> $OUT/err.txt
+  timeout 300 python bench.py --no-cpu-baseline --config 5 --set spk_s2_fuse=0 > $OUT/bench_cfg5_nos2_$i.json 2>> $OUT/err.txt
+  timeout 300 python bench.py --no-cpu-baseline --config 5 --set slab_small=34 --set spk_pool_fuse=0 > $OUT/bench_cfg5_old_$i.json 2>> $OUT/err.txt
 done
 python - <<'PY'
 import json,glob,os
 for f in sorted(glob.glob(os.environ.get("GRAFT_REPO_ROOT",".")+"/gpurun_out/r5j/bench_*.json")):
     try:
         j=json.loads(open(f).read().strip().splitlines()[-1])
-        print(os.path.basename(f), round(j["ms_per_step"],3), round(j["value"]), [(k["name"],k["launches"],k["ms"]) for k in j.get("kernels_one_step",[]) if "convreg" in k["name"]])
+        print(os.path.basename(f), round(j["ms_per_step"],3), round(j["value"]), [(k["name"],k["launches"],k["ms"]) for k in j.get("kernels_one_step",[])])
     except Exception as e: print(f, "ERR", e)
 PY
 tail -5 $OUT/err.txt

@@ -1034,9 +1034,11 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN * WGPC / 4) void conv2d_persi
         const int b = t / ntm, mt = t - b * ntm, m0 = mt * BM;
         // (barriers as bare s_barrier behind an LDS-only wait: __syncthreads() would also wait for the requests in flight)
         if (r) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // every wave is done with the previous tile's rows
+        int ts = tid;
+        asm volatile("" : "+v"(ts));                  // opaque: the per-iteration LDS addresses are recomputed per tile instead of living in NIT registers
 #pragma unroll
         for (int it = 0; it < NIT; it++) {
-            const int c = tid + it * NTHR;
+            const int c = ts + it * NTHR;
             if (c < SR * CPR) *(u32x4*)(slab + (c / CPR) * PITCH_ + (c % CPR) * 16) = sv[it];
         }
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -1145,6 +1147,156 @@ static void launch_conv2d_persist(const GemmArgs& a, hipStream_t stream) {
         ZVX_LAUNCH((conv2d_persist_kernel<C, BM, WM, WN, MAXH, 0, WGPC>), dim3(G), dim3(WM * WN * 64), lds, stream, a, ntm, ntiles);
         if (a.se_part && a.se_part_S) *a.se_part_S = ntm * WM;          // tells the caller that (and in how many partials) the pool was written
     }
+}
+
+// ================================================================================================
+// conv2d-s2 kernel (round 5): the level transitions of the speaker encoder (ResNetSE34V2.py:74-76, 94-95): the 3 x 3 / stride-2 / pad-1
+// convolution C -> 2C of a block's conv1 (ReLU, BatchNorm) and, in the same launch (FUSE_DS), the block's 1 x 1 / stride-2 shortcut
+// convolution (+ folded BatchNorm) -- it reads the centre tap's rows.  Persistent workgroups of 8 waves like conv2d_persist_kernel.
+// The input map [hin][win] is staged as its four PARITY PLANES P(pr, pc)[u][v] = x[2u + pr][2v + pc], each flattened over the OUTPUT
+// map's rows (pitch Wo = wout): tap (du, dv) reads plane (du != 0, dv != 0) at flat offset -(du < 0) Wo - (dv < 0).  The output map is
+// one column wider than the widest utterance, so v - 1 = -1 wraps onto a column whose input position 2 (Wo - 1) + pc lies beyond every
+// utterance's width: staged as zero, like every position outside the map.  Every input row is fetched once per tile (plus the one-row
+// halo): the generic gathered-row GEMM ran these launches at 230 TFLOP/s and 1.2 TB/s.
+// ================================================================================================
+template <int C, int BM, int WM, int WN, int MAXHP, bool FUSE_DS>
+__global__ __launch_bounds__(512, 2) void conv2d_s2_kernel(const GemmArgs a, const int ntm, const int ntiles) {
+    constexpr int NTHR = 512, N = 2 * C;
+    constexpr int TM = BM / WM / 32, KS = C / 16, PITCH_ = C * 2 + 16, CPR = C / 8, SRP = BM + MAXHP;
+    constexpr int NCH = 4 * SRP * CPR, NIT = (NCH + NTHR - 1) / NTHR;
+    static_assert(WM * WN == 8 && WN * 32 == N && BM % (WM * 32) == 0, "wave layout");
+    extern __shared__ __attribute__((aligned(16))) unsigned char slab[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave % WM, wc = wave / WM;
+    const int G = gridDim.x, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;      // G is a multiple of 8
+    auto tile_of = [&](int r) {
+        const int base = r * G, n = ntiles - base < G ? ntiles - base : G;
+        if (n <= 0) return ntiles;
+        const int per = (n + 7) >> 3, t = xcd * per + slot;
+        return (slot < per && t < n) ? base + t : ntiles;
+    };
+    const int Wo = a.wout, win = a.win, hin = a.hin, M = a.M;
+    const float rWo = 1.0f / (float)Wo;
+
+    uint4 w[9][KS], wd[FUSE_DS ? KS : 1];
+    {
+        const uint4* Wq = (const uint4*)a.Wp + ((long)wc * 9 * 4) * 64 + lane;
+#pragma unroll
+        for (int t = 0; t < 9; t++)
+#pragma unroll
+            for (int kk = 0; kk < KS; kk++) w[t][kk] = Wq[(t * 4 + kk) * 64];
+        if (FUSE_DS) {
+            const uint4* Dq = (const uint4*)a.ds_Wp + ((long)wc * 4) * 64 + lane;
+#pragma unroll
+            for (int kk = 0; kk < KS; kk++) wd[kk] = Dq[kk * 64];
+        }
+    }
+    // epilogue constants in LDS behind the planes: [N] scale, [N] shift (conv1: ReLU -> x scale + shift), [N] shortcut bias
+    float* const ecl = (float*)(slab + ((4 * SRP * PITCH_ + 15) & ~15));
+    if (tid < N) { ecl[tid] = a.post_scale[tid]; ecl[N + tid] = a.post_shift[tid]; if (FUSE_DS) ecl[2 * N + tid] = a.ds_bias[tid]; }
+
+    u32x4 sv[NIT];
+    auto request = [&](int t) __attribute__((always_inline)) {
+        const int b = t / ntm, m0 = (t - b * ntm) * BM;
+        const int in_len = a.in_len[b];
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)((const unsigned short*)a.X + (long)b * a.x_bs), 0, hin * win * a.ldx * 2, 0x00020000);
+        int tq = tid;
+        asm volatile("" : "+v"(tq));                  // opaque: keeps the per-iteration (plane, row) arithmetic inside the call (hoisted out of the tile loop it cost 24 spilled registers)
+#pragma unroll
+        for (int it = 0; it < NIT; it++) {
+            const int c = tq + it * NTHR, q = c % CPR, rr = c / CPR, plane = rr / SRP, r = rr - plane * SRP;
+            const int g = m0 - MAXHP + r;                                  // flat position of the output map
+            const int gc = g < 0 ? 0 : g;
+            int u = (int)(((float)gc + 0.5f) * rWo);                       // exact for g < 2^22
+            const int v = gc - u * Wo;
+            const int iu = 2 * u + (plane >> 1), iv = 2 * v + (plane & 1);
+            const bool ok = c < NCH && g >= 0 && g < M && iu < hin && iv < in_len;
+            sv[it] = __builtin_amdgcn_raw_buffer_load_b128(rs, ok ? ((iu * win + iv) * a.ldx + q * 8) * 2 : (int)0x80000000, 0, 0);
+        }
+    };
+    int r = 0, t = tile_of(0);
+    if (t < ntiles) request(t);
+    const int xrow0 = MAXHP + wr * (BM / WM) + (lane & 31);
+    const int koff = (lane >> 5) * 16;
+    while (t < ntiles) {
+        const int b = t / ntm, mt = t - b * ntm, m0 = mt * BM;
+        if (r) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // every wave is done with the previous tile's rows
+        int ts = tid;
+        asm volatile("" : "+v"(ts));                  // (opaque, as in request())
+#pragma unroll
+        for (int it = 0; it < NIT; it++) {
+            const int c = ts + it * NTHR;
+            if (c < NCH) *(u32x4*)(slab + (c / CPR) * PITCH_ + (c % CPR) * 16) = sv[it];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        const int tn = tile_of(++r);
+        if (tn < ntiles) request(tn);
+
+        f32x16 acc[TM], accd[FUSE_DS ? TM : 1];
+#pragma unroll
+        for (int j = 0; j < TM; j++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) { acc[j][e] = 0.f; if (FUSE_DS) accd[j][e] = 0.f; }
+#pragma unroll
+        for (int tp = 0; tp < 9; tp++) {
+            const int du = tp / 3 - 1, dv = tp % 3 - 1;
+            const int plane = (du != 0 ? 2 : 0) + (dv != 0 ? 1 : 0);
+            const int off = (du < 0 ? -Wo : 0) + (dv < 0 ? -1 : 0);
+            const unsigned char* rowp = slab + (plane * SRP + xrow0 + off) * PITCH_ + koff;
+#pragma unroll
+            for (int kk = 0; kk < KS; kk++)
+#pragma unroll
+                for (int j = 0; j < TM; j++) {
+                    const uint4 xf = *(const uint4*)(rowp + j * 32 * PITCH_ + kk * 32);
+                    acc[j] = mfma16<false>(w[tp][kk], xf, acc[j]);
+                    if (FUSE_DS && tp == 4) accd[j] = mfma16<false>(wd[kk], xf, accd[j]);
+                }
+        }
+        {
+            unsigned short* const ob = (unsigned short*)a.out + (long)b * a.o_bs + wc * 32 + 4 * (lane >> 5);
+            unsigned short* const db = FUSE_DS ? (unsigned short*)a.ds_out + (long)b * a.o_bs + wc * 32 + 4 * (lane >> 5) : nullptr;
+#pragma unroll
+            for (int j = 0; j < TM; j++) {
+                const int row = m0 + wr * (BM / WM) + j * 32 + (lane & 31);
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    const int ch = wc * 32 + 8 * g + 4 * (lane >> 5);
+                    const float4 e0 = *(const float4*)(ecl + ch), e1 = *(const float4*)(ecl + N + ch);
+                    const float v0 = fmaxf(acc[j][4 * g], 0.f) * e0.x + e1.x, v1 = fmaxf(acc[j][4 * g + 1], 0.f) * e0.y + e1.y;
+                    const float v2 = fmaxf(acc[j][4 * g + 2], 0.f) * e0.z + e1.z, v3 = fmaxf(acc[j][4 * g + 3], 0.f) * e0.w + e1.w;
+                    if (row < M) *(uint2*)(ob + (long)row * a.ldo + 8 * g) = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
+                    if (FUSE_DS) {
+                        const float4 e2 = *(const float4*)(ecl + 2 * N + ch);
+                        if (row < M) *(uint2*)(db + (long)row * a.ldo + 8 * g) =
+                            make_uint2(pack_bf16x2(accd[j][4 * g] + e2.x, accd[j][4 * g + 1] + e2.y), pack_bf16x2(accd[j][4 * g + 2] + e2.z, accd[j][4 * g + 3] + e2.w));
+                    }
+                }
+            }
+        }
+        t = tn;
+    }
+}
+
+// the fused level-transition launch (GemmArgs::ds_out set): true if the shape is covered (and dispatched, unless this is a dry run)
+static bool launch_conv2d_s2(const GemmArgs& a, hipStream_t stream) {
+    bool ok9 = a.ntaps == 9;
+    for (int t = 0; ok9 && t < 9; t++) ok9 = a.du[t] == t / 3 - 1 && a.dv[t] == t % 3 - 1;
+    if (!ok9 || a.dtype != DT_BF16 || a.stride != 2 || a.K != 32 || a.N != 64 || !a.Wp || !a.ds_Wp || !a.ds_out || !a.ds_bias || !a.in_len ||
+        a.wout <= 0 || a.wout + 1 > 136 || a.M != ((a.hin - 1) / 2 + 1) * a.wout || a.ldx != a.K || a.ldo % 4 || !a.out || a.out_dtype != DT_BF16 ||
+        !a.post_scale || !a.post_shift || a.bias_mode != 0 || a.act != ACT_RELU || a.alpha != 1.f || a.out_scale != 1.f || a.res_mode || a.accum_mode || a.out_split3 ||
+        a.nheads != 1 || a.w_bs || (long)a.hin * a.win * a.ldx * 2 >= 0x7fffffffL || (a.slab_small & 32))
+        return false;
+    constexpr int C = 32, BM = 256, MAXHP = 136;
+    const size_t lds = (((size_t)4 * (BM + MAXHP) * (C * 2 + 16) + 15) & ~(size_t)15) + 3 * 2 * C * sizeof(float);
+    const int ntm = (a.M + BM - 1) / BM, ntiles = ntm * a.nbatch;
+    int G = persistent_cus() & ~7;
+    if (ntiles < G) G = (ntiles + 7) & ~7;
+    auto kfn = conv2d_s2_kernel<C, BM, 4, 2, MAXHP, true>;
+    static std::atomic<bool> attr_done{false};
+    if (!attr_done) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_done = true; }
+    ZVX_LAUNCH(kfn, dim3(G), dim3(512), lds, stream, a, ntm, ntiles);
+    return true;
 }
 
 template <int C, int BM, int WM, int WN, int MINW>
@@ -1741,6 +1893,7 @@ static const Variant kVariants[] = {
     {"pairstream_bf16_c128", DT_BF16, 128, 128},
     {"narrowstage_c16", DT_BF16, 256, 16}, {"narrowstage_c8", DT_BF16, 512, 8},      // whole narrow stages in one launch (narrowstage.hip)
     {"conv2d_persist_c32", DT_BF16, 384, 32}, {"conv2d_persist_c64", DT_BF16, 256, 64},   // persistent 3 x 3 convolutions of the speaker encoder (26, 27)
+    {"conv2d_s2_c32", DT_BF16, 256, 64},                                                   // ... its stride-2 level transition + shortcut (28)
 };
 const char* gemm_variant_name(int id) { return kVariants[id].name; }
 int gemm_num_variants() { return (int)(sizeof(kVariants) / sizeof(kVariants[0])); }
@@ -1969,6 +2122,7 @@ void gemm_profile_events(hipEvent_t start, hipEvent_t stop) { g_ev_start = start
 
 int launch_gemm(const GemmArgs& a, hipStream_t stream) {
     if (a.N <= 0 || a.M <= 0 || a.nbatch <= 0) return -1;
+    if (a.ds_out) return launch_conv2d_s2(a, stream) ? 28 : -7;      // the fused level transition is asked for explicitly (the caller probes with gemm_variant_of)
     if (a.ntaps < 1 || a.ntaps > ZVX_MAX_TAPS) return -2;
     if (a.out_split3 && (a.out_dtype != DT_F32 || a.N % 8 || a.flat_win || a.wout > 0)) return -2;
     // N not a multiple of 4: the last 4-wide store spills into [N, roundup4(N)) of the row (ldo must cover it)

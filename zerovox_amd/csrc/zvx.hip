@@ -123,6 +123,7 @@ struct zvx_ctx {
     int use_resstream = 1;                 // zvx_set_int("resstream", 0): ResBlocks of the narrow stages as per-pair launches (A/B, bit-equal)
     int rs_seg_min = 0;                    // zvx_set_int("rs_seg_min", -1): streaming ResBlock segments never shorter than 2048 rows (A/B of the single-request sizing)
     int rs_opt = 3;                        // zvx_set_int("rs_opt", v): StreamArgs.opt of the streaming ResBlock kernels (bit 0: staggered wave priorities)
+    int spk_s2_fuse = 1;                   // zvx_set_int("spk_s2_fuse", 0): the level transitions as two launches of the gathered-row GEMM (A/B)
     int spk_pool_fuse = 1;                 // zvx_set_int("spk_pool_fuse", 0): the speaker encoder's SE pool as its own pass everywhere (A/B)
     int slab_small = 2, slab_flat = 1;     // zvx_set_int("slab_small" / "slab_flat", v): conv-slab tile choice for single requests / whole-grid XCD remap (A/B; per context)
     int poison_pads = 0;                   // zvx_set_int("poison_pads", 1): every work buffer of the mel decoders is filled with NaN bit patterns before a decode (tests: padding rows / stale rows must never reach a result -- ADVICE r4)
@@ -1544,6 +1545,27 @@ void run_spkemb(zvx_ctx* c, const float* ref_mels, const int32_t* lens, int B, i
                 c->gemm(a);
             };
             // conv1 -> ReLU -> BN1                                          ResNetSE34V2.py:86-88
+            // (level transition: conv1 and the shortcut's 1 x 1 convolution, both stride 2 over the same input, in one launch where
+            // conv2d_s2_kernel covers the shape)
+            bool ds_done = false;
+            if (stride == 2 && c->has(p + ".ds") && dt == DT_BF16 && c->spk_s2_fuse) {
+                GemmArgs a = gemm_base(dt);
+                a.X = x; a.x_bs = (long)Hin * Win * Cin; a.ldx = Cin; a.W = c->t(p + ".c1").dev; a.ldw = Cin; a.w_ts = (long)planes * Cin;
+                a.M = Hout * Wout; a.N = planes; a.K = Cin; a.nbatch = B; a.in_len = win_d; a.out_len = wout_d;
+                a.stride = 2; a.wout = Wout; a.hin = Hin; a.win = Win; a.ntaps = 9;
+                for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { a.du[i * 3 + j] = i - 1; a.dv[i * 3 + j] = j - 1; }
+                a.act = ACT_RELU; a.post_scale = c->pf(p + ".bn1_s"); a.post_shift = c->pf(p + ".bn1_t");
+                a.out = o1; a.o_bs = (long)Hout * Wout * planes; a.ldo = planes;
+                auto itp = c->packed.find(c->t(p + ".ds").dev);
+                if (itp != c->packed.end()) {
+                    a.ds_out = rs; a.ds_Wp = itp->second; a.ds_bias = c->pf(p + ".ds_b");
+                    a.flops = 2.0 * (double)a.M * B * planes * (double)Cin * 10;
+                    auto itw = c->packed.find(a.W); if (itw != c->packed.end()) a.Wp = itw->second;
+                    a.slab_small = c->slab_small;
+                    if (gemm_variant_of(a) >= 0) { c->gemm(a); ds_done = true; }
+                }
+            }
+            if (!ds_done)
             conv3(p + ".c1", x, Cin, Hin, Win, win_d, stride, o1, nullptr, ACT_RELU, c->pf(p + ".bn1_s"), c->pf(p + ".bn1_t"), 3);
             // conv2 (+ folded BN2)                                           :90-91
             // SE: global average pool -> fc -> relu -> fc -> sigmoid        :63-67
@@ -1562,7 +1584,7 @@ void run_spkemb(zvx_ctx* c, const float* ref_mels, const int32_t* lens, int B, i
             }
             const void* resid = x;
             if (c->has(p + ".ds")) {                                          // 1x1 stride-s conv + folded BN   :94-95
-                conv3(p + ".ds", x, Cin, Hin, Win, win_d, stride, rs, c->pf(p + ".ds_b"), ACT_NONE, nullptr, nullptr, 1);
+                if (!ds_done) conv3(p + ".ds", x, Cin, Hin, Win, win_d, stride, rs, c->pf(p + ".ds_b"), ACT_NONE, nullptr, nullptr, 1);
                 resid = rs;
             }
             launch_se_apply(o2, resid, o1, dt, sescale, B, Hout, Wout, wout_d, planes, c->stream);     // out*y + residual -> ReLU  :97-98
@@ -1852,6 +1874,7 @@ zvx_status zvx_set_int(zvx_ctx* c, const char* key, int64_t value) {
         else if (std::string(key) == "rs_seg_min") c->rs_seg_min = (int)value;
         else if (std::string(key) == "slab_small") c->slab_small = (int)value;
         else if (std::string(key) == "spk_pool_fuse") c->spk_pool_fuse = (int)value;
+        else if (std::string(key) == "spk_s2_fuse") c->spk_s2_fuse = (int)value;
         else if (std::string(key) == "slab_flat") c->slab_flat = (int)value;
         else if (std::string(key) == "max_frames") { if (value < 1 || value > (1 << 24)) fail(ZVX_E_INVALID, "max_frames out of range"); c->max_frames = (int)value; }
         else fail(ZVX_E_INVALID, "unknown option '%s'", key);

@@ -94,6 +94,10 @@ struct GemmArgs {
     // positions of the f32 results before the bias, [nbatch][S][N]; the launcher writes S to *se_part_S (a HOST int the caller
     // zeroed) when the launch it chose fills them -- otherwise the caller runs the pool pass (launch_se_pool)
     float* se_part; int* se_part_S;
+    // level transition of the speaker encoder in one launch (conv2d_s2_kernel): besides the 3 x 3 / stride-2 convolution these
+    // arguments describe, the block's 1 x 1 / stride-2 shortcut convolution of the SAME input: packed weights [1][N][K], bias [N],
+    // 16-bit output laid out like `out`.  launch_gemm returns -7 when the shape is not covered (probe with gemm_variant_of).
+    void* ds_out; const void* ds_Wp; const float* ds_bias;
     // accounting
     double flops;              // algorithmic FLOPs of this launch (filled by the launcher)
 };
