@@ -951,6 +951,21 @@ __global__ __launch_bounds__(256, MINW) void convreg_kernel(const GemmArgs a) {
     epilogue_rows<TM, 1>(a, acc, b, m0 + wr * (BM / WM), wc * 32, out_len, lane, slab + wave * (32 * (32 * 4 + 16)));
 }
 
+// Stores of a 32 x 32 result block from the MFMA layout (conv2d_persist_kernel / conv2d_s2_kernel): a lane holds 4 groups of 4 consecutive
+// channels of one row, packed to 8 bytes each (pk[g]: channels 8 g + 4 (lane >> 5) ..+3); lanes l and l + 32 hold the two halves of each
+// 16-byte piece.  v_permlane32_swap trades them (gfx950): the low lane ends up with both halves of groups 0 / 2, the high lane with
+// both halves of groups 1 / 3 -> TWO 16-byte stores per lane and block instead of four 8-byte ones (C = 32: conv1 166 -> 154 us, conv2
+// 208 -> 171 us per launch).  The 8-wave kernels store the 8-byte pieces directly: they have no registers for the trade (24-60 spilled).
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
+__device__ __forceinline__ void store_block_mfma_layout(unsigned short* row_ptr /* channel 0 of this wave's 32, this lane's row */, const uint2 (&pk)[4], int lane, bool ok) {
+#pragma unroll
+    for (int pr = 0; pr < 2; pr++) {
+        const u32x2_t sx = __builtin_amdgcn_permlane32_swap(pk[2 * pr].x, pk[2 * pr + 1].x, false, false);
+        const u32x2_t sy = __builtin_amdgcn_permlane32_swap(pk[2 * pr].y, pk[2 * pr + 1].y, false, false);
+        if (ok) *(u32x4*)(row_ptr + 8 * (2 * pr + (lane >> 5))) = (u32x4){sx.x, sy.x, sx.y, sy.y};
+    }
+}
+
 // ================================================================================================
 // conv2d-persist kernel (round 5): the 3 x 3 convolutions over flattened [H][W] maps with C = 32 / 64 channels (the speaker encoder's
 // first two levels, ResNetSE34V2.py:74-76) as PERSISTENT workgroups.  convreg_kernel above spends a tile on serial latencies -- 72 KB of
@@ -959,16 +974,16 @@ __global__ __launch_bounds__(256, MINW) void convreg_kernel(const GemmArgs a) {
 //  * a workgroup keeps its weight fragments for ALL its tiles;
 //  * the rows of its next tile are requested (branch-free raw buffer loads, out-of-range offset = masked) right after the current
 //    tile's rows are committed to LDS: they are in flight under the matrix steps and the epilogue;
-//  * results leave in the MFMA layout: a lane holds 4 x 4 consecutive channels of ONE row -> 4 stores of 8 bytes (lanes l and l + 32
-//    write adjacent halves of a 16-byte piece; the 4 stores of a row block fill whole rows in L2).  The LDS transpose of
-//    epilogue_rows measured 12 k of 25 k cycles per 768-row tile (cut-outs, tools/experiments/README.md);
+//  * results leave from the MFMA layout (store_block_mfma_layout above: two 16-byte stores per lane and 32 x 32 block after a
+//    v_permlane32_swap of the packed halves).  The LDS transpose of epilogue_rows measured 12 k of 25 k cycles per 768-row tile
+//    (cut-outs, tools/experiments/README.md);
 //  * tiles are dealt round by round, in contiguous runs per XCD (a tile's halo rows are its neighbours' centre rows: same L2);
 //  * MODE 0 (conv2, the block's second convolution) also leaves the squeeze-excite pool's partial sums (GemmArgs::se_part): one
 //    [32-channel] partial per (tile, wave) in a fixed slot, folded by k_se_fc in a fixed order -- no pass over the output for the pool.
 // C = 32: 4 waves, two workgroups per CU (246-250 registers).  C = 64 (144 registers of weights per wave): 8 waves of 64 rows, one
 // workgroup per CU, so that the requests of a tile spread over twice the lanes; the epilogue constants live in LDS there.
 // ================================================================================================
-template <int C, int BM, int WM, int WN, int MAXH, int MODE, int WGPC>
+template <int C, int BM, int WM, int WN, int MAXH, int MODE, int WGPC, bool POOL = false>
 __global__ __launch_bounds__(WM * WN * 64, WM * WN * WGPC / 4) void conv2d_persist_kernel(const GemmArgs a, const int ntm, const int ntiles) {
     constexpr int NTHR = WM * WN * 64;
     constexpr int NT = 9, TM = BM / WM / 32, KS = C / 16, PITCH_ = C * 2 + 16, CPR = C / 8, RSTEP = NTHR / CPR;
@@ -1029,7 +1044,7 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN * WGPC / 4) void conv2d_persi
     if (t < ntiles) request(t);
     const int xrow0 = HL + wr * (BM / WM) + (lane & 31);
     const int koff = (lane >> 5) * 16;
-    const bool pool = MODE == 0 && a.se_part != nullptr;
+    constexpr bool pool = MODE == 0 && POOL;
     while (t < ntiles) {
         const int b = t / ntm, mt = t - b * ntm, m0 = mt * BM;
         // (barriers as bare s_barrier behind an LDS-only wait: __syncthreads() would also wait for the requests in flight)
@@ -1072,7 +1087,7 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN * WGPC / 4) void conv2d_persi
         if (!(a.slab_small & 256))
 #endif
         {
-            unsigned short* const ob = (unsigned short*)a.out + (long)b * a.o_bs + wc * 32 + 4 * (lane >> 5);
+            unsigned short* const ob = (unsigned short*)a.out + (long)b * a.o_bs + wc * 32 + (EC_LDS ? 4 * (lane >> 5) : 0);
             const int row0 = m0 + wr * (BM / WM) + (lane & 31);
             // squeeze-excite pool (MODE 0): this lane's sums over its valid rows (positions of the utterance's true width) of the
             // f32 results BEFORE the bias (k_se_fc adds it to the mean: every valid position carries it once)
@@ -1083,6 +1098,7 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN * WGPC / 4) void conv2d_persi
 #pragma unroll
             for (int j = 0; j < TM; j++) {
                 const int row = row0 + j * 32;
+                uint2 pk[4];
 #pragma unroll
                 for (int g = 0; g < 4; g++) {
                     float v0 = acc[0][j][4 * g], v1 = acc[0][j][4 * g + 1], v2 = acc[0][j][4 * g + 2], v3 = acc[0][j][4 * g + 3];
@@ -1096,8 +1112,10 @@ __global__ __launch_bounds__(WM * WN * 64, WM * WN * WGPC / 4) void conv2d_persi
                         v0 = fmaxf(v0, 0.f) * e0.x + e1.x; v1 = fmaxf(v1, 0.f) * e0.y + e1.y;
                         v2 = fmaxf(v2, 0.f) * e0.z + e1.z; v3 = fmaxf(v3, 0.f) * e0.w + e1.w;
                     }
-                    if (row < a.M) *(uint2*)(ob + (long)row * a.ldo + 8 * g) = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
+                    pk[g] = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
+                    if (EC_LDS && row < a.M) *(uint2*)(ob + (long)row * a.ldo + 8 * g) = pk[g];      // (8 waves: no registers for the trade below)
                 }
+                if (!EC_LDS) store_block_mfma_layout(ob + (long)row * a.ldo, pk, lane, row < a.M);
                 if (pool) {
                     const bool pv = row < a.M && col < wlen;
 #pragma unroll
@@ -1143,10 +1161,12 @@ static void launch_conv2d_persist(const GemmArgs& a, hipStream_t stream) {
         attr_done = true;
     }
     if (a.post_scale) ZVX_LAUNCH((conv2d_persist_kernel<C, BM, WM, WN, MAXH, 1, WGPC>), dim3(G), dim3(WM * WN * 64), lds, stream, a, ntm, ntiles);
-    else {
-        ZVX_LAUNCH((conv2d_persist_kernel<C, BM, WM, WN, MAXH, 0, WGPC>), dim3(G), dim3(WM * WN * 64), lds, stream, a, ntm, ntiles);
-        if (a.se_part && a.se_part_S) *a.se_part_S = ntm * WM;          // tells the caller that (and in how many partials) the pool was written
-    }
+    else if (a.se_part && a.se_part_S && (C == 32 || (a.slab_small & 512))) {      // (C = 64: the pool costs the 8-wave kernel 18-50 spilled registers: off unless slab_small bit 9, A/B)
+        static std::atomic<bool> attr2_done{false};
+        if (!attr2_done) { (void)hipFuncSetAttribute((const void*)conv2d_persist_kernel<C, BM, WM, WN, MAXH, 0, WGPC, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr2_done = true; }
+        ZVX_LAUNCH((conv2d_persist_kernel<C, BM, WM, WN, MAXH, 0, WGPC, true>), dim3(G), dim3(WM * WN * 64), lds, stream, a, ntm, ntiles);
+        *a.se_part_S = ntm * WM;                                         // tells the caller that (and in how many partials) the pool was written
+    } else ZVX_LAUNCH((conv2d_persist_kernel<C, BM, WM, WN, MAXH, 0, WGPC>), dim3(G), dim3(WM * WN * 64), lds, stream, a, ntm, ntiles);
 }
 
 // ================================================================================================
@@ -1966,7 +1986,7 @@ static int launch_convslab(GemmArgs a, hipStream_t stream) {
         if (a.N == a.K && (a.N == 32 || a.N == 64) && !(a.slab_small & 32) && a.dtype == DT_BF16 && a.ntaps == 9 && a.in_len && !a.out_len && hl == a.flat_win + 1 && hr == hl &&
             a.flat_win >= 64 && (long)a.flat_rows * a.ldx * 2 < 0x7fffffffL &&
             // ... and one of the block's two epilogue forms: conv1 -> ReLU -> BatchNorm (no bias), or conv2 + bias (folded BatchNorm)
-            a.out && a.out_dtype == DT_BF16 && a.alpha == 1.f && a.out_scale == 1.f && !a.res_mode && !a.accum_mode && !a.out_split3 && a.ldo % 4 == 0 &&
+            a.out && a.out_dtype == DT_BF16 && a.alpha == 1.f && a.out_scale == 1.f && !a.res_mode && !a.accum_mode && !a.out_split3 && a.ldo % 8 == 0 &&
             ((a.post_scale && a.post_shift && a.bias_mode == 0 && a.act == ACT_RELU) || (!a.post_scale && a.bias_mode == 1 && a.bias && a.act == ACT_NONE))) {
             if (a.N == 32 && hl + hr <= 544) { launch_conv2d_persist<32, 384, 4, 1, 544, 2>(a, stream); return 26; }
             if (a.N == 64 && hl + hr <= 288) { launch_conv2d_persist<64, 256, 4, 2, 288, 1>(a, stream); return 27; }
