@@ -8,7 +8,7 @@ ZVX_ERR_LOG=$OUT/errlog.txt timeout 1200 python -m pytest tests -m gpu -x -q -k 
 grep -h variants $OUT/errlog.txt
 for i in 1 2 3; do
   timeout 300 python bench.py --no-cpu-baseline --config 5 > $OUT/bench_cfg5_new_$i.json 2>> $OUT/err.txt
-  timeout 300 python bench.py --no-cpu-baseline --config 5 --set slab_small=514 > $OUT/bench_cfg5_pool64_$i.json 2>> $OUT/err.txt
+  timeout 300 python bench.py --no-cpu-baseline --config 5 --set slab_small=34 --set spk_pool_fuse=0 --set spk_s2_fuse=0 > $OUT/bench_cfg5_old_$i.json 2>> $OUT/err.txt
 done
 python - <<'PY'
 import json,glob,os

@@ -1298,25 +1298,31 @@ __global__ __launch_bounds__(512, 2) void conv2d_s2_kernel(const GemmArgs a, con
     }
 }
 
-// the fused level-transition launch (GemmArgs::ds_out set): true if the shape is covered (and dispatched, unless this is a dry run)
-static bool launch_conv2d_s2(const GemmArgs& a, hipStream_t stream) {
-    bool ok9 = a.ntaps == 9;
-    for (int t = 0; ok9 && t < 9; t++) ok9 = a.du[t] == t / 3 - 1 && a.dv[t] == t % 3 - 1;
-    if (!ok9 || a.dtype != DT_BF16 || a.stride != 2 || a.K != 32 || a.N != 64 || !a.Wp || !a.ds_Wp || !a.ds_out || !a.ds_bias || !a.in_len ||
-        a.wout <= 0 || a.wout + 1 > 136 || a.M != ((a.hin - 1) / 2 + 1) * a.wout || a.ldx != a.K || a.ldo % 4 || !a.out || a.out_dtype != DT_BF16 ||
-        !a.post_scale || !a.post_shift || a.bias_mode != 0 || a.act != ACT_RELU || a.alpha != 1.f || a.out_scale != 1.f || a.res_mode || a.accum_mode || a.out_split3 ||
-        a.nheads != 1 || a.w_bs || (long)a.hin * a.win * a.ldx * 2 >= 0x7fffffffL || (a.slab_small & 32))
-        return false;
-    constexpr int C = 32, BM = 256, MAXHP = 136;
+// the level-transition launch: C = 32 -> 64 with the shortcut convolution fused (GemmArgs::ds_out set), C = 64 -> 128 without (the 144
+// registers of weight fragments leave no room for the shortcut's accumulators).  true if the shape is covered (and dispatched, unless
+// this is a dry run)
+template <int C, int BM, int WM, int WN, int MAXHP, bool FUSE_DS>
+static void launch_conv2d_s2_variant(const GemmArgs& a, hipStream_t stream) {
     const size_t lds = (((size_t)4 * (BM + MAXHP) * (C * 2 + 16) + 15) & ~(size_t)15) + 3 * 2 * C * sizeof(float);
     const int ntm = (a.M + BM - 1) / BM, ntiles = ntm * a.nbatch;
     int G = persistent_cus() & ~7;
     if (ntiles < G) G = (ntiles + 7) & ~7;
-    auto kfn = conv2d_s2_kernel<C, BM, 4, 2, MAXHP, true>;
+    auto kfn = conv2d_s2_kernel<C, BM, WM, WN, MAXHP, FUSE_DS>;
     static std::atomic<bool> attr_done{false};
     if (!attr_done) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_done = true; }
     ZVX_LAUNCH(kfn, dim3(G), dim3(512), lds, stream, a, ntm, ntiles);
-    return true;
+}
+static bool launch_conv2d_s2(const GemmArgs& a, hipStream_t stream) {
+    bool ok9 = a.ntaps == 9;
+    for (int t = 0; ok9 && t < 9; t++) ok9 = a.du[t] == t / 3 - 1 && a.dv[t] == t % 3 - 1;
+    if (!ok9 || a.dtype != DT_BF16 || a.stride != 2 || a.N != 2 * a.K || !a.Wp || !a.in_len ||
+        a.wout <= 0 || a.M != ((a.hin - 1) / 2 + 1) * a.wout || a.ldx != a.K || a.ldo % 8 || !a.out || a.out_dtype != DT_BF16 ||
+        !a.post_scale || !a.post_shift || a.bias_mode != 0 || a.act != ACT_RELU || a.alpha != 1.f || a.out_scale != 1.f || a.res_mode || a.accum_mode || a.out_split3 ||
+        a.nheads != 1 || a.w_bs || (long)a.hin * a.win * a.ldx * 2 >= 0x7fffffffL || (a.slab_small & 32))
+        return false;
+    if (a.K == 32 && a.ds_out && a.ds_Wp && a.ds_bias && a.wout + 1 <= 136) { launch_conv2d_s2_variant<32, 256, 4, 2, 136, true>(a, stream); return true; }
+    if (a.K == 64 && !a.ds_out && a.wout + 1 <= 72) { launch_conv2d_s2_variant<64, 128, 2, 4, 72, false>(a, stream); return true; }
+    return false;
 }
 
 template <int C, int BM, int WM, int WN, int MINW>
@@ -1913,7 +1919,7 @@ static const Variant kVariants[] = {
     {"pairstream_bf16_c128", DT_BF16, 128, 128},
     {"narrowstage_c16", DT_BF16, 256, 16}, {"narrowstage_c8", DT_BF16, 512, 8},      // whole narrow stages in one launch (narrowstage.hip)
     {"conv2d_persist_c32", DT_BF16, 384, 32}, {"conv2d_persist_c64", DT_BF16, 256, 64},   // persistent 3 x 3 convolutions of the speaker encoder (26, 27)
-    {"conv2d_s2_c32", DT_BF16, 256, 64},                                                   // ... its stride-2 level transition + shortcut (28)
+    {"conv2d_s2_c32", DT_BF16, 256, 64}, {"conv2d_s2_c64", DT_BF16, 128, 128},            // ... its stride-2 level transitions (28: + shortcut, 29)
 };
 const char* gemm_variant_name(int id) { return kVariants[id].name; }
 int gemm_num_variants() { return (int)(sizeof(kVariants) / sizeof(kVariants[0])); }
@@ -2143,6 +2149,7 @@ void gemm_profile_events(hipEvent_t start, hipEvent_t stop) { g_ev_start = start
 int launch_gemm(const GemmArgs& a, hipStream_t stream) {
     if (a.N <= 0 || a.M <= 0 || a.nbatch <= 0) return -1;
     if (a.ds_out) return launch_conv2d_s2(a, stream) ? 28 : -7;      // the fused level transition is asked for explicitly (the caller probes with gemm_variant_of)
+    if (a.stride == 2 && a.wout > 0 && a.ntaps == 9 && a.K == 64 && a.Wp && launch_conv2d_s2(a, stream)) return 29;
     if (a.ntaps < 1 || a.ntaps > ZVX_MAX_TAPS) return -2;
     if (a.out_split3 && (a.out_dtype != DT_F32 || a.N % 8 || a.flat_win || a.wout > 0)) return -2;
     // N not a multiple of 4: the last 4-wide store spills into [N, roundup4(N)) of the row (ldo must cover it)
