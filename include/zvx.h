@@ -67,7 +67,7 @@ int64_t    zvx_get_int(const zvx_ctx* ctx, const char* key);
  * the reference has none, fs2.py:678-681 -- a garbage log-duration must not drive an allocation -> ZVX_E_BUFFER).
  * Every other key is an A/B switch of a scheduling / tiling / arithmetic choice (INTEGRATION.md has the table: "enc_split",
  * "front_overlap", "front_prio", "dec_flat", "dec_sc_fuse", "dec_f16", "voc_f16", "stagefuse", "pairstream", "resstream", "slab_small", "slab_flat",
- * "poison_pads", ...);
+ * "poison_pads", "spk_pool_fuse", "spk_s2_fuse", ...);
  * all of them live in the context.  Unknown keys: ZVX_E_INVALID. */
 zvx_status zvx_set_int(zvx_ctx* ctx, const char* key, int64_t value);
 
