@@ -653,6 +653,22 @@ def test_speaker_encoder_persistent_convolutions_and_fused_se_pool():
     assert np.array_equal(e_new, ctx.spkemb(mels, lens))
 
 
+def test_speaker_encoder_long_reference_clips_take_the_fallback_kernels():
+    """Reference clips longer than the persistent / flattened kernels cover (a 3 x 3 convolution over a flattened map needs
+    2 (width + 1) halo rows in LDS: widths up to 271; the stride-2 kernel's parity planes up to 135 output columns): an 8 s clip
+    (700 frames) beside a short one -- level 0 runs on the gathered-row GEMM, level 1 (351 columns) too, levels 2-3 on the
+    flattened kernels; every clip against the oracle."""
+    ctx = ctx_for("styletts", "tiny", "bf16")
+    cfg, sd = tts_sd("styletts")
+    r = np.random.default_rng(29)
+    lens = np.array([700, 300, 541], np.int32)
+    mels = r.standard_normal((3, 700, 80)).astype(np.float32)
+    e = ctx.spkemb(mels, lens)
+    assert np.abs(np.linalg.norm(e, axis=1) - 1.0).max() < 1e-4
+    for b in range(3):
+        check_embed16(e[b], O.resnet_se34v2(mels[b, :lens[b]], sd, cfg), f"long clip {b} ({lens[b]} frames)")
+
+
 def test_stage_times_and_kernel_stats_are_reported():
     ctx = ctx_for("styletts", "tiny", "bf16")
     ph, pu, T, spk, dur = synthetic.batch(2, 16, 0, "uniform")
