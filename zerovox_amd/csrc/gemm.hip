@@ -1153,6 +1153,7 @@ static void launch_conv2d_persist(const GemmArgs& a, hipStream_t stream) {
     const size_t lds = (((size_t)(BM + a.halo_l + a.halo_r) * (C * 2 + 16) + 15) & ~(size_t)15) + 2 * C * sizeof(float);
     const int ntm = (a.M + BM - 1) / BM, ntiles = ntm * a.nbatch;
     int G = (WGPC * persistent_cus()) & ~7;
+    if (G < 8) G = 8;
     if (ntiles < G) G = (ntiles + 7) & ~7;
     static std::atomic<bool> attr_done{false};
     if (!attr_done) {
@@ -1165,7 +1166,7 @@ static void launch_conv2d_persist(const GemmArgs& a, hipStream_t stream) {
         static std::atomic<bool> attr2_done{false};
         if (!attr2_done) { (void)hipFuncSetAttribute((const void*)conv2d_persist_kernel<C, BM, WM, WN, MAXH, 0, WGPC, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr2_done = true; }
         ZVX_LAUNCH((conv2d_persist_kernel<C, BM, WM, WN, MAXH, 0, WGPC, true>), dim3(G), dim3(WM * WN * 64), lds, stream, a, ntm, ntiles);
-        *a.se_part_S = ntm * WM;                                         // tells the caller that (and in how many partials) the pool was written
+        if (!g_dry_run) *a.se_part_S = ntm * WM;                         // tells the caller that (and in how many partials) the pool was written
     } else ZVX_LAUNCH((conv2d_persist_kernel<C, BM, WM, WN, MAXH, 0, WGPC>), dim3(G), dim3(WM * WN * 64), lds, stream, a, ntm, ntiles);
 }
 
@@ -1306,6 +1307,7 @@ static void launch_conv2d_s2_variant(const GemmArgs& a, hipStream_t stream) {
     const size_t lds = (((size_t)4 * (BM + MAXHP) * (C * 2 + 16) + 15) & ~(size_t)15) + 3 * 2 * C * sizeof(float);
     const int ntm = (a.M + BM - 1) / BM, ntiles = ntm * a.nbatch;
     int G = persistent_cus() & ~7;
+    if (G < 8) G = 8;
     if (ntiles < G) G = (ntiles + 7) & ~7;
     auto kfn = conv2d_s2_kernel<C, BM, WM, WN, MAXHP, FUSE_DS>;
     static std::atomic<bool> attr_done{false};
