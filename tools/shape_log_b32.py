@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from zerovox_amd import config as zcfg, weights as zw, pack, _lib, synthetic
 DEC = os.environ.get("ZVX_DECODER", "styletts")
 cfg = zcfg.medium_modelcfg(DEC); sd = zw.tts_state_dict(cfg, 0)
-h = zcfg.hifigan_config("v1"); hsd = zw.hifigan_state_dict(h, 0)
+h = zcfg.hifigan_config(os.environ.get("ZVX_VOCODER", "v1")); hsd = zw.hifigan_state_dict(h, 0)
 man, blob = pack.pack_model(cfg, sd, h, hsd, "bf16")
 ctx = _lib.Context(man, blob, 0)
 for kv in sys.argv[1:]:

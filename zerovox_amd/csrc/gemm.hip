@@ -1342,9 +1342,18 @@ static bool launch_convreg_c(const GemmArgs& a, hipStream_t stream) {
         ZVX_LAUNCH(kfn, grid, dim3(256), lds, stream, a);
         return true;
     }
+    // (k = 5 and the 96-row halo: HiFi-GAN V3's ResBlock2 convolutions -- kernel sizes 3 / 5 / 7 with dilations (1, 2) / (2, 6) / (3, 12),
+    // hifigan.py:60-81 with config_v3: its k = 7, dilation-12 taps span 72 rows and used to fall through to the gathered-row GEMM)
+    if (a.halo_l + a.halo_r > 64) {
+        if (a.ntaps != 7 || a.halo_l + a.halo_r > 96) return false;
+        if (a.dtype == DT_F16) ZVX_LAUNCH((convreg_kernel<C, 7, BM, WM, WN, MINW, 96, true>), grid, dim3(256), lds, stream, a);
+        else ZVX_LAUNCH((convreg_kernel<C, 7, BM, WM, WN, MINW, 96>), grid, dim3(256), lds, stream, a);
+        return true;
+    }
     if (a.dtype == DT_F16) {
         switch (a.ntaps) {
             case 3: ZVX_LAUNCH((convreg_kernel<C, 3, BM, WM, WN, MINW, 64, true>), grid, dim3(256), lds, stream, a); return true;
+            case 5: ZVX_LAUNCH((convreg_kernel<C, 5, BM, WM, WN, MINW, 64, true>), grid, dim3(256), lds, stream, a); return true;
             case 7: ZVX_LAUNCH((convreg_kernel<C, 7, BM, WM, WN, MINW, 64, true>), grid, dim3(256), lds, stream, a); return true;
             case 11: ZVX_LAUNCH((convreg_kernel<C, 11, BM, WM, WN, MINW, 64, true>), grid, dim3(256), lds, stream, a); return true;
         }
@@ -1352,6 +1361,7 @@ static bool launch_convreg_c(const GemmArgs& a, hipStream_t stream) {
     }
     switch (a.ntaps) {
         case 3: ZVX_LAUNCH((convreg_kernel<C, 3, BM, WM, WN, MINW>), grid, dim3(256), lds, stream, a); return true;
+        case 5: ZVX_LAUNCH((convreg_kernel<C, 5, BM, WM, WN, MINW>), grid, dim3(256), lds, stream, a); return true;
         case 7: ZVX_LAUNCH((convreg_kernel<C, 7, BM, WM, WN, MINW>), grid, dim3(256), lds, stream, a); return true;
         case 11: ZVX_LAUNCH((convreg_kernel<C, 11, BM, WM, WN, MINW>), grid, dim3(256), lds, stream, a); return true;
     }
@@ -2007,9 +2017,21 @@ static int launch_convslab(GemmArgs a, hipStream_t stream) {
         ZVX_LAUNCH((convslab_kernel<256, 128, 2, 2, true, 2, 0, -1, 160>), grid, dim3(256), lds, stream, a);
         return 7;
     }
-    if (a.dtype != DT_F32 && a.N == a.K && !a.K2 && (a.ntaps == 3 || a.ntaps == 7 || a.ntaps == 11)) {   // (a second source exists on the slab kernel only: round 5, found on a reduced-width model whose fused shortcut convolutions are square with C = 32 / 64)
+    if (a.dtype != DT_F32 && a.N == a.K && !a.K2 && (a.ntaps == 3 || a.ntaps == 5 || a.ntaps == 7 || a.ntaps == 11)) {   // (a second source exists on the slab kernel only: round 5, found on a reduced-width model whose fused shortcut convolutions are square with C = 32 / 64)
         if (a.N == 32 && launch_convreg_c<32, 512, 4, 1, 2>(a, stream)) return 14;
         if (a.N == 64 && launch_convreg_c<64, 256, 2, 2, 2>(a, stream)) return 15;
+    }
+    if (hl + hr > 64) {
+        // every tile kernel below stages at most 64 halo rows -- but for the 256 x 128 register-ring tile with the 160-row budget of the
+        // flattened 2-D convolutions, here for the closing launch of V3's first stage (C = 128, k = 7, dilation 12: residual + running sum + output)
+        if (hl + hr <= 160 && a.N % 128 == 0 && a.K % SLAB_KC == 0 && !a.K2 && !a.bflat && !a.flat_win && epi_mode_of(a) == ZVX_EPI(1, 1, 1)) {
+            dim3 grid((a.N / 128) * ((a.M + 255) / 256), a.nbatch);
+            const size_t lds = ((size_t)(256 + hl + hr) * SLAB_PITCH + 1023) & ~(size_t)1023;
+            if (a.dtype == DT_F16) ZVX_LAUNCH((convslab_kernel<256, 128, 2, 2, true, 2, 0, ZVX_EPI(1, 1, 1), 160, true>), grid, dim3(256), lds, stream, a);
+            else ZVX_LAUNCH((convslab_kernel<256, 128, 2, 2, true, 2, 0, ZVX_EPI(1, 1, 1), 160>), grid, dim3(256), lds, stream, a);
+            return 7;
+        }
+        return -4;
     }
     // tile choice: padded N weighted by the tile's MFMA efficiency
     static const int bns[4] = {256, 128, 64, 32};
@@ -2176,6 +2198,12 @@ int launch_gemm(const GemmArgs& a, hipStream_t stream) {
         int lo = 0, hi = 0;
         for (int i = 0; i < a.ntaps; i++) { if (a.dv[i] < lo) lo = a.dv[i]; if (a.dv[i] > hi) hi = a.dv[i]; }
         if (hi - lo <= 64 && hi >= 0 && lo <= 0) return launch_convslab(a, stream);
+        // a 96-row halo on the register-weight kernel only (C = 32 / 64, k = 7: HiFi-GAN V3's dilation-12 convolutions)
+        // (... and the 256 x 128 tile's 160-row variant for C = 128)
+        if (hi - lo <= 96 && hi >= 0 && lo <= 0 && a.ntaps == 7 && a.N == a.K && (a.N == 32 || a.N == 64 || a.N == 128) && !a.K2 && !a.out_split3 && !a.bflat) {
+            const int id = launch_convslab(a, stream);
+            if (id >= 0) return id;
+        }
     }
     if (a.out_split3 || a.K2) return -2;                        // only the conv-slab kernel writes split planes / takes a second source
     // tile choice: padded N weighted by the tile's MFMA efficiency, ties -> wider BN
