@@ -202,6 +202,52 @@ __global__ void k_layernorm(const void* x, int xdt, int ldx, void* y, int ydt, i
         return;
     }
     const long xo = ((long)b * rows_max + r) * ldx, yo = ((long)b * rows_max + r) * ldy;
+    if (ydt != DT_F32 && !planes && (C & 7) == 0 && C <= 1024 && (ldx & 7) == 0 && (ldy & 7) == 0) {
+        // 16-bit output rows (the FFT-block decoder's 12 LayerNorm / SCLN passes per call, f32 or 16-bit in): the row is read ONCE, as
+        // 16-byte vectors (8 elements per lane and round, one or two rounds), and stays in registers for the mean, the centred second
+        // moment and the affine -- the element-wise form below reads it three times, element by element: 52 us for 28672 x 528 (1.7 TB/s)
+        float v[2][8];
+        bool has[2];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const int c = (lane + 64 * i) * 8;
+            has[i] = c < C;
+            if (has[i] && xdt == DT_F32) {
+                const float4 t0 = *(const float4*)((const float*)x + xo + c), t1 = *(const float4*)((const float*)x + xo + c + 4);
+                v[i][0] = t0.x; v[i][1] = t0.y; v[i][2] = t0.z; v[i][3] = t0.w; v[i][4] = t1.x; v[i][5] = t1.y; v[i][6] = t1.z; v[i][7] = t1.w;
+            } else if (has[i]) unpack8(*(const uint4*)((const unsigned short*)x + xo + c), xdt, v[i]);
+            else { for (int e = 0; e < 8; e++) v[i][e] = 0.f; }
+#pragma unroll
+            for (int e = 0; e < 8; e++) s += v[i][e];
+        }
+        const float mu = wave_sum(s) / C;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int e = 0; e < 8; e++) { const float d = has[i] ? v[i][e] - mu : 0.f; q += d * d; }
+        q = wave_sum(q);
+        const float inv = mode == 0 ? 1.0f / sqrtf(q / C + eps) : 1.0f / (sqrtf(q / (C - 1)) + eps);
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            if (!has[i]) continue;
+            const int c = (lane + 64 * i) * 8;
+            const float* gp = mode == 0 ? gamma + c : bg + (long)b * bg_bs + C + c;
+            const float* bp = mode == 0 ? beta + c : bg + (long)b * bg_bs + c;
+            const float4 g0 = *(const float4*)gp, g1 = *(const float4*)(gp + 4), b0 = *(const float4*)bp, b1 = *(const float4*)(bp + 4);
+            const float g[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w}, be[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+            float o[8];
+#pragma unroll
+            for (int e = 0; e < 8; e++) o[e] = (v[i][e] - mu) * inv * g[e] + be[e];
+            if (post_add) {
+                const float4 p0 = *(const float4*)(post_add + (long)b * C + c), p1 = *(const float4*)(post_add + (long)b * C + c + 4);
+                o[0] += p0.x; o[1] += p0.y; o[2] += p0.z; o[3] += p0.w; o[4] += p1.x; o[5] += p1.y; o[6] += p1.z; o[7] += p1.w;
+            }
+            *(uint4*)((unsigned short*)y + yo + c) = pack8(o, ydt);
+        }
+        return;
+    }
     float s = 0.f;
     for (int c = lane; c < C; c += 64) s += ld(x, xdt, xo + c);
     const float mu = wave_sum(s) / C;
