@@ -2012,6 +2012,19 @@ static int launch_convslab(GemmArgs a, hipStream_t stream) {
         if (a.N == a.K && a.N == 32 && launch_convreg_c<32, 384, 4, 1, 2>(a, stream)) return 14;      // 384 rows: 2.35x halo over-read instead of 3x, two workgroups per CU still fit
         if (a.N == a.K && a.N == 64 && launch_convreg_c<64, 256, 2, 2, 2>(a, stream)) return 15;
         if (a.N % 128 || a.K % SLAB_KC || hl + hr > 160) return -4;
+        // maps whose rows fill 256-row tiles badly (the last level of the speaker encoder: 10 x 34 = 340 positions are 1.33 tiles of
+        // 256 -- a third of the matrix steps on padding -- and 2.66 of 128): 128-row tiles of the same kernel (same K order per output
+        // row: bit-identical): config 5 6.44 -> 6.32 ms.  The level before it (1340 positions: 9 % padding against 5 %) measured 1.85 -> 1.88 ms with
+        // 128-row tiles: not taken.  slab_small bit 10: off (A/B)
+        const int pad256 = ((a.M + 255) / 256) * 256, pad128 = ((a.M + 127) / 128) * 128;
+        if (!(a.slab_small & 1024) && (long)pad256 * 100 > (long)pad128 * 115) {
+            dim3 g128((a.N / 128) * (pad128 / 128), a.nbatch);
+            size_t lds128 = ((size_t)(128 + hl + hr) * SLAB_PITCH + 1023) & ~(size_t)1023;
+            const size_t stage128 = (size_t)4 * 32 * (2 * 128 + 16);
+            if (lds128 < stage128) lds128 = stage128;
+            ZVX_LAUNCH((convslab_kernel<128, 128, 2, 2, true, 2, 0, -1, 160>), g128, dim3(256), lds128, stream, a);
+            return 22;
+        }
         dim3 grid((a.N / 128) * ((a.M + 255) / 256), a.nbatch);
         size_t lds = ((size_t)(256 + hl + hr) * SLAB_PITCH + 1023) & ~(size_t)1023;
         ZVX_LAUNCH((convslab_kernel<256, 128, 2, 2, true, 2, 0, -1, 160>), grid, dim3(256), lds, stream, a);
