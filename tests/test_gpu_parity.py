@@ -262,6 +262,41 @@ def test_vocoder_v3_resblock2_ragged_batch_equals_independent_oracle_calls(prec)
         assert not wav[b, P[b] * 256:].any()
 
 
+def _variants_of(ctx, fn):
+    """kernel variants (names) the conv / GEMM launches of one call went to"""
+    ctx.set_int("profile", 2)
+    ctx.reset_stats()
+    try:
+        fn()
+        return {k["name"]: k["launches"] for k in ctx.kernel_stats()}
+    finally:
+        ctx.set_int("profile", 0)
+
+
+def test_vocoder_v3_routing_no_gathered_row_fallback():
+    """HiFi-GAN V3's k = 7 / dilation-12 convolutions span 72 rows of taps: they used to fall through to the generic gathered-row GEMM
+    (0.99 + 0.63 + 0.22 ms of a 5.1 ms vocoder at the benchmark shape) because the slab kernels stage 64 halo rows.  Every
+    convolution of the V3 generator must run on a slab / register-weight kernel (results: the parity tests above)."""
+    ctx = ctx_for("styletts", "v3", "bf16")
+    rng = np.random.default_rng(5)
+    mel = rng.standard_normal((4, 96, 80)).astype(np.float32)
+    v = _variants_of(ctx, lambda: ctx.vocode_mel(mel, np.full(4, 96, np.int32)))
+    assert v and not [n for n in v if n.startswith("gemm_")], v
+
+
+def test_speaker_encoder_routing_persistent_kernels():
+    """3 s clips: the C = 32 / 64 levels run on conv2d_persist_kernel, both covered level transitions on conv2d_s2_kernel; what is left on
+    the gathered-row GEMM is the 128 -> 256 transition's conv1 and two shortcut convolutions (+ the attention's second projection)."""
+    ctx = ctx_for("styletts", "tiny", "bf16")
+    rng = np.random.default_rng(6)
+    mels = rng.standard_normal((4, 258, 80)).astype(np.float32)
+    v = _variants_of(ctx, lambda: ctx.spkemb(mels, np.full(4, 258, np.int32)))
+    assert v.get("conv2d_persist_c32") == 6 and v.get("conv2d_persist_c64") == 7, v
+    assert v.get("conv2d_s2_c32") == 1 and v.get("conv2d_s2_c64") == 1, v
+    assert "convreg_bf16_c32" not in v and "convreg_bf16_c64" not in v, v
+    assert sum(n for k, n in v.items() if k.startswith("gemm_bf16")) <= 4, v
+
+
 def test_vocoder_many_short_utterances():
     """130 utterances of 1-4 frames: more utterances than the fused kernel's LDS length table holds (scalar-load path),
     fewer tiles than CUs, row tiles entirely past an utterance's end."""
