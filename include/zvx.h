@@ -44,8 +44,14 @@ enum {                   /* flags */
     ZVX_DEVICE_OUT = 1,  /* wav (and mel, if given) output pointers are device pointers */
     ZVX_NO_SYNC = 2,     /* do not hipStreamSynchronize before returning (device outputs only) */
     ZVX_DEVICE_IN = 8,   /* the bulk input (zvx_vocode_mel: mel, zvx_spkemb_ex: ref_mels) is a device pointer */
-    ZVX_PCM16 = 4        /* wav rows are int16 PCM: (int16)(sample * 32760), truncated like numpy astype (demo.py:29-35,
+    ZVX_PCM16 = 4,       /* wav rows are int16 PCM: (int16)(sample * 32760), truncated like numpy astype (demo.py:29-35,
                             model.py:44-63); halves the bytes of the multi-GPU waveform gather.  wav_stride stays in samples */
+    ZVX_HOST_ASYNC = 16  /* zvx_synthesize / zvx_vocode / zvx_vocode_mel: the waveform is delivered to HOST memory without the call waiting
+                            for it (round 6) -- `wav` / `wav_stride` are ignored (wav may be NULL): the rows go to one of the context's two
+                            pinned host slots on a copy stream of their own, the call returns after queueing (as with
+                            ZVX_DEVICE_OUT | ZVX_NO_SYNC; no host mel / log_duration output), zvx_get_int("host_slot") names the slot
+                            and zvx_wait_host(ctx, slot, ...) is where the host meets the rows.  Slots alternate (call i: slot i & 1);
+                            a slot's rows stay valid until the second next ZVX_HOST_ASYNC call */
 };
 
 enum {                   /* zvx_stage_times indices (milliseconds, hipEvent-timed on the ctx stream) */
@@ -60,11 +66,19 @@ enum {                   /* zvx_stage_times indices (milliseconds, hipEvent-time
 zvx_status zvx_create(const char* manifest, const void* weights, size_t nbytes, int device, zvx_ctx** out);
 void       zvx_destroy(zvx_ctx* ctx);
 const char* zvx_last_error(const zvx_ctx* ctx);
-/* "precision" -> 0 bf16 / 1 f32; "hidden", "n_mels", "hop", "device" ... ; -1 if unknown */
+/* "precision" -> 0 bf16 / 1 f32; "hidden", "n_mels", "hop", "device" ... ; -1 if unknown.
+ * "host_slot": the pinned host slot the last ZVX_HOST_ASYNC call writes (-1: none yet).
+ * "f16_sat_events" (round 6): the telltale of the half mode's clamp.  Every 16-bit store of the IEEE-half kernels saturates at +-65504
+ *   (below); after zvx_set_int("f16_sat_check", 1) every convolution of the vocoder and the mel decoders runs as its own launch (no
+ *   LDS-resident intermediate; same arithmetic per convolution, ~3x the time: a debug mode) and every 16-bit tensor it writes is
+ *   scanned for clamped values.  This key drains the context and returns how many were seen since the switch was last set: 0 means no
+ *   clamp engaged on the inputs run so far -- the check to make once on a real checkpoint (the reference, fp32, has no such failure
+ *   mode).  "f16_sat_check" returns the switch. */
 int64_t    zvx_get_int(const zvx_ctx* ctx, const char* key);
 /* "profile" 0/1/2 (0 off, 1 per-stage events, 2 + per-GEMM-launch events); "profile_only" variant id (-1 = all);
  * "shape_log" 0/1 (one stderr line per timed launch); "max_frames" hard cap on a predicted mel length (default 2^18:
  * the reference has none, fs2.py:678-681 -- a garbage log-duration must not drive an allocation -> ZVX_E_BUFFER).
+ * "f16_sat_check" 0/1: the saturation audit of the half mode (see zvx_get_int "f16_sat_events"); setting it (re)zeroes the counter.
  * Every other key is an A/B switch of a scheduling / tiling / arithmetic choice (INTEGRATION.md has the table: "enc_split",
  * "front_overlap", "front_prio", "dec_flat", "dec_sc_fuse", "dec_f16", "voc_f16", "stagefuse", "pairstream", "resstream", "slab_small", "slab_flat",
  * "poison_pads", "spk_pool_fuse", "spk_s2_fuse", ...);
@@ -136,6 +150,13 @@ zvx_status zvx_synthesize(zvx_ctx* ctx, const int32_t* phoneme, const int32_t* p
                           const int32_t* T, int B, int Tmax, const float* spk, const int32_t* pad_to,
                           int Lmax_cap, void* wav, int64_t wav_stride, int32_t* mel_len,
                           float* mel_out, int Lstride, float* log_duration, int flags);
+
+/* Host side of ZVX_HOST_ASYNC: blocks until the waveform copy into `slot` (0 / 1) has landed, then hands out the slot's pinned rows:
+ * *rows -> [*nrows][*stride] samples (f32, or int16 for a ZVX_PCM16 call), the first *valid samples of a row defined as for zvx_vocode
+ * (mel_len[b]*hop samples, then zeros up to max_b).  Any out pointer may be NULL.  The memory belongs to the context (freed by
+ * zvx_destroy, reused by the second next ZVX_HOST_ASYNC call).  ZVX_E_STATE if no call has used the slot.
+ * Replaces the `.cpu().numpy()` hand-over of ZeroVoxTTS.tts_ex (synthesize.py:233-239) for a host that keeps calls in flight. */
+zvx_status zvx_wait_host(zvx_ctx* ctx, int slot, const void** rows, int64_t* stride, int32_t* nrows, int64_t* valid);
 
 /* Debug/parity taps: copy an intermediate of the last call to host fp32.
  * what: "encoder_out" [B][Tmax][hidden] (after the style add), "features" [B][Lmax][hidden],

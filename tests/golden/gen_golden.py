@@ -246,9 +246,8 @@ def text_cases():
 
 
 def main():
-    for f in os.listdir(HERE):
-        if f.endswith(".npz"):
-            os.remove(os.path.join(HERE, f))
+    # (every fixture below is overwritten in place by save(); nothing else in this directory is touched -- refckpt_expected.npz and
+    # refckpt/ belong to gen_ref_checkpoint.py, which keeps its own REFCKPT_MANIFEST.json)
     e2e_case("e2e_styletts_tiny_T8", "styletts", "tiny", 8, 0, "uniform", 32)
     e2e_case("e2e_fs2_tiny_T8", "fastspeech2", "tiny", 8, 1, "uniform", 32)
     e2e_case("e2e_styletts_tiny_T16_pred", "styletts", "tiny", 16, 2, None, 16)

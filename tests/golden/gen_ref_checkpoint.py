@@ -23,6 +23,23 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 warnings.filterwarnings("ignore")
 
+
+def write_manifest():
+    """sha256 of everything this script writes -> tests/golden/REFCKPT_MANIFEST.json (checked by tests/test_oracle_golden.py::test_manifest_hashes;
+    `python tests/golden/gen_ref_checkpoint.py --manifest-only` re-hashes the committed files without importing the reference)."""
+    import json
+    files = ["refckpt_expected.npz", "refckpt/checkpoints/epoch=0-step=0.ckpt", "refckpt/modelcfg.yaml", "refckpt/meldec_config.yaml"]
+    man = {f: {"sha256": hashlib.sha256(open(os.path.join(HERE, f), "rb").read()).hexdigest(), "bytes": os.path.getsize(os.path.join(HERE, f))} for f in files}
+    with open(os.path.join(HERE, "REFCKPT_MANIFEST.json"), "w") as f:
+        json.dump({"generator": "tests/golden/gen_ref_checkpoint.py", "files": man}, f, indent=1, sort_keys=True)
+    print("wrote REFCKPT_MANIFEST.json")
+
+
+
+if __name__ == "__main__" and "--manifest-only" in sys.argv:
+    write_manifest()
+    sys.exit(0)
+
 import ref_import  # noqa: E402
 
 ref_import.install()
@@ -88,6 +105,7 @@ def main():
     path = os.path.join(HERE, "refckpt_expected.npz")
     np.savez_compressed(path, phoneme=phoneme, puncts=puncts, spk=spk, duration=dur, seed=np.int32(SEED), **res)
     print(f"wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB), checkpoint sha256 {hashlib.sha256(open(ck, 'rb').read()).hexdigest()[:16]}")
+    write_manifest()
 
 
 if __name__ == "__main__":

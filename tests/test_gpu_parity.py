@@ -1266,6 +1266,82 @@ def test_half_vocoder_saturates_instead_of_overflowing(voc):
         assert not w[1, P[1] * 256:].any()
 
 
+@pytest.mark.parametrize("voc", ["v1", "v2", "v3"])
+def test_half_mode_saturation_audit_counts_clamped_stores(voc):
+    """Round 6: the half mode's clamp at +-65504 has a telltale.  zvx_set_int("f16_sat_check", 1) runs every convolution of the
+    vocoder and the mel decoders as its own launch (no LDS-resident intermediate) and counts the clamped values in every 16-bit tensor it
+    writes; zvx_get_int("f16_sat_events") reads the count.  At the nominal scale it is 0 -- on the vocoder alone and on a whole synthesis
+    call -- and the audit's waveform meets the oracle like the default path's; a mel scaled by 4096 clamps (> 0), and so does one scaled by
+    256 in the wide V1 generator; re-arming zeroes the counter; the bf16 kernels (voc_f16 0) never count."""
+    h, hsd = voc_sd(voc)
+    ctx = ctx_for("styletts", voc, "bf16")
+    P = np.array([40, 33], np.int32)
+    rng = np.random.default_rng(31)
+    mel = np.zeros((2, 40, 80), np.float32)
+    for b in range(2):
+        mel[b, :P[b]] = rng.standard_normal((P[b], 80)).astype(np.float32)
+    assert ctx.get_int("f16_sat_check") == 0
+    try:
+        ctx.set_int("f16_sat_check", 1)
+        assert ctx.get_int("f16_sat_events") == 0
+        w1 = ctx.vocode_mel(mel, P)
+        assert ctx.get_int("f16_sat_events") == 0, "clamped stores at the nominal scale"
+        check_wav(w1[0, :P[0] * 256], O.hifigan_generator(mel[0, :P[0]].T, hsd, h), "bf16", f"{voc} audit path x1", e2e=False)
+        ph, pu, Tl, spk, dur = synthetic.batch(2, 16, 5, "uniform")
+        ctx.synthesize(ph, pu, Tl, spk, dur, None)
+        assert ctx.get_int("f16_sat_events") == 0, "clamped stores in a whole synthesis call at the nominal scale"
+        w = ctx.vocode_mel(mel * 4096.0, P)
+        n4096 = ctx.get_int("f16_sat_events")
+        assert n4096 > 0 and np.isfinite(w).all()
+        ctx.set_int("f16_sat_check", 1)                      # re-armed: counter back to zero
+        assert ctx.get_int("f16_sat_events") == 0
+        ctx.set_int("voc_f16", 0)
+        ctx.vocode_mel(mel * 4096.0, P)
+        assert ctx.get_int("f16_sat_events") == 0             # bf16 tensors are not half: nothing to clamp, nothing counted
+    finally:
+        ctx.set_int("voc_f16", 1)
+        ctx.set_int("f16_sat_check", 0)
+    assert np.array_equal(ctx.vocode_mel(mel, P), ctx.vocode_mel(mel, P))
+
+
+def test_asynchronous_host_delivery_equals_the_synchronous_call():
+    """Round 6 (synthesize.py:233-239 hands the caller host memory): zvx_synthesize with ZVX_HOST_ASYNC only queues work -- the
+    waveform rows travel to one of the context's two pinned host slots on its copy stream -- and zvx_wait_host hands them out.  Seven calls
+    with different inputs and shapes are queued, each call's host arrays are overwritten as soon as it returns, the host takes delivery of
+    call i - 1 after queueing call i (the pipelined pattern of `bench.py --host-out`): every waveform equals the synchronous call's bit
+    for bit; slots alternate; int16 PCM rows too; a host mel output is refused."""
+    ctx = ctx_for("styletts", "v1", "bf16")
+    shapes = [(3, 24), (2, 40), (3, 24), (1, 9), (4, 31), (3, 24), (2, 17)]
+    cases, refs = [], []
+    for i, (B, T) in enumerate(shapes):
+        ph, pu, Tl, spk, dur = synthetic.batch(B, T, 70 + 5 * i, "uniform")
+        Tl = np.array([T] + [max(1, T - 3 * (b + i % 3)) for b in range(1, B)], np.int32)
+        for b in range(B): ph[b, Tl[b]:] = 0; pu[b, Tl[b]:] = 0; dur[b, Tl[b]:] = 0
+        cases.append((ph, pu, Tl, spk, dur))
+        refs.append(ctx.synthesize(ph, pu, Tl, spk, dur, None, want_mel=False, pcm16=(i == 4)))
+    got, prev = {}, None
+    for i, (ph, pu, Tl, spk, dur) in enumerate(cases):
+        a = [x.copy() for x in (ph, pu, Tl, spk, dur)]
+        r = ctx.synthesize(a[0], a[1], a[2], a[3], a[4], None, want_mel=False, host_async=True, pcm16=(i == 4))
+        assert r["slot"] == i % 2 and r["wav"] is None and np.array_equal(r["mel_len"], refs[i]["mel_len"])
+        a[0][:] = 1; a[1][:] = 1; a[2][:] = 1; a[3][:] = 1e9; a[4][:] = 30
+        if prev is not None:
+            got[prev[0]] = ctx.wait_host(prev[1], pcm16=(prev[0] == 4)).copy()
+        prev = (i, r["slot"])
+    got[prev[0]] = ctx.wait_host(prev[1]).copy()
+    for i, (B, T) in enumerate(shapes):
+        n = int(refs[i]["mel_len"].max()) * 256
+        assert got[i].shape == (B, n) and got[i].dtype == refs[i]["wav"].dtype, (i, got[i].shape, got[i].dtype)
+        assert np.array_equal(got[i], refs[i]["wav"][:, :n]), i
+    with pytest.raises(_lib.ZvxError):
+        ctx.synthesize(*cases[0], None, want_mel=True, host_async=True)
+    # the staged API and a synchronous call between two queued ones
+    r = ctx.synthesize(*cases[1], None, want_mel=False, host_async=True)
+    mid = ctx.synthesize(*cases[2], None, want_mel=False)
+    assert np.array_equal(mid["wav"], refs[2]["wav"])
+    assert np.array_equal(ctx.wait_host(r["slot"]), refs[1]["wav"][:, :int(refs[1]["mel_len"].max()) * 256])
+
+
 def test_vocoder_v2_full_size_ragged_batch_against_the_oracle():
     """HiFi-GAN V2 (the reference's default vocoder, model.py:84) at the benchmark's utterance length on a ragged batch, every utterance
     against its own batch-1 oracle call.  Its last two stages (C = 16 / 8) run as ONE launch per stage (narrowstage.hip: tiles of 384 /
@@ -1314,6 +1390,28 @@ def test_non_finite_mel_values_stay_inside_their_utterance():
     assert not out[2, P[2] * 256:].any()
     again = ctx.vocode_mel(mel, P)
     assert np.array_equal(again, clean)
+
+
+def test_non_finite_mel_values_stay_inside_their_utterance_in_the_narrow_stage_kernel():
+    """The same contract on HiFi-GAN V2, whose last two stages run on narrowstage.hip with PERSISTENT workgroups: 24 utterances
+    of 48 frames are 384 / 576 tiles on 256 / 512 workgroups, so a workgroup moves from a tile of utterance b to a tile of utterance
+    b + 16 (b + 21) with its LDS streams still holding the first one's rows -- a NaN / Inf mel in utterances 1 and 2 must not reach any
+    other utterance through the zero-weight padded tap slots of a convolution's last matrix step (0 x NaN)."""
+    ctx = ctx_for("styletts", "v2", "bf16")
+    B = 24
+    P = np.full(B, 48, np.int32); P[5] = 31; P[20] = 40
+    rng = np.random.default_rng(43)
+    mel = np.zeros((B, 48, 80), np.float32)
+    for b in range(B):
+        mel[b, :P[b]] = rng.standard_normal((P[b], 80)).astype(np.float32)
+    clean = ctx.vocode_mel(mel, P)
+    bad = mel.copy()
+    bad[1, :, :] = np.nan; bad[2, 7:40, 3::5] = np.inf; bad[2, 11:30, 1::7] = -np.inf
+    out = ctx.vocode_mel(bad, P)
+    for b in range(B):
+        if b not in (1, 2):
+            assert np.array_equal(out[b], clean[b]), f"utterance {b} changed by a non-finite mel in utterances 1 / 2"
+    assert np.array_equal(ctx.vocode_mel(mel, P), clean)
 
 
 def test_config5_speaker_encoder_1000_clips():
@@ -1441,7 +1539,8 @@ def test_fused_attention_of_the_fs2_decoder():
         ref = O.fs2_decoder(feats[b, :L[b]], spk[b], sd, cfg)
         check_mel(fused[b, :L[b]], ref, "bf16", f"fused attention utt {b}")
         check_mel(unfused[b, :L[b]], ref, "bf16", f"unfused attention utt {b}", "bf16")       # flash 0: the block falls back to bf16
-        assert np.abs(fused[b, :L[b]] - unfused[b, :L[b]]).max() < 0.08
+        # the two paths against each other: no looser than the sum of their own stated limits against the oracle (check_mel: 2e-2 half, 4e-2 bf16)
+        assert np.abs(fused[b, :L[b]] - unfused[b, :L[b]]).max() <= 2e-2 + 4e-2
         assert not fused[b, L[b]:].any()
 
 
@@ -1462,7 +1561,7 @@ def test_speaker_encoder_sap_pooling_against_reference_golden():
             if prec == "f32":
                 check_f32(e, g["embed"], "SAP embed", 5e-5)
             else:
-                assert float(e @ g["embed"]) > 0.999 and np.abs(e - g["embed"]).max() < 6e-3
+                check_embed16(e, g["embed"], "SAP embed (16-bit mode)")
         finally:
             ctx.close()
 

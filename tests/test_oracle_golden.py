@@ -131,6 +131,15 @@ def test_manifest_hashes():
     for name, meta in man["fixtures"].items():
         data = open(os.path.join(GOLDEN, name + ".npz"), "rb").read()
         assert hashlib.sha256(data).hexdigest() == meta["sha256"], name
+    # the reference-written checkpoint, its configs and the reference's outputs on it (tests/golden/gen_ref_checkpoint.py)
+    ref = json.load(open(os.path.join(GOLDEN, "REFCKPT_MANIFEST.json")))
+    assert set(ref["files"]) >= {"refckpt_expected.npz", "refckpt/checkpoints/epoch=0-step=0.ckpt"}
+    for name, meta in ref["files"].items():
+        data = open(os.path.join(GOLDEN, name), "rb").read()
+        assert hashlib.sha256(data).hexdigest() == meta["sha256"] and len(data) == meta["bytes"], name
+    # every committed fixture is covered by one of the two manifests
+    on_disk = {f for f in os.listdir(GOLDEN) if f.endswith(".npz")}
+    assert on_disk == {n + ".npz" for n in man["fixtures"]} | {n for n in ref["files"] if n.endswith(".npz")}, on_disk
 
 
 def test_onednn_backed_oracle_is_the_same_function():

@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(HERE, "libzvx.so")
 
 ZVX_OK = 0
 ZVX_E_INVALID, ZVX_E_MANIFEST, ZVX_E_HIP, ZVX_E_STATE, ZVX_E_BUFFER, ZVX_E_UNSUPPORTED = 1, 2, 3, 4, 5, 6
-ZVX_DEVICE_OUT, ZVX_NO_SYNC, ZVX_PCM16, ZVX_DEVICE_IN = 1, 2, 4, 8
+ZVX_DEVICE_OUT, ZVX_NO_SYNC, ZVX_PCM16, ZVX_DEVICE_IN, ZVX_HOST_ASYNC = 1, 2, 4, 8, 16
 STAGES = ("encoder", "variance", "lenreg", "decoder", "vocoder", "spkemb")
 ZVX_T_COUNT = 8
 
@@ -20,7 +20,7 @@ EXPORTS = ("zvx_create", "zvx_destroy", "zvx_last_error", "zvx_get_int", "zvx_se
            "zvx_decode", "zvx_decode_features", "zvx_vocode", "zvx_vocode_mel", "zvx_synthesize", "zvx_fetch",
            "zvx_sync", "zvx_stage_times", "zvx_kernel_stats", "zvx_tag_stats", "zvx_reset_stats",
            "zvx_comm_unique_id", "zvx_comm_init", "zvx_comm_gather", "zvx_comm_barrier", "zvx_comm_max_f64", "zvx_comm_info", "zvx_comm_destroy",
-           "zvx_dev_alloc", "zvx_dev_free", "zvx_dev_from_host", "zvx_dev_to_host", "zvx_spkemb_ex")
+           "zvx_dev_alloc", "zvx_dev_free", "zvx_dev_from_host", "zvx_dev_to_host", "zvx_spkemb_ex", "zvx_wait_host")
 ZVX_COMM_ID_BYTES = 128
 
 
@@ -84,6 +84,7 @@ def load():
     lib.zvx_dev_to_host.argtypes = [vp, vp, vp, C.c_size_t]
     lib.zvx_dev_from_host.argtypes = [vp, vp, vp, C.c_size_t]
     lib.zvx_spkemb_ex.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp, C.c_int]
+    lib.zvx_wait_host.argtypes = [vp, C.c_int, C.POINTER(vp), C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_int64)]
     _lib = lib
     return lib
 
@@ -219,8 +220,10 @@ class Context:
         return wav
 
     def synthesize(self, phoneme, puncts, T, spk, duration=None, pad_to=None, want_mel=True, Lmax_cap=0,
-                   wav_device_ptr=None, wav_stride=None, no_sync=False, pcm16=False, mel_device_ptr=None):
+                   wav_device_ptr=None, wav_stride=None, no_sync=False, pcm16=False, mel_device_ptr=None, host_async=False):
         """Batched phoneme -> waveform.  Returns dict(wav [B][N] (None if device output), mel_len, mel, log_duration).
+        host_async: the call only queues work and returns dict(..., slot=s); wait_host(s) hands out the waveform rows in the
+        context's pinned host memory (ZVX_HOST_ASYNC: forced durations, no mel / log-duration output).
         With a device waveform (wav_device_ptr) the mel, if wanted, is a device buffer too (ZVX_DEVICE_OUT covers both outputs):
         mel_device_ptr -> [B][Lmax][n_mels] f32 with Lmax = the longest utterance's forced-duration sum (or Lmax_cap)."""
         phoneme = _i32(phoneme)
@@ -237,6 +240,13 @@ class Context:
             if Lmax <= 0:
                 raise ZvxError(ZVX_E_INVALID, "predicted durations need Lmax_cap (or use encode/decode/vocode)")
         mel_len = np.zeros(B, np.int32)
+        if host_async:
+            if want_mel or wav_device_ptr is not None:
+                raise ZvxError(ZVX_E_INVALID, "host_async delivers the waveform only (want_mel=False, no device pointer)")
+            self._chk(self._lib.zvx_synthesize(self._h, _ptr(phoneme), _ptr(puncts), _ptr(dur), _ptr(T), B, Tmax, _ptr(spk),
+                                               _ptr(pt), Lmax, None, 0, _ptr(mel_len), None, max(Lmax, 1), None,
+                                               ZVX_HOST_ASYNC | (ZVX_PCM16 if pcm16 else 0)))
+            return dict(wav=None, mel_len=mel_len, mel=None, log_duration=None, slot=self.get_int("host_slot"))
         # a queued call (device output, no_sync) must not ask for host outputs: a copy into pageable memory would wait for the stream
         logd = None if (wav_device_ptr is not None and no_sync) else np.zeros((B, Tmax), np.float32)
         mel = np.zeros((B, max(Lmax, 1), self.n_mels), np.float32) if (want_mel and wav_device_ptr is None) else None
@@ -257,6 +267,16 @@ class Context:
                                            _ptr(pt), Lmax, wptr, stride, _ptr(mel_len), mptr, max(Lmax, 1),
                                            _ptr(logd), flags))
         return dict(wav=wav, mel_len=mel_len, mel=mel, log_duration=logd)
+
+    def wait_host(self, slot: int, pcm16=False):
+        """Waveform rows of the ZVX_HOST_ASYNC call that used `slot`: an ndarray VIEW [B][valid samples] of the context's pinned host
+        memory (no copy; valid until the second next host_async call -- copy it to keep it)."""
+        rows, stride, nrows, valid = C.c_void_p(), C.c_int64(), C.c_int32(), C.c_int64()
+        self._chk(self._lib.zvx_wait_host(self._h, int(slot), C.byref(rows), C.byref(stride), C.byref(nrows), C.byref(valid)))
+        ct = C.c_int16 if pcm16 else C.c_float
+        n = int(nrows.value) * int(stride.value)
+        flat = np.ctypeslib.as_array(C.cast(rows, C.POINTER(ct)), shape=(n,))
+        return flat.reshape(int(nrows.value), int(stride.value))[:, :max(int(valid.value), 1)]
 
     # ---- introspection ------------------------------------------------------------------------
     def fetch(self, what, shape):

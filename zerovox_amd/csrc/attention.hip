@@ -337,12 +337,7 @@ bool launch_flash_attention(const FlashArgs& a, hipStream_t stream, bool dry_run
     const size_t lds = 2 * ((size_t)FA_BK * (DP * 2 + 16) + (size_t)DO * (FA_BK * 2 + 16));
     const dim3 grid(((a.L + FA_BQ - 1) / FA_BQ) * a.nbatch * a.nheads), block(256);      // 1-D: the kernel deals (utterance, head, query tile) to the XCDs itself
     if (lds > 160 * 1024) return false;
-    static std::atomic<bool> attr_done{false};
-    if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)flash_attn_kernel<264, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)flash_attn_kernel<264, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_done = true;
-    }
+    if (!lds_opt_in(a.f16 ? (const void*)flash_attn_kernel<264, true> : (const void*)flash_attn_kernel<264, false>)) return false;
     if (a.f16) {
         if (g_fa_ev_start) hipExtLaunchKernelGGL((flash_attn_kernel<264, true>), grid, block, lds, stream, g_fa_ev_start, g_fa_ev_stop, 0, a);
         else hipLaunchKernelGGL((flash_attn_kernel<264, true>), grid, block, lds, stream, a);
@@ -570,8 +565,7 @@ bool launch_attention_f32(const AttnF32Args& a, hipStream_t stream, bool dry_run
     constexpr int D = 264, KP = (D - 128) + 4;
     const size_t lds = sizeof(float) * ((size_t)AF_BQ * (D + 4) + (size_t)AF_BK * KP + (size_t)AF_BQ * (AF_BK + 4) + 32);
     auto kfn = attn_f32_kernel<264>;
-    static std::atomic<bool> attr_done{false};
-    if (!attr_done) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_done = true; }
+    if (!lds_opt_in((const void*)kfn)) return false;
     const dim3 grid((a.L + AF_BQ - 1) / AF_BQ, a.nbatch * a.nheads), block(256);
     if (g_fa_ev_start) hipExtLaunchKernelGGL(kfn, grid, block, lds, stream, g_fa_ev_start, g_fa_ev_stop, 0, a);
     else hipLaunchKernelGGL(kfn, grid, block, lds, stream, a);

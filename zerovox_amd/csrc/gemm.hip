@@ -1155,16 +1155,11 @@ static void launch_conv2d_persist(const GemmArgs& a, hipStream_t stream) {
     int G = (WGPC * persistent_cus()) & ~7;
     if (G < 8) G = 8;
     if (ntiles < G) G = (ntiles + 7) & ~7;
-    static std::atomic<bool> attr_done{false};
-    if (!attr_done) {
-        (void)hipFuncSetAttribute((const void*)conv2d_persist_kernel<C, BM, WM, WN, MAXH, 0, WGPC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)conv2d_persist_kernel<C, BM, WM, WN, MAXH, 1, WGPC>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        attr_done = true;
-    }
+    (void)lds_opt_in((const void*)conv2d_persist_kernel<C, BM, WM, WN, MAXH, 0, WGPC>);        // (per device; a refusal shows up as the launch's own error)
+    (void)lds_opt_in((const void*)conv2d_persist_kernel<C, BM, WM, WN, MAXH, 1, WGPC>);
     if (a.post_scale) ZVX_LAUNCH((conv2d_persist_kernel<C, BM, WM, WN, MAXH, 1, WGPC>), dim3(G), dim3(WM * WN * 64), lds, stream, a, ntm, ntiles);
     else if (a.se_part && a.se_part_S && (C == 32 || (a.slab_small & 512))) {      // (C = 64: the pool costs the 8-wave kernel 18-50 spilled registers: off unless slab_small bit 9, A/B)
-        static std::atomic<bool> attr2_done{false};
-        if (!attr2_done) { (void)hipFuncSetAttribute((const void*)conv2d_persist_kernel<C, BM, WM, WN, MAXH, 0, WGPC, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr2_done = true; }
+        (void)lds_opt_in((const void*)conv2d_persist_kernel<C, BM, WM, WN, MAXH, 0, WGPC, true>);
         ZVX_LAUNCH((conv2d_persist_kernel<C, BM, WM, WN, MAXH, 0, WGPC, true>), dim3(G), dim3(WM * WN * 64), lds, stream, a, ntm, ntiles);
         if (!g_dry_run) *a.se_part_S = ntm * WM;                         // tells the caller that (and in how many partials) the pool was written
     } else ZVX_LAUNCH((conv2d_persist_kernel<C, BM, WM, WN, MAXH, 0, WGPC>), dim3(G), dim3(WM * WN * 64), lds, stream, a, ntm, ntiles);
@@ -1310,8 +1305,7 @@ static void launch_conv2d_s2_variant(const GemmArgs& a, hipStream_t stream) {
     if (G < 8) G = 8;
     if (ntiles < G) G = (ntiles + 7) & ~7;
     auto kfn = conv2d_s2_kernel<C, BM, WM, WN, MAXHP, FUSE_DS>;
-    static std::atomic<bool> attr_done{false};
-    if (!attr_done) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_done = true; }
+    (void)lds_opt_in((const void*)kfn);
     ZVX_LAUNCH(kfn, dim3(G), dim3(512), lds, stream, a, ntm, ntiles);
 }
 static bool launch_conv2d_s2(const GemmArgs& a, hipStream_t stream) {
@@ -1337,8 +1331,7 @@ static bool launch_convreg_c(const GemmArgs& a, hipStream_t stream) {
         if (a.dtype != DT_BF16) return false;
         if (a.ntaps != 9 || a.halo_l + a.halo_r > 544 || lds > 160 * 1024) return false;
         auto kfn = convreg_kernel<C, 9, BM, WM, WN, MINW, 544>;
-        static std::atomic<bool> attr_done{false};
-        if (!attr_done) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_done = true; }
+        if (!lds_opt_in((const void*)kfn)) return false;
         ZVX_LAUNCH(kfn, grid, dim3(256), lds, stream, a);
         return true;
     }

@@ -243,16 +243,26 @@ __global__ __launch_bounds__(64 * NW, NW * WGPC / 4) void narrowstage_kernel(con
         for (int i = tid; i < wbytes / 16; i += 64 * NW) wd[i] = ws[i];
         float* const bd = (float*)(lds + 3 * KN::ROWS * KN::P + wbytes);
         for (int i = tid; i < 6 * a.nk * C; i += 64 * NW) bd[i] = a.bias[i];
-        // the streams start as zeros: block-rounded convolutions read a few rows nothing has written yet (never consumed, but a stale
-        // NaN pattern there would not stay a NaN-free zero in 0 x garbage products of the padded matrix slots)
-        for (int i = tid; i < 3 * KN::ROWS * KN::P / 16; i += 64 * NW) ((uint4*)lds)[i] = make_uint4(0, 0, 0, 0);
     }
-    __syncthreads();
     for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
         const int b = t / ntm, mt = t - b * ntm;
         int len = a.len ? a.len[b] : a.M;
         len = __builtin_amdgcn_readfirstlane(len);
         if (mt * R >= len) continue;
+        // Every tile starts from zeroed streams.  Block-rounded convolutions read a few rows nothing has written in this tile,
+        // and the padded tap slots of a convolution's last matrix step read up to (slots - 1 - h) dil rows past what this tile's earlier
+        // convolutions wrote -- rows left over from the workgroup's previous tile, which may belong to ANOTHER utterance.  Those products
+        // have zero weights, but 0 x NaN is NaN: a non-finite mel of that utterance must not reach this one (include/zvx.h: every other
+        // utterance of the batch stays bit for bit).  4-10 LDS stores per thread and tile; unconditional on purpose (no state carried
+        // across the tile loop: the C = 8 form sits at its 128-register budget).  The barrier also orders the weight / bias fill above.
+        {
+            int z = threadIdx.x;
+            unsigned z0 = 0, z1 = 0, z2 = 0, z3 = 0;
+            asm volatile("" : "+v"(z), "+v"(z0), "+v"(z1), "+v"(z2), "+v"(z3));   // materialised HERE: hoisted out of the tile loop these five registers cost the C = 8 form 9 spills
+#pragma nounroll
+            for (int i = z; i < 3 * KN::ROWS * KN::P / 16; i += 64 * NW) ((uint4*)lds)[i] = make_uint4(z0, z1, z2, z3);
+            __syncthreads();
+        }
         kn.len = len;
         kn.tile(b, mt);
         __syncthreads();
@@ -287,8 +297,7 @@ static bool launch_ns(const StageArgs& a, hipStream_t stream, bool dry_run) {
     const int ncu = persistent_cus() * WGPC;                                       // WGPC workgroups per CU where the LDS footprint allows (one's loads under the other's matrix steps)
     const dim3 grid(ntiles < ncu ? ntiles : ncu), block(64 * NW);
 #define NS_GO(H_) do { auto kfn = narrowstage_kernel<C, R, NW, WGPC, H_>; \
-        static std::atomic<bool> attr_done{false}; \
-        if (!attr_done) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_done = true; } \
+        if (!lds_opt_in((const void*)kfn)) return false; \
         if (g_ns_ev_start) hipExtLaunchKernelGGL(kfn, grid, block, lds, stream, g_ns_ev_start, g_ns_ev_stop, 0, a, wbytes, ntm, ntiles); \
         else hipLaunchKernelGGL(kfn, grid, block, lds, stream, a, wbytes, ntm, ntiles); } while (0)
     if (a.f16) NS_GO(true); else NS_GO(false);

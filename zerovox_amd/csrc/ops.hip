@@ -712,6 +712,28 @@ void launch_zero_tail_rows(float* x, int ldx, int B, int rows_max, const int* ro
     hipLaunchKernelGGL(k_zero_tail_rows, dim3(rows_max, B), dim3(128), 0, s, x, ldx, rows_max, rows, C);
 }
 
+// Saturation audit of the IEEE-half mode (zvx_set_int "f16_sat_check"): every 16-bit store of that mode clamps at +-65504
+// (MODE.FP16_OVFL), so a clamped result IS the bit pattern 0x7BFF / 0xFBFF.  Counts those patterns (and Inf / NaN patterns, which the
+// clamp should have made impossible) in the valid rows of a stored tensor x[b][r][0:C]; one 64-bit atomic per workgroup that found any.
+__global__ void k_count_sat16(const unsigned short* x, long bs, int ld, int rows_max, const int* rows, int C, unsigned long long* count) {
+    const int b = blockIdx.y;
+    const int nr = rows ? min(rows[b], rows_max) : rows_max;
+    unsigned n = 0;
+    for (int r = blockIdx.x; r < nr; r += gridDim.x) {
+        const unsigned short* row = x + (long)b * bs + (long)r * ld;
+        for (int c = threadIdx.x; c < C; c += blockDim.x) n += (row[c] & 0x7FFF) >= 0x7BFF;
+    }
+    for (int o = 32; o > 0; o >>= 1) n += __shfl_down(n, o);
+    __shared__ unsigned part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = n;
+    __syncthreads();
+    if (threadIdx.x == 0) { const unsigned t = part[0] + part[1] + part[2] + part[3]; if (t) atomicAdd(count, (unsigned long long)t); }
+}
+void launch_count_sat16(const void* x, long bs, int ld, int B, int rows_max, const int* rows, int C, unsigned long long* count, hipStream_t s) {
+    if (B <= 0 || rows_max <= 0 || C <= 0) return;
+    hipLaunchKernelGGL(k_count_sat16, dim3(rows_max < 1024 ? rows_max : 1024, B), dim3(256), 0, s, (const unsigned short*)x, bs, ld, rows_max, rows, C, count);
+}
+
 // x[b][r][c] = 0 for len[b] <= c < cols (element size es = 2 / 4 bytes): the key-contiguous V^T of the unfused attention path, whose
 // columns past an utterance's length come from rows nothing has defined (0 x NaN would not be 0 in the P.V product)
 __global__ void k_zero_tail_cols(unsigned char* x, int es, long ld, long bs, int rows, int cols, const int* len) {

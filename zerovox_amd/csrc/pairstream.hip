@@ -483,8 +483,7 @@ bool launch_pairstream(PairArgs a, hipStream_t stream, bool dry_run, hipEvent_t 
     const int nsegs = a.nseg * a.nbatch;
     const dim3 grid(nsegs < nwg ? nsegs : nwg), block(512);
 #define PS_GO1(NT_, AM_, HO_, H_) do { auto kfn = pairstream128_kernel<NT_, AM_, HO_, H_>; \
-        static std::atomic<bool> attr_done{false}; \
-        if (!attr_done) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_done = true; } \
+        if (!lds_opt_in((const void*)kfn)) return false; \
         if (ev_start) hipExtLaunchKernelGGL(kfn, grid, block, lds, stream, ev_start, ev_stop, 0, a); \
         else hipLaunchKernelGGL(kfn, grid, block, lds, stream, a); return true; } while (0)
 #define PS_GO(NT_, AM_, HO_) do { if (a.f16) PS_GO1(NT_, AM_, HO_, true); else PS_GO1(NT_, AM_, HO_, false); } while (0)

@@ -509,8 +509,7 @@ static bool launch_rs(StreamArgs& a, hipStream_t stream, bool dry_run) {
     const dim3 grid(nsegs < nwg ? nsegs : nwg), block(64 * NR * WPR);
     const int am = a.accum ? a.accum_mode : 0;
 #define RS_GO1(AM_, HO_, H_) do { auto kfn = resstream_kernel<C, NT, NPAIR, RSPLIT, AM_, HO_, DP, H_>; \
-        static std::atomic<bool> attr_done{false}; \
-        if (!attr_done) { (void)hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_done = true; } \
+        if (!lds_opt_in((const void*)kfn)) return false; \
         if (g_rs_ev_start) hipExtLaunchKernelGGL(kfn, grid, block, lds, stream, g_rs_ev_start, g_rs_ev_stop, 0, a); \
         else hipLaunchKernelGGL(kfn, grid, block, lds, stream, a); return true; } while (0)
 #define RS_GO(AM_, HO_) do { if (a.f16) RS_GO1(AM_, HO_, true); else RS_GO1(AM_, HO_, false); } while (0)

@@ -78,6 +78,13 @@ struct zvx_ctx {
     int front_overlap = 1;
     bool mel_free_pending = false;         // ev_mel_free is recorded and the front stream has not waited for it yet
     bool front_dirty_main = true;          // front-end buffers were touched on `stream` (zvx_encode / zvx_decode ...) since the front stream last joined it
+    // Asynchronous host delivery (ZVX_HOST_ASYNC; synthesize.py:233-239 hands the caller host memory): the finished waveform rows go to one
+    // of two PINNED host slots on a copy stream of their own, behind an event the vocoder's last kernel records -- the copy of call i runs
+    // under the front end / vocoder of call i + 1, the host thread never waits inside a synthesis call (zvx_wait_host does).
+    struct HostSlot { void* p = nullptr; size_t cap = 0; hipEvent_t ready = nullptr, done = nullptr; bool pending = false; int B = 0, pcm16 = 0; long stride = 0, need = 0; };
+    HostSlot host_slot[2];
+    int host_next = 0, host_last = -1;
+    hipStream_t copy_stream = nullptr;
     hipStream_t aux_stream = nullptr;      // second compute stream: the duration predictor of a small batch beside the pitch predictor
     hipEvent_t ev_aux[2] = {nullptr, nullptr};
     int va_overlap_maxb = 1 << 20;             // zvx_set_int("va_overlap_maxb", n): batches of at most n utterances overlap the two predictors (0: never; A/B)
@@ -115,6 +122,7 @@ struct zvx_ctx {
     int norm_fuse_maxb = 1 << 20;          // zvx_set_int("norm_fuse_maxb", n): batches of at most n utterances may take the one-launch InstanceNorm of the StyleTTS decoder (0: never; A/B)
     int dec_sc_fuse = 1;                   // zvx_set_int("dec_sc_fuse", 0): the 1x1 shortcut of a StyleTTS residual block as its own launch (A/B; the fused form skips one 16-bit rounding of the conv2 result)
     int dec_flat = 1;                      // zvx_set_int("dec_flat", 0): the StyleTTS decoder's convolutions per utterance instead of batch-flattened (A/B, bit-identical)
+    int voc_h16_ok = -1;                   // every contraction weight of the generator has an IEEE-half copy (decided on the first vocoder call)
     int voc_f16 = 1;                       // zvx_set_int("voc_f16", 0): the vocoder's activations / weights / running sum in bf16 instead of IEEE half (A/B; round 5)
     int dec_f16 = 1;                       // zvx_set_int("dec_f16", 0): StyleTTS decoder activations / weights in bf16 instead of IEEE half (A/B)
     int use_attn_f32 = 1;                  // zvx_set_int("attn_f32", 0): the encoder's attention as V^T / score / P.V GEMMs + softmax (A/B)
@@ -127,6 +135,15 @@ struct zvx_ctx {
     int spk_pool_fuse = 1;                 // zvx_set_int("spk_pool_fuse", 0): the speaker encoder's SE pool as its own pass everywhere (A/B)
     int slab_small = 2, slab_flat = 1;     // zvx_set_int("slab_small" / "slab_flat", v): conv-slab tile choice for single requests / whole-grid XCD remap (A/B; per context)
     int poison_pads = 0;                   // zvx_set_int("poison_pads", 1): every work buffer of the mel decoders is filled with NaN bit patterns before a decode (tests: padding rows / stale rows must never reach a result -- ADVICE r4)
+    // Saturation audit of the half mode (zvx_set_int("f16_sat_check", 1)): every 16-bit tensor of the vocoder and the mel
+    // decoders goes through HBM (one launch per convolution: no LDS-resident intermediate) and is scanned for clamped values
+    // (+-65504) behind the launch that wrote it; zvx_get_int("f16_sat_events") is the count since the switch was last set.  A debug mode:
+    // same arithmetic per convolution, ~3x the time.
+    int sat_check = 0;
+    unsigned long long* sat_count_dev() { return (unsigned long long*)buf("sat.count", 64); }
+    void sat_scan(const void* x, int dt, long bs, int ld, int B, int rows_max, const int* rows, int C) {
+        if (sat_check && x && dt == DT_F16) launch_count_sat16(x, bs, ld, B, rows_max, rows, C, sat_count_dev(), stream);
+    }
     int use_stagefuse = 1;                 // zvx_set_int("stagefuse", 0): narrow vocoder stages (C = 16 / 8) as per-pair launches instead of ONE launch per stage (narrowstage.hip; A/B)
     struct NsWeights { void* W = nullptr; float* bias = nullptr; int woff[18] = {0}; };
     std::map<std::string, NsWeights> ns_weights;   // narrowstage.hip fragment order, per (stage, dtype), built on first use
@@ -168,7 +185,7 @@ struct zvx_ctx {
     // of the context is drained first; hipFree's own device-wide synchronisation is not a contract to lean on
     void drain_for_free() {
         HIPCHK(hipStreamSynchronize(stream));
-        for (hipStream_t s2 : {main0, front_stream, aux_stream, voc_aux[0], voc_aux[1], comm_stream})
+        for (hipStream_t s2 : {main0, front_stream, aux_stream, voc_aux[0], voc_aux[1], comm_stream, copy_stream})
             if (s2 && s2 != stream) HIPCHK(hipStreamSynchronize(s2));
     }
     void* buf(const std::string& name, size_t bytes) {
@@ -255,13 +272,17 @@ struct zvx_ctx {
     void gemm(GemmArgs& a) {
         if (a.flops <= 0) a.flops = 2.0 * (double)a.M * a.nbatch * a.nheads * (double)a.N * ((double)a.K * a.ntaps + (double)a.K2);
         if (!a.Wp && a.dtype != DT_F32) { auto it = packed.find(a.W); if (it != packed.end()) a.Wp = it->second; }
-        a.slab_small = slab_small; a.xcd_flat = slab_flat;
+        a.slab_small = slab_small | (spk_s2_fuse ? 0 : 32); a.xcd_flat = slab_flat;      // (bit 5: no conv2d_s2_kernel -- spk_s2_fuse 0 is the gathered-row launch set for BOTH level transitions)
         GemmEvent ev{};
         const bool prof = profile >= 2 && (profile_only < 0 || gemm_variant_of(a) == profile_only);
         if (prof) { ev.a = new_event(); ev.b = new_event(); gemm_profile_events(ev.a, ev.b); }
         int id = a.fused ? launch_resfuse(a, stream) : launch_gemm(a, stream);
         if (prof) gemm_profile_events(nullptr, nullptr);
         if (id < 0) fail(ZVX_E_INVALID, "launch_gemm rejected shape M=%d N=%d K=%d taps=%d", a.M, a.N, a.K, a.ntaps);
+        if (sat_check && a.nheads == 1) {                   // (audit mode: the attention products run fused, their output is scanned by fft_block)
+            sat_scan(a.out, a.out_dtype, a.o_bs, a.ldo, a.nbatch, a.M, a.out_len, a.N);
+            if (a.accum && (a.accum_mode & 2)) sat_scan(a.accum, a.accum_dtype, a.a_bs, a.lda, a.nbatch, a.M, a.out_len, a.N);
+        }
         if (prof) {
             ev.variant = id; ev.flops = a.flops; ev.rows = (long)a.M * a.nbatch * a.nheads; ev.N = a.N; ev.K = a.K; ev.taps = a.ntaps; ev.res = a.res_mode; ev.fused = a.fused;
             const double esz = dtype_size(a.dtype);
@@ -328,6 +349,7 @@ struct zvx_ctx {
         if (front_stream) HIPCHK(hipStreamSynchronize(front_stream));
         HIPCHK(hipStreamSynchronize(stream));
         if (comm_stream) HIPCHK(hipStreamSynchronize(comm_stream));
+        if (copy_stream) HIPCHK(hipStreamSynchronize(copy_stream));
         if (profile) resolve_events();
     }
     // error path of an API call: whatever it queued on a side stream before it threw is drained, so that the next call's main-stream
@@ -338,13 +360,10 @@ struct zvx_ctx {
         for (int i = 0; i < 2; i++) if (voc_aux[i]) (void)hipStreamSynchronize(voc_aux[i]);
         front_dirty_main = true; mel_free_pending = false;
     }
-    int cu_split = 0;                      // ZVX_CU_SPLIT (environment, read by zvx_create): CUs reserved for the front stream; 0 = no spatial split
-    std::vector<uint32_t> cu_mask_front, cu_mask_main;
     int front_prio = 1;                    // zvx_set_int("front_prio", v): priority of the front stream: 1 = highest the device offers, -1 = lowest, 0 = default
     void front_setup() {
         if (front_stream) return;
-        if (cu_split > 0) HIPCHK(hipExtStreamCreateWithCUMask(&front_stream, (uint32_t)cu_mask_front.size(), cu_mask_front.data()));
-        else if (front_prio) {
+        if (front_prio) {
             int least = 0, greatest = 0;                                     // (numerically: greatest priority = the smaller value)
             HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
             HIPCHK(hipStreamCreateWithPriority(&front_stream, hipStreamNonBlocking, front_prio > 0 ? greatest : least));
@@ -704,6 +723,7 @@ void fft_block(zvx_ctx* c, void* x, int dt, int B, int Lmax, const int* len_dev,
     if (flash) {
         // softmax(Q K^T / sqrt(d)) V in one launch, scores and probabilities stay on chip            fs2.py:47-58
         c->timed(4.0 * B * nheads * (double)Lmax * Lmax * d, (double)B * Lmax * (3.0 * H + H) * es, [&] { launch_flash_attention(fa, c->stream, false); });
+        c->sat_scan(o, dt, (long)Ls * H, H, B, Lmax, len_dev, H);
     } else {
     {   // scores = Q K^T / sqrt(d)                                    fs2.py:49-50
         GemmArgs a = gemm_base(dt);
@@ -742,6 +762,7 @@ void fft_block(zvx_ctx* c, void* x, int dt, int B, int Lmax, const int* len_dev,
         if (w.scln) launch_layernorm(y, DT_F32, H, x, dt, H, B, Ls, len_dev, H, 1, 1e-8f, nullptr, nullptr, w.bg, w.bg_bs, nullptr, c->stream);
         else launch_layernorm(y, DT_F32, H, x, dt, H, B, Ls, len_dev, H, 0, 1e-5f, c->pf(w.p + ".ln1_g"), c->pf(w.p + ".ln1_b"), nullptr, 0, nullptr, c->stream, split ? xs : nullptr, sp16);
     });
+    c->sat_scan(x, dt, (long)Ls * H, H, B, Lmax, len_dev, H);
     {   // h = relu(conv_k9(x))                                         fs2.py:198-200
         GemmArgs a = gemm_base(dt);
         a.X = x; a.x_bs = (long)Ls * H; a.ldx = H; a.W = wdev(".w1"); a.ldw = H; a.w_ts = (long)F * H;
@@ -772,6 +793,7 @@ void fft_block(zvx_ctx* c, void* x, int dt, int B, int Lmax, const int* len_dev,
         if (w.scln) launch_layernorm(y, DT_F32, H, x, dt, H, B, Ls, len_dev, H, 1, 1e-8f, nullptr, nullptr, w.bg + 2 * H, w.bg_bs, w.post_add, c->stream);
         else launch_layernorm(y, DT_F32, H, x, dt, H, B, Ls, len_dev, H, 0, 1e-5f, c->pf(w.p + ".ln2_g"), c->pf(w.p + ".ln2_b"), nullptr, 0, w.post_add, c->stream, split ? xs : nullptr, sp16);
     });
+    c->sat_scan(x, dt, (long)Ls * H, H, B, Lmax, len_dev, H);
     if (split && !w.scln) c->fft_xs_ready = x;                                       // the next block on the same buffer finds its input planes in fft.xs
 }
 
@@ -965,6 +987,7 @@ void decoder_fs2(zvx_ctx* c, const float* feats, const float* spk_d, const int* 
     const int Ls = flat ? Lmax + std::max(c->ffn_k0, c->ffn_k1) / 2 : Lmax;
     void* x = c->buf("dec.x", (size_t)B * Ls * H * dtype_size(dt));
     launch_add_pe_cast(feats, pe, x, dt, H, B, Lmax, L_d, H, c->stream, Ls);
+    c->sat_scan(x, dt, (long)Ls * H, H, B, Lmax, L_d, H);
     float* bg = nullptr; long bg_bs = 0;
     if (c->dec_scln) {      // all 2*layers SCLN affine vectors of the call in one GEMM: [b | g] = W s   (fs2.py:85)
         const int NA = 2 * c->dec_layers * 2 * H;
@@ -1027,6 +1050,7 @@ void sty_norm(const StyCtx& s, const void* x, int ldx, int C, void* y, int ldy, 
         launch_norm_affine_act(x, s.dt, ldx, y, s.dt, ldy, s.B, s.Lmax, s.L_d, C, s.mean, s.rstd, gamma, beta, g_bs, one_plus,
                                act, 0.2f, s.c->stream);
     });
+    s.c->sat_scan(y, s.dt, (long)s.Lmax * ldy, ldy, s.B, s.Lmax, s.L_d, C);
     s.c->tag = keep;
 }
 
@@ -1044,6 +1068,7 @@ void decoder_styletts(zvx_ctx* c, const float* feats, const float* spk_d, const 
     void* catA = c->buf("sty.catA", rows * CW * es);
     void* catB = c->buf("sty.catB", rows * CW * es);
     launch_add_pe_cast(feats, nullptr, e, dt, H, B, Lrows, L_d, H, c->stream, Lmax);
+    c->sat_scan(e, dt, (long)Lmax * H, H, B, Lmax, L_d, H);
 
     // AdaIN affine vectors for all 10 norms: h = fc(s)          styletts.py:89-91
     const Tensor& aw = c->t("sty.adain_w");
@@ -1083,6 +1108,7 @@ void decoder_styletts(zvx_ctx* c, const float* feats, const float* spk_d, const 
     for (void* cat : {catA, catB})
         launch_norm_affine_act(t1, dt, R, (char*)cat + (size_t)H2 * es, dt, CW, B, Lmax, L_d, R, s.mean, s.rstd, c->pf("sty.asr_g"),
                                c->pf("sty.asr_beta"), 0, 0, ACT_NONE, 0.f, c->stream);
+    c->sat_scan((char*)catA + (size_t)H2 * es, dt, (long)Lmax * CW, CW, B, Lmax, L_d, R);
     // decode.0..4: AdainResBlk1d                                    styletts.py:119-139
     struct Blk { int cin, cout; bool cat_out; };
     const Blk blks[5] = {{CW, H2, true}, {CW, H2, true}, {CW, H, false}, {H, H, false}, {H, H, false}};
@@ -1148,7 +1174,14 @@ void run_vocoder(zvx_ctx* c, const float* mel, int ldm, int Lmel_max, const int*
                  void* wav_dev, long wav_stride, int pcm16) {
     // 16-bit mode: IEEE half (round 5) -- f16 copies of the weights, f16 activations / running sum, the f16 MFMA at the bf16 rate and 8x
     // less rounding error per tensor; every store saturates (MODE.FP16_OVFL inside the kernels).  zvx_set_int("voc_f16", 0): bf16 (A/B)
-    const int dt = (c->dt == DT_BF16 && c->voc_f16 && c->has("voc.pre_w.h16")) ? DT_F16 : c->dt, nm = c->n_mels;
+    if (c->voc_h16_ok < 0) {
+        // decided once: the half copies exist only for 3-D weights with K % 8 == 0 (upload_weights); a generator with a narrower tensor
+        // (e.g. a 4-channel last stage) runs entirely on the bf16 kernels, which need no packed copies
+        c->voc_h16_ok = 1;
+        for (auto& kv : c->tensors)
+            if (kv.first.rfind("voc.", 0) == 0 && kv.second.kind == 'w' && kv.second.dims.size() == 3 && !c->has(kv.first + ".h16")) c->voc_h16_ok = 0;
+    }
+    const int dt = (c->dt == DT_BF16 && c->voc_f16 && c->voc_h16_ok == 1 && c->has("voc.pre_w.h16")) ? DT_F16 : c->dt, nm = c->n_mels;
     const bool h16 = dt == DT_F16;
     auto vt = [&](const std::string& n) -> const Tensor& { return c->t(h16 ? n + ".h16" : n); };      // a contraction weight in the vocoder's dtype
     const size_t es = dtype_size(dt);
@@ -1186,6 +1219,7 @@ void run_vocoder(zvx_ctx* c, const float* mel, int ldm, int Lmel_max, const int*
 
     c->tag = "voc.pre";
     launch_mel_pad(mel, DT_F32, ldm, Lmel_max, mel_len_d, vin, dt, nm, Pmax, P_d, B, nm, c->stream);     // model.py:331-335
+    c->sat_scan(vin, dt, (long)Pmax * nm, nm, B, Pmax, P_d, nm);
     if (c->front_stream && c->stream != c->front_stream) {   // the mel buffer is free again: a queued call's decoder (front stream) may overwrite it
         HIPCHK(hipEventRecord(c->ev_mel_free, c->stream));
         c->mel_free_pending = true;
@@ -1241,7 +1275,7 @@ void run_vocoder(zvx_ctx* c, const float* mel, int ldm, int Lmel_max, const int*
         const int CH = (c->voc_chunk > 0 && c->voc_chunk < B) ? c->voc_chunk : B;
         // narrow stages (C = 16 / 8: HiFi-GAN V2's last two): all ResBlocks of the stage, their mean and the next stage's activation in ONE
         // launch -- the stage tensor crosses HBM once in, once out (narrowstage.hip)
-        if (c->use_stagefuse && c->voc_resblock == 1 && dt != DT_F32 && (Cout == 16 || Cout == 8) && nk >= 1 && nk <= 3 && CH == B) {
+        if (c->use_stagefuse && !c->sat_check && c->voc_resblock == 1 && dt != DT_F32 && (Cout == 16 || Cout == 8) && nk >= 1 && nk <= 3 && CH == B) {
             bool ok = true;
             for (int j = 0; j < nk; j++) ok = ok && c->voc_rb_d[j].size() == 3;
             StageArgs sa;
@@ -1338,7 +1372,7 @@ void run_vocoder(zvx_ctx* c, const float* mel, int ldm, int Lmel_max, const int*
                 const void* cur = X0s;
                 int pp = 0;
                 int t_first = 0;
-                if (c->voc_resblock == 1 && dt != DT_F32 && c->use_resstream && nd >= 1 && nd <= 3) {
+                if (c->voc_resblock == 1 && dt != DT_F32 && c->use_resstream && !c->sat_check && nd >= 1 && nd <= 3) {
                     // whole ResBlock (or its first two pairs + the last one) as streaming launches: the stage tensor crosses HBM once
                     bool packed_ok = true;
                     for (int t = 0; t < nd; t++)
@@ -1419,7 +1453,7 @@ void run_vocoder(zvx_ctx* c, const float* mel, int ldm, int Lmel_max, const int*
                         const std::string ts = std::to_string(t);
                         const Tensor& w1 = vt(rb + ".c1_" + ts + "_w");
                         const Tensor& w2 = vt(rb + ".c2_" + ts + "_w");
-                        bool fuse = dt != DT_F32 && c->packed.count(w1.dev) && c->packed.count(w2.dev);
+                        bool fuse = dt != DT_F32 && !c->sat_check && c->packed.count(w1.dev) && c->packed.count(w2.dev);
                         if (fuse) {
                             // one launch: xt = lrelu(c1(x_act)+b1) stays in LDS; x' = c2(xt) + b2 + x      hifigan.py:51-55
                             a.X = cur; a.W = w2.dev; a.Wp = c->packed[w2.dev]; a.Wp2 = c->packed[w1.dev];
@@ -1699,13 +1733,33 @@ void do_vocode(zvx_ctx* c, const int32_t* pad_to, void* wav, int64_t wav_stride,
     std::vector<int> P(B);
     int need = 0;
     for (int b = 0; b < B; b++) { P[b] = std::max(pad_to ? pad_to[b] : 0, c->mel_len_host[b]); need = std::max(need, c->mel_len_host[b] * c->hop); }
-    if (wav_stride < need) fail(ZVX_E_BUFFER, "wav_stride %lld < %d samples", (long long)wav_stride, need);
+    const bool host_async = flags & ZVX_HOST_ASYNC;
+    if (!host_async && wav_stride < need) fail(ZVX_E_BUFFER, "wav_stride %lld < %d samples", (long long)wav_stride, need);
     c->stage_begin(ZVX_T_VOCODER);
     void* wdev; long wstride;
-    const bool dev_out = flags & ZVX_DEVICE_OUT;
+    const bool dev_out = (flags & ZVX_DEVICE_OUT) && !host_async;
     const int pcm16 = (flags & ZVX_PCM16) ? 1 : 0;
     const size_t ss = pcm16 ? 2 : 4;
-    if (dev_out) {
+    zvx_ctx::HostSlot* hs = nullptr;
+    if (host_async) {
+        // slot i & 1 of call i: its previous copy (two calls back) has normally long landed and been read; the device-side staging rows are
+        // per slot as well, so this vocoder's conv_post never writes what the previous call's copy is still reading
+        const int slot = c->host_next; c->host_next ^= 1; c->host_last = slot;
+        hs = &c->host_slot[slot];
+        if (!c->copy_stream) HIPCHK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+        if (!hs->ready) { HIPCHK(hipEventCreateWithFlags(&hs->ready, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&hs->done, hipEventDisableTiming)); }
+        if (hs->pending) { HIPCHK(hipEventSynchronize(hs->done)); hs->pending = false; }
+        wstride = (std::max(need, 1) + 7) & ~7;
+        const size_t bytes = (size_t)B * wstride * ss;
+        if (bytes > hs->cap) {
+            if (hs->p) { HIPCHK(hipHostFree(hs->p)); hs->p = nullptr; hs->cap = 0; }
+            const size_t cap = bytes + bytes / 8 + 256;
+            HIPCHK(hipHostMalloc(&hs->p, cap, hipHostMallocDefault));
+            hs->cap = cap;
+        }
+        wdev = c->buf(slot ? "wav.async1" : "wav.async0", bytes);
+        hs->B = B; hs->pcm16 = pcm16; hs->stride = wstride; hs->need = need;
+    } else if (dev_out) {
         wdev = wav; wstride = wav_stride;
         auto f = c->gather_fence.find(wav);                 // a gather still reading this buffer: the vocoder's writes queue behind it
         if (f != c->gather_fence.end()) HIPCHK(hipStreamWaitEvent(c->stream, f->second, 0));
@@ -1713,6 +1767,14 @@ void do_vocode(zvx_ctx* c, const int32_t* pad_to, void* wav, int64_t wav_stride,
     else { wstride = (std::max(need, 1) + 7) & ~7; wdev = c->buf("wav", (size_t)B * wstride * ss); }
     run_vocoder(c, c->fbuf("mel", 0), c->n_mels, c->Lmax, c->mel_len_host.data(), P.data(), B, wdev, wstride, pcm16);
     c->stage_end(ZVX_T_VOCODER);
+    if (host_async) {
+        HIPCHK(hipEventRecord(hs->ready, c->stream));
+        HIPCHK(hipStreamWaitEvent(c->copy_stream, hs->ready, 0));
+        if (need > 0) HIPCHK(hipMemcpyAsync(hs->p, wdev, (size_t)B * wstride * ss, hipMemcpyDeviceToHost, c->copy_stream));
+        HIPCHK(hipEventRecord(hs->done, c->copy_stream));
+        hs->pending = true;
+        return;                                              // queued: zvx_wait_host(slot) is where the host meets the rows
+    }
     if (!dev_out && need > 0)
         HIPCHK(hipMemcpy2DAsync(wav, (size_t)wav_stride * ss, wdev, (size_t)wstride * ss, (size_t)need * ss, B, hipMemcpyDeviceToHost, c->stream));
     if (!(dev_out && (flags & ZVX_NO_SYNC))) c->sync();
@@ -1757,22 +1819,6 @@ zvx_status zvx_create(const char* manifest, const void* weights, size_t nbytes, 
         if (device < 0 || device >= ndev) fail(ZVX_E_INVALID, "device %d out of range (%d visible)", device, ndev);
         c->device = device;
         HIPCHK(hipSetDevice(device));
-        // ZVX_CU_SPLIT=n (A/B experiment, VERDICT r4 #1c): a SPATIAL split of the chip between the two streams of the front-end overlap --
-        // the front stream may only use n CUs, the main stream (vocoder) the other num_cus() - n, and the persistent vocoder kernels size
-        // their grids for those.  ZVX_CU_SPLIT_MODE: 0 = the front stream's CUs are the mask's lowest n bits, 1 = n / 8 bits in each group of 32
-        if (const char* sp = getenv("ZVX_CU_SPLIT")) c->cu_split = std::max(0, std::min(atoi(sp), num_cus() - 8));
-        if (c->cu_split > 0) {
-            const int mode = getenv("ZVX_CU_SPLIT_MODE") ? atoi(getenv("ZVX_CU_SPLIT_MODE")) : 0;
-            const int n = num_cus(), words = (n + 31) / 32;
-            c->cu_mask_front.assign(words, 0u); c->cu_mask_main.assign(words, 0u);
-            for (int i = 0; i < n; i++) {
-                const bool front = mode == 0 ? i < c->cu_split : (i % 32) < c->cu_split / std::max(1, n / 32);
-                (front ? c->cu_mask_front : c->cu_mask_main)[i / 32] |= 1u << (i % 32);
-            }
-            HIPCHK(hipExtStreamCreateWithCUMask(&c->stream, (uint32_t)words, c->cu_mask_main.data()));
-            int nm = 0; for (int i = 0; i < n; i++) nm += (c->cu_mask_main[i / 32] >> (i % 32)) & 1;
-            persistent_cus_override().store(nm);
-        } else
         HIPCHK(hipStreamCreate(&c->stream));
         c->main0 = c->stream;
         for (int s = 0; s < ZVX_T_COUNT; s++) { HIPCHK(hipEventCreate(&c->stage_ev[s][0])); HIPCHK(hipEventCreate(&c->stage_ev[s][1])); c->stage_used[s] = false; c->stage_ms[s] = 0.f; }
@@ -1799,6 +1845,8 @@ void zvx_destroy(zvx_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     zvx_comm_destroy(c);
     for (int i = 0; i < 2; i++) { if (c->arena[i].p) (void)hipHostFree(c->arena[i].p); if (c->arena[i].ev) (void)hipEventDestroy(c->arena[i].ev); }
+    if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
+    for (auto& hs : c->host_slot) { if (hs.p) (void)hipHostFree(hs.p); if (hs.ready) (void)hipEventDestroy(hs.ready); if (hs.done) (void)hipEventDestroy(hs.done); }
     for (int i = 0; i < 2; i++) if (c->voc_aux[i]) { (void)hipStreamSynchronize(c->voc_aux[i]); (void)hipStreamDestroy(c->voc_aux[i]); }
     for (int i = 0; i < 3; i++) if (c->voc_ev[i]) (void)hipEventDestroy(c->voc_ev[i]);
     if (c->aux_stream) { (void)hipStreamSynchronize(c->aux_stream); (void)hipStreamDestroy(c->aux_stream); (void)hipEventDestroy(c->ev_aux[0]); (void)hipEventDestroy(c->ev_aux[1]); }
@@ -1829,6 +1877,15 @@ int64_t zvx_get_int(const zvx_ctx* c, const char* key) {
     if (k == "Lmax") return c->Lmax;
     if (k == "profile") return c->profile;
     if (k == "profile_only") return c->profile_only;
+    if (k == "f16_sat_check") return c->sat_check;
+    if (k == "f16_sat_events") {                             // clamped 16-bit stores seen since zvx_set_int("f16_sat_check", 1); drains the context's streams
+        zvx_ctx* m = const_cast<zvx_ctx*>(c);
+        unsigned long long n = 0;
+        if (hipSetDevice(m->device) != hipSuccess) return -1;
+        try { unsigned long long* d = m->sat_count_dev(); m->sync(); if (hipMemcpy(&n, d, sizeof n, hipMemcpyDeviceToHost) != hipSuccess) return -1; } catch (...) { return -1; }
+        return (int64_t)n;
+    }
+    if (k == "host_slot") return c->host_last;             // the slot the last ZVX_HOST_ASYNC call writes (-1: none yet)
     if (k.rfind("variant_id:", 0) == 0) { for (int i = 0; i < gemm_num_variants(); i++) if (k.substr(11) == gemm_variant_name(i)) return i; return -1; }
     auto it = c->cfg.find(k);
     if (it != c->cfg.end()) return atoll(it->second.c_str());
@@ -1849,6 +1906,10 @@ zvx_status zvx_set_int(zvx_ctx* c, const char* key, int64_t value) {
         else if (std::string(key) == "dec_f16") c->dec_f16 = (int)value;
         else if (std::string(key) == "voc_f16") c->voc_f16 = (int)value;
         else if (std::string(key) == "stagefuse") c->use_stagefuse = (int)value;
+        else if (std::string(key) == "f16_sat_check") {       // (re)arms the audit and zeroes its counter
+            c->sync(); c->sat_check = value ? 1 : 0;
+            HIPCHK(hipMemsetAsync(c->sat_count_dev(), 0, 64, c->stream));
+        }
         else if (std::string(key) == "poison_pads") c->poison_pads = (int)value;
         else if (std::string(key) == "dec_flat") c->dec_flat = (int)value;
         else if (std::string(key) == "dec_sc_fuse") c->dec_sc_fuse = (int)value;
@@ -1947,14 +2008,14 @@ zvx_status zvx_decode_features(zvx_ctx* c, const float* features, const int32_t*
 
 zvx_status zvx_vocode(zvx_ctx* c, const int32_t* pad_to, void* wav, int64_t wav_stride, int flags) {
     return guarded(c, [&] {
-        if (!wav) fail(ZVX_E_INVALID, "zvx_vocode: wav is NULL");
+        if (!wav && !(flags & ZVX_HOST_ASYNC)) fail(ZVX_E_INVALID, "zvx_vocode: wav is NULL");
         do_vocode(c, pad_to, wav, wav_stride, flags);
     });
 }
 
 zvx_status zvx_vocode_mel(zvx_ctx* c, const float* mel, const int32_t* P, int B, int Pmax, void* wav, int64_t wav_stride, int flags) {
     return guarded(c, [&] {
-        if (!mel || !P || !wav || B <= 0 || Pmax <= 0) fail(ZVX_E_INVALID, "zvx_vocode_mel: bad arguments");
+        if (!mel || !P || (!wav && !(flags & ZVX_HOST_ASYNC)) || B <= 0 || Pmax <= 0) fail(ZVX_E_INVALID, "zvx_vocode_mel: bad arguments");
         for (int b = 0; b < B; b++) if (P[b] < 1 || P[b] > Pmax) fail(ZVX_E_INVALID, "P[%d]=%d out of range (1..%d)", b, P[b], Pmax);
         c->B = B; c->Lmax = Pmax; c->Tmax = 0; c->mel_len_host.assign(P, P + B);
         c->have_features = false; c->have_mel = false;             // the context's batch geometry changes: earlier intermediates are void
@@ -1969,7 +2030,9 @@ zvx_status zvx_synthesize(zvx_ctx* c, const int32_t* phoneme, const int32_t* pun
                           int B, int Tmax, const float* spk, const int32_t* pad_to, int Lmax_cap, void* wav, int64_t wav_stride,
                           int32_t* mel_len, float* mel_out, int Lstride, float* log_duration, int flags) {
     return guarded(c, [&] {
-        if (!phoneme || !puncts || !T || !spk || !wav) fail(ZVX_E_INVALID, "zvx_synthesize: NULL input");
+        const bool host_async = flags & ZVX_HOST_ASYNC;
+        if (!phoneme || !puncts || !T || !spk || (!wav && !host_async)) fail(ZVX_E_INVALID, "zvx_synthesize: NULL input");
+        if (host_async && ((mel_out && !(flags & ZVX_DEVICE_OUT)) || log_duration)) fail(ZVX_E_INVALID, "zvx_synthesize: ZVX_HOST_ASYNC takes no host mel / log_duration output (they would make the call wait)");
         auto front_end = [&] {
             run_encode(c, phoneme, puncts, duration, T, B, Tmax, spk, mel_len, Lmax_cap);
             if (log_duration) HIPCHK(hipMemcpyAsync(log_duration, c->fbuf("va.logd", 0), (size_t)B * Tmax * 4, hipMemcpyDeviceToHost, c->stream));
@@ -1979,7 +2042,7 @@ zvx_status zvx_synthesize(zvx_ctx* c, const int32_t* phoneme, const int32_t* pun
         };
         // a call that waits for its own result (no ZVX_NO_SYNC) has nothing to overlap with: it stays on the one stream (two streams
         // cost an event round trip, which a single short request would see); front_overlap 2 forces the two-stream schedule (tests)
-        if (c->front_overlap == 2 || (c->front_overlap == 1 && (flags & ZVX_NO_SYNC) && (flags & ZVX_DEVICE_OUT))) {
+        if (c->front_overlap == 2 || (c->front_overlap == 1 && (host_async || ((flags & ZVX_NO_SYNC) && (flags & ZVX_DEVICE_OUT))))) {
             // the front end on its own stream (see zvx_ctx::front_stream): ordered behind (1) whatever other entry points did to the
             // front-end buffers on the main stream, (2) the previous vocoder's read of the mel buffer -- and NOT behind that vocoder
             c->front_setup();
@@ -2042,6 +2105,19 @@ zvx_status zvx_fetch(zvx_ctx* c, const char* what, float* out, size_t out_floats
 }
 
 zvx_status zvx_sync(zvx_ctx* c) { return guarded(c, [&] { c->sync(); }); }
+
+zvx_status zvx_wait_host(zvx_ctx* c, int slot, const void** rows, int64_t* stride, int32_t* nrows, int64_t* valid) {
+    return guarded(c, [&] {
+        if (slot < 0 || slot > 1) fail(ZVX_E_INVALID, "zvx_wait_host: slot %d (0 or 1)", slot);
+        zvx_ctx::HostSlot& hs = c->host_slot[slot];
+        if (!hs.done || !hs.p) fail(ZVX_E_STATE, "zvx_wait_host: no ZVX_HOST_ASYNC call has used slot %d", slot);
+        if (hs.pending) { HIPCHK(hipEventSynchronize(hs.done)); hs.pending = false; }
+        if (rows) *rows = hs.p;
+        if (stride) *stride = hs.stride;
+        if (nrows) *nrows = hs.B;
+        if (valid) *valid = hs.need;
+    });
+}
 
 // ---- RCCL, resolved at run time ----------------------------------------------------------------------------------
 extern "C++" {

@@ -4,6 +4,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <atomic>
+#include <mutex>
+#include <set>
+#include <utility>
 
 namespace zvx {
 
@@ -18,10 +21,24 @@ inline int num_cus() {
     static const int n = [] { int dev = 0, v = 0; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256; return v; }();
     return n;
 }
-// CUs the PERSISTENT vocoder kernels size their grids for: num_cus(), or fewer when the context's main stream is confined to a CU mask
-// (zvx_create with ZVX_CU_SPLIT=n: the front stream owns n CUs, the main stream the rest -- an A/B experiment)
-inline std::atomic<int>& persistent_cus_override() { static std::atomic<int> v{0}; return v; }
-inline int persistent_cus() { const int o = persistent_cus_override().load(std::memory_order_relaxed); return o > 0 ? o : num_cus(); }
+// CUs the PERSISTENT kernels size their grids for (round 5's spatial split of the chip between the two streams -- ZVX_CU_SPLIT, a
+// process-wide override -- measured as a dead end and is gone: DESIGN.md section 4)
+inline int persistent_cus() { return num_cus(); }
+
+// Opt-in to more than 64 KiB of dynamic LDS for a kernel: hipFuncAttributeMaxDynamicSharedMemorySize is a PER-DEVICE attribute of the
+// function, so it is set once per (function, device) -- a second context on another device of the same process opts in again.
+// false when the runtime refuses (the launcher then declines the shape instead of launching into an error).
+inline bool lds_opt_in(const void* kfn) {
+    static std::mutex mu;
+    static std::set<std::pair<const void*, int>> done;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    std::lock_guard<std::mutex> lk(mu);
+    if (done.count({kfn, dev})) return true;
+    if (hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return false;
+    done.insert({kfn, dev});
+    return true;
+}
 
 enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_LRELU = 2, ACT_TANH = 3 };
 
@@ -293,6 +310,9 @@ void launch_copy_rows_f32(const void* src, int s_dt, int lds, long s_bs, float* 
 void launch_conv_post_tanh(const void* x, int x_dt, int ldx, long x_bs, const float* w /*[k][C]*/, float bias,
                            int ktaps, int C, void* wav, long wav_bs, int pcm16, int B, int Nmax, const int* in_len,
                            int len_mul, const int* out_len, int out_mul, hipStream_t s);
+// half-mode saturation audit: *count += number of elements of x[b][r < rows[b]][0:C] (16-bit, batch stride bs, row stride ld) whose
+// magnitude bits are >= 0x7BFF (+-65504 = a clamped store, or Inf / NaN)
+void launch_count_sat16(const void* x, long bs, int ld, int B, int rows_max, const int* rows, int C, unsigned long long* count, hipStream_t s);
 // x[b][r][0:C] = 0 for rows[b] <= r < rows_max
 void launch_zero_tail_rows(float* x, int ldx, int B, int rows_max, const int* rows, int C, hipStream_t s);
 
