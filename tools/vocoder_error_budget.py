@@ -63,3 +63,6 @@ if __name__ == "__main__":
         show(f"half up to stage {s - 1}, bf16 from stage {s}", ["f16"] * s + ["bf16"] * (ns + 1 - s))
     for s in range(0, ns + 1):
         show(f"only stage {s} in bf16, rest f32", ["f32"] * s + ["bf16"] + ["f32"] * (ns - s))
+    # round 6: the per-stage choice of zvx_set_int("voc_f16_stages", mask) -- bit k: domain k in half, else bf16
+    for mask in (0b11111, 0b11011, 0b11001, 0b10001, 0b11101, 0b11010, 0b00000):
+        show(f"voc_f16_stages = {mask:#07b} (bit k = domain k in half)", ["f16" if (mask >> k) & 1 else "bf16" for k in range(ns + 1)])

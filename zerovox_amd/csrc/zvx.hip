@@ -85,6 +85,7 @@ struct zvx_ctx {
     HostSlot host_slot[2];
     int host_next = 0, host_last = -1;
     hipStream_t copy_stream = nullptr;
+    bool copy_is_comm = false;
     hipStream_t aux_stream = nullptr;      // second compute stream: the duration predictor of a small batch beside the pitch predictor
     hipEvent_t ev_aux[2] = {nullptr, nullptr};
     int va_overlap_maxb = 1 << 20;             // zvx_set_int("va_overlap_maxb", n): batches of at most n utterances overlap the two predictors (0: never; A/B)
@@ -122,6 +123,7 @@ struct zvx_ctx {
     int norm_fuse_maxb = 1 << 20;          // zvx_set_int("norm_fuse_maxb", n): batches of at most n utterances may take the one-launch InstanceNorm of the StyleTTS decoder (0: never; A/B)
     int dec_sc_fuse = 1;                   // zvx_set_int("dec_sc_fuse", 0): the 1x1 shortcut of a StyleTTS residual block as its own launch (A/B; the fused form skips one 16-bit rounding of the conv2 result)
     int dec_flat = 1;                      // zvx_set_int("dec_flat", 0): the StyleTTS decoder's convolutions per utterance instead of batch-flattened (A/B, bit-identical)
+    int voc_f16_stages = 0x7fffffff;       // zvx_set_int("voc_f16_stages", mask): which domains of the generator (bit 0: mel / conv_pre, bit i: upsampling stage i) compute in IEEE half when voc_f16 is on; the others in bf16
     int voc_h16_ok = -1;                   // every contraction weight of the generator has an IEEE-half copy (decided on the first vocoder call)
     int voc_f16 = 1;                       // zvx_set_int("voc_f16", 0): the vocoder's activations / weights / running sum in bf16 instead of IEEE half (A/B; round 5)
     int dec_f16 = 1;                       // zvx_set_int("dec_f16", 0): StyleTTS decoder activations / weights in bf16 instead of IEEE half (A/B)
@@ -349,7 +351,7 @@ struct zvx_ctx {
         if (front_stream) HIPCHK(hipStreamSynchronize(front_stream));
         HIPCHK(hipStreamSynchronize(stream));
         if (comm_stream) HIPCHK(hipStreamSynchronize(comm_stream));
-        if (copy_stream) HIPCHK(hipStreamSynchronize(copy_stream));
+        if (copy_stream && !copy_is_comm) HIPCHK(hipStreamSynchronize(copy_stream));
         if (profile) resolve_events();
     }
     // error path of an API call: whatever it queued on a side stream before it threw is drained, so that the next call's main-stream
@@ -1181,10 +1183,16 @@ void run_vocoder(zvx_ctx* c, const float* mel, int ldm, int Lmel_max, const int*
         for (auto& kv : c->tensors)
             if (kv.first.rfind("voc.", 0) == 0 && kv.second.kind == 'w' && kv.second.dims.size() == 3 && !c->has(kv.first + ".h16")) c->voc_h16_ok = 0;
     }
-    const int dt = (c->dt == DT_BF16 && c->voc_f16 && c->voc_h16_ok == 1 && c->has("voc.pre_w.h16")) ? DT_F16 : c->dt, nm = c->n_mels;
-    const bool h16 = dt == DT_F16;
-    auto vt = [&](const std::string& n) -> const Tensor& { return c->t(h16 ? n + ".h16" : n); };      // a contraction weight in the vocoder's dtype
-    const size_t es = dtype_size(dt);
+    const bool half_ok = c->dt == DT_BF16 && c->voc_f16 && c->voc_h16_ok == 1 && c->has("voc.pre_w.h16");
+    const int nm = c->n_mels;
+    // The 16-bit arithmetic is chosen PER STAGE (round 6; zvx_set_int("voc_f16_stages", mask)): domain 0 = the padded mel, conv_pre and its
+    // output; domain i = everything of upsampling stage i (the ConvTranspose's OUTPUT, the ResBlocks' tensors, weights and running sum, the
+    // stage's result).  A ConvTranspose reads domain i - 1 with that domain's weights and writes domain i (the run-time epilogue converts:
+    // one rounding either way).  Bit k of the mask: domain k in IEEE half, else bf16.
+    auto dom = [&](int k) -> int { return (half_ok && ((c->voc_f16_stages >> k) & 1)) ? (int)DT_F16 : c->dt; };
+    auto vtd = [&](const std::string& n, int d) -> const Tensor& { return c->t(d == DT_F16 ? n + ".h16" : n); };      // a contraction weight in a domain's dtype
+    const size_t es = dtype_size(c->dt);
+    int dt = dom(0);                                                  // the domain of the launches being issued
     int Pmax = 0; for (int b = 0; b < B; b++) Pmax = std::max(Pmax, P_host[b]);
     if (Pmax <= 0) return;
     const int ns = (int)c->voc_rates.size(), nk = (int)c->voc_rb_k.size();
@@ -1226,7 +1234,7 @@ void run_vocoder(zvx_ctx* c, const float* mel, int ldm, int Lmel_max, const int*
     }
     {   // conv_pre, stored as leaky_relu(x, 0.1) (its only consumer, hifigan.py:115-117)
         GemmArgs a = gemm_base(dt);
-        a.X = vin; a.x_bs = (long)Pmax * nm; a.ldx = nm; a.W = vt("voc.pre_w").dev; a.ldw = nm; a.w_ts = (long)c->voc_c0 * nm;
+        a.X = vin; a.x_bs = (long)Pmax * nm; a.ldx = nm; a.W = vtd("voc.pre_w", dt).dev; a.ldw = nm; a.w_ts = (long)c->voc_c0 * nm;
         a.M = Pmax; a.N = c->voc_c0; a.K = nm; a.nbatch = B; a.in_len = P_d; a.out_len = P_d;
         set_taps_1d(a, c->t("voc.pre_w").dim(0), 1);
         a.bias = c->pf("voc.pre_b"); a.bias_mode = 1; a.act = ACT_LRELU; a.slope = 0.1f;
@@ -1239,26 +1247,31 @@ void run_vocoder(zvx_ctx* c, const float* mel, int ldm, int Lmel_max, const int*
         const int rows_in = Pmax * mul, rows = rows_in * u;
         const int* len_in = lens_d + (size_t)(i + 1) * B; const int* len = lens_d + (size_t)(i + 2) * B;
         c->tag = "voc.up" + std::to_string(i + 1);
+        const int dt_in = dom(i);
+        dt = dom(i + 1);
+        const bool h16 = dt == DT_F16;
+        auto vt = [&](const std::string& n) -> const Tensor& { return vtd(n, dt); };                // a contraction weight in this stage's dtype
         {   // ConvTranspose1d as a polyphase GEMM: out[t][ph*Cout+co]                  hifigan.py:118
             const std::string up = "voc.up" + std::to_string(i);
-            GemmArgs a = gemm_base(dt);
+            GemmArgs a = gemm_base(dt_in);
+            a.out_dtype = dt;
             a.X = A; a.x_bs = (long)rows_in * Cin; a.ldx = Cin; a.ldw = Cin;
             a.M = rows_in; a.K = Cin; a.nbatch = B; a.in_len = len_in; a.out_len = len_in;
             a.bias_mode = 1; a.act = ACT_LRELU; a.slope = 0.1f;
             a.o_bs = (long)rows_in * u * Cout; a.ldo = u * Cout;
-            if (dt != DT_F32 && c->has(up + "_wlo")) {
+            if (dt_in != DT_F32 && c->has(up + "_wlo")) {
                 // k = 2u: two 2-tap GEMMs over half the phases each (rows t-1, t / rows t, t+1) instead of one 3-tap GEMM
                 const int hc = (u / 2) * Cout;
                 a.N = hc; a.ntaps = 2; a.w_ts = (long)hc * Cin; a.flops = 2.0 * B * (double)rows_in * Cin * Cout * ku / 2;
-                a.W = vt(up + "_wlo").dev; a.dv[0] = -1; a.dv[1] = 0;
+                a.W = vtd(up + "_wlo", dt_in).dev; a.dv[0] = -1; a.dv[1] = 0;
                 a.bias = c->pf(up + "_b"); a.out = X0;
                 c->gemm(a);
                 a.Wp = nullptr;
-                a.W = vt(up + "_whi").dev; a.dv[0] = 0; a.dv[1] = 1;
+                a.W = vtd(up + "_whi", dt_in).dev; a.dv[0] = 0; a.dv[1] = 1;
                 a.bias = c->pf(up + "_b") + hc; a.out = (char*)X0 + (size_t)hc * es;
                 c->gemm(a);
             } else {
-                a.W = vt(up + "_w").dev; a.w_ts = (long)u * Cout * Cin; a.N = u * Cout;
+                a.W = vtd(up + "_w", dt_in).dev; a.w_ts = (long)u * Cout * Cin; a.N = u * Cout;
                 a.ntaps = 3; a.dv[0] = -1; a.dv[1] = 0; a.dv[2] = 1;
                 a.bias = c->pf(up + "_b"); a.out = X0;
                 a.flops = 2.0 * B * (double)rows_in * Cin * Cout * ku;
@@ -1503,6 +1516,7 @@ void run_vocoder(zvx_ctx* c, const float* mel, int ldm, int Lmel_max, const int*
     }
     // conv_post + tanh on the first mel_len*hop samples            hifigan.py:127-128, model.py:347
     c->tag = "voc.post";
+    dt = dom(ns);
     {
         double nout = 0; for (int b = 0; b < B; b++) nout += (double)mel_len_host[b] * c->hop;
         // rows are zero-filled up to max_b(mel_len) * hop, the extent include/zvx.h promises (and the caller's wav_stride covers):
@@ -1746,7 +1760,11 @@ void do_vocode(zvx_ctx* c, const int32_t* pad_to, void* wav, int64_t wav_stride,
         // per slot as well, so this vocoder's conv_post never writes what the previous call's copy is still reading
         const int slot = c->host_next; c->host_next ^= 1; c->host_last = slot;
         hs = &c->host_slot[slot];
-        if (!c->copy_stream) HIPCHK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+        // The copies ride the communication stream where the context has one (world 1: it is idle; a multi-GPU rank gathers on the device
+        // instead of delivering to its host): the runtime maps streams onto FOUR hardware queues by default (GPU_MAX_HW_QUEUES), and the
+        // context's main / front / predictor / communication streams are four -- a fifth stream shares a queue with one of them, and its
+        // wait-for-the-vocoder barrier then holds up that stream's launches too (measured: the whole front-end overlap lost, +1.2 ms)
+        if (!c->copy_stream) { if (c->comm_stream) { c->copy_stream = c->comm_stream; c->copy_is_comm = true; } else HIPCHK(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking)); }
         if (!hs->ready) { HIPCHK(hipEventCreateWithFlags(&hs->ready, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&hs->done, hipEventDisableTiming)); }
         if (hs->pending) { HIPCHK(hipEventSynchronize(hs->done)); hs->pending = false; }
         wstride = (std::max(need, 1) + 7) & ~7;
@@ -1845,7 +1863,7 @@ void zvx_destroy(zvx_ctx* c) {
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     zvx_comm_destroy(c);
     for (int i = 0; i < 2; i++) { if (c->arena[i].p) (void)hipHostFree(c->arena[i].p); if (c->arena[i].ev) (void)hipEventDestroy(c->arena[i].ev); }
-    if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
+    if (c->copy_stream && !c->copy_is_comm) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
     for (auto& hs : c->host_slot) { if (hs.p) (void)hipHostFree(hs.p); if (hs.ready) (void)hipEventDestroy(hs.ready); if (hs.done) (void)hipEventDestroy(hs.done); }
     for (int i = 0; i < 2; i++) if (c->voc_aux[i]) { (void)hipStreamSynchronize(c->voc_aux[i]); (void)hipStreamDestroy(c->voc_aux[i]); }
     for (int i = 0; i < 3; i++) if (c->voc_ev[i]) (void)hipEventDestroy(c->voc_ev[i]);
@@ -1905,6 +1923,7 @@ zvx_status zvx_set_int(zvx_ctx* c, const char* key, int64_t value) {
         else if (std::string(key) == "attn_f32") c->use_attn_f32 = (int)value;
         else if (std::string(key) == "dec_f16") c->dec_f16 = (int)value;
         else if (std::string(key) == "voc_f16") c->voc_f16 = (int)value;
+        else if (std::string(key) == "voc_f16_stages") c->voc_f16_stages = (int)value;
         else if (std::string(key) == "stagefuse") c->use_stagefuse = (int)value;
         else if (std::string(key) == "f16_sat_check") {       // (re)arms the audit and zeroes its counter
             c->sync(); c->sat_check = value ? 1 : 0;
@@ -2279,6 +2298,7 @@ void zvx_comm_destroy(zvx_ctx* c) {
     for (auto& kv : c->gather_fence) if (kv.second) (void)hipEventDestroy(kv.second);
     c->gather_fence.clear();
     if (c->ev_compute) { (void)hipEventDestroy(c->ev_compute); c->ev_compute = nullptr; }
+    if (c->copy_is_comm) { c->copy_stream = nullptr; c->copy_is_comm = false; }      // (host deliveries rode this stream: the next one creates its own)
     if (c->comm_stream) { (void)hipStreamDestroy(c->comm_stream); c->comm_stream = nullptr; }
     c->world = 1; c->rank = 0;
 }
