@@ -375,7 +375,9 @@ def main(argv=None, ctx_factory=default_ctx_factory):
                                             "IEEE half weights + activations on the f16 MFMA (log-mel within 2e-2 of the f32 reference)"),
                      "vocoder_arithmetic": ("f32" if args.precision == "f32" else
                                             ("bf16 weights + activations + running sum (rounds 1-4; A/B: --set voc_f16=0)" if overrides.get("voc_f16", 1) == 0 else
-                                             "IEEE half weights + activations + running sum on the f16 MFMA, saturating stores (round 5 default: waveform error 8x below bf16's, ~3 % more time at the board's power limit)")),
+                                             ("per-stage mask --set voc_f16_stages (bit k: domain k in IEEE half, else bf16)" if "voc_f16_stages" in overrides else
+                                              "IEEE half weights + activations + running sum (saturating stores) everywhere except the 128-channel ResBlock1 stage, which runs in bf16 "
+                                              "(round 6: the f16 multiplier array's extra power costs that stage 0.3 ms of the 0.8-1.0 ms an all-half generator costs; ab_vocoder_arithmetic has all three)"))),
                      "wav_delivery": ("host (synchronous D2H copy of every step's waveform inside the timed region: every call waits)" if (args.host_out and args.host_out_sync) else
                                       "host (ZVX_HOST_ASYNC: every step's waveform lands in a pinned host slot via the context's copy stream inside the timed region; "
                                       "the host takes step i's rows while step i+1 runs)") if args.host_out else
@@ -454,24 +456,30 @@ def main(argv=None, ctx_factory=default_ctx_factory):
     # IEEE half (8x less rounding noise in the waveform); the bf16 kernels of rounds 1-4 stay behind zvx_set_int("voc_f16", 0) and are
     # ~4-5 % faster at the board's power limit.  Untimed for the line's `value`; reported beside it so that one run carries both figures.
     voc_ab = None
-    if world == 1 and args.config in (2, 4) and args.precision == "bf16" and "voc_f16" not in overrides and not args.host_out and args.in_flight <= 1 \
-            and not os.environ.get("ZVX_BENCH_NO_AB") and args.steps >= 10:
+    if world == 1 and args.config in (2, 4) and args.precision == "bf16" and "voc_f16" not in overrides and "voc_f16_stages" not in overrides \
+            and not args.host_out and args.in_flight <= 1 and not os.environ.get("ZVX_BENCH_NO_AB") and args.steps >= 10:
+        # measured error of each choice at the headline shape (tools/ab_voc_stages.py, profiles/r06_ab_voc_stages.txt): waveform error against
+        # the f32 oracle end to end / the generator alone, max | rms
+        notes = {"all_bf16": ("voc_f16", 0, "bf16 everywhere (rounds 1-4): 7.3e-3 | 1.36e-3 end to end, 6.7e-3 | 1.33e-3 alone"),
+                 "all_half": ("voc_f16_stages", 31, "IEEE half everywhere (round 5's default): 1.64e-3 | 3.1e-4 end to end, 1.02e-3 | 1.7e-4 alone")}
+        voc_ab = {"default": "IEEE half everywhere except the 128-channel ResBlock1 stage (the pair kernel: 43 % of the generator's matrix work) in bf16: "
+                             "3.55e-3 | 6.6e-4 end to end, 3.33e-3 | 6.1e-4 alone (SURVEY 8c allows 1e-2 | 2e-3)"}
         try:
-            ctx.set_int("voc_f16", 0)
-            for _ in range(3):
-                step()
-            fence()
-            n_ab = min(args.steps, 40)
-            t1 = time.perf_counter()
-            for _ in range(n_ab):
-                step()
-            fence()
-            dt_ab = time.perf_counter() - t1
-            voc_ab = {"set": "voc_f16=0", "steps": n_ab, "ms_per_step": 1e3 * dt_ab / n_ab, "value": units_per_step * n_ab / dt_ab,
-                      "note": "same process, same box, right behind the timed region: the bf16 vocoder kernels of rounds 1-4 (waveform error vs the f32 reference "
-                              "<= 8.5e-3 / 1.9e-3 rms end to end; the default's: <= 2.0e-3 / 4.2e-4)"}
+            for name, (key, val, note) in notes.items():
+                ctx.set_int(key, val)
+                for _ in range(3):
+                    step()
+                fence()
+                n_ab = min(args.steps, 40)
+                t1 = time.perf_counter()
+                for _ in range(n_ab):
+                    step()
+                fence()
+                dt_ab = time.perf_counter() - t1
+                voc_ab[name] = {"set": f"{key}={val}", "steps": n_ab, "ms_per_step": 1e3 * dt_ab / n_ab, "value": units_per_step * n_ab / dt_ab, "wav_err_max_rms": note}
+                ctx.set_int("voc_f16", 1); ctx.set_int("voc_f16_stages", -1)
         finally:
-            ctx.set_int("voc_f16", 1)
+            ctx.set_int("voc_f16", 1); ctx.set_int("voc_f16_stages", -1)
             step(); fence()                           # (back on the default kernels before anything else runs)
     # a timed region shorter than an external sampler's period (amd-smi at 1-5 s) would read as "GPU idle": keep the chip busy for >= 6 s
     # more, OUTSIDE the timed region and before the CPU baseline (VERDICT r4 #8d, r5 #6b: 2 s was still shorter than a 5 s sampler); the
@@ -536,7 +544,11 @@ def main(argv=None, ctx_factory=default_ctx_factory):
     elif args.config == 5:
         dtype_name = "bf16"
     else:
-        dtype_name = "bf16" if overrides.get("voc_f16", 1) == 0 else "f16"
+        # the generator's arithmetic is chosen per stage (zvx_set_int voc_f16_stages): by default IEEE half everywhere except V1's 128-channel
+        # stage, whose pair kernel -- the step's dominant kernel -- runs in bf16; both are 16-bit MFMA types of the same rate
+        mask = overrides.get("voc_f16_stages", -1)
+        mixed = args.vocoder == "v1" and mask < 0
+        dtype_name = "bf16" if overrides.get("voc_f16", 1) == 0 or mask == 0 else ("f16+bf16" if (mixed or (0 < mask < 31 and mask & 31 != 31)) else "f16")
     if rank == 0:
         total = float(world) * units_per_step * args.steps
         value = total / elapsed
@@ -556,7 +568,9 @@ def main(argv=None, ctx_factory=default_ctx_factory):
         if f32_mode is not None:
             res["f32_mode"] = f32_mode
         if voc_ab is not None:
-            res["ab_voc_bf16"] = voc_ab
+            res["ab_vocoder_arithmetic"] = voc_ab         # same process, same box, right behind the timed region: the two uniform choices beside the default
+            if "all_bf16" in voc_ab:
+                res["ab_voc_bf16"] = voc_ab["all_bf16"]   # (the round-5 key, kept for readers of earlier lines)
         if stage_ms_alone is not None:
             # stage_ms_last_step are event pairs on the stream a stage runs on: with the front end of step i+1 queued under the vocoder of
             # step i (config.front_overlap) the encoder / decoder figures are WALL times of work that waits for free CUs most of the time;

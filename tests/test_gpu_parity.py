@@ -46,8 +46,12 @@ def voc_sd(name):
     return _sd[name]
 
 
+_last_voc = [None]                                       # the generator of the context a test last asked for (check_wav picks its limits by it)
+
+
 def ctx_for(kind, voc, prec):
     key = (kind, voc, prec)
+    _last_voc[0] = voc
     if key not in _ctx:
         if len(_ctx) >= 4:                                # keep device memory bounded
             k0 = next(iter(_ctx))
@@ -101,17 +105,24 @@ def check_embed16(e, ref, what):
     assert cos >= 0.9999 and mx <= 2.5e-3, f"{what}: cosine {cos:.6f}, max err {mx:.3e}"
 
 
-def check_wav(a, b, prec, what, e2e=True):
-    """16-bit mode (round 5: the vocoder's tensors are IEEE half).  SURVEY 8c's waveform bound is 1e-2 abs / 2e-3 rms; the limits here are
-    what the half vocoder measures, with 2x margin: end to end 4e-3 abs / 8e-4 rms (measured over every fixture and the headline shape:
-    <= 1.97e-3 / 4.2e-4), the vocoder alone 2e-3 / 4e-4 (measured <= 9.8e-4 / 1.6e-4).  With the bf16 vocoder of rounds 1-4
-    (zvx_set_int("voc_f16", 0)) the same comparisons read <= 8.5e-3 / 1.9e-3 and <= 6.3e-3 / 1.3e-3."""
+def check_wav(a, b, prec, what, e2e=True, voc=None):
+    """16-bit mode.  SURVEY 8c's waveform bound is 1e-2 abs / 2e-3 rms.  The generator's arithmetic is chosen per stage (round 6,
+    zvx_set_int("voc_f16_stages")): IEEE half everywhere except a ResBlock1 stage of 128 channels -- HiFi-GAN V1's stage 2, the pair kernel,
+    43 % of the generator's matrix work for 1/5 of its error budget -- which runs in bf16.  Limits = what that measures, with ~1.5x margin:
+      V1 (voc "v1"):             end to end 6e-3 / 1.2e-3 (measured at the headline shape 3.55e-3 / 6.6e-4), the vocoder alone 5e-3 / 9e-4 (3.33e-3 / 6.1e-4);
+      every other generator (all of it in half): end to end 4e-3 / 8e-4 (measured <= 1.97e-3 / 4.2e-4), alone 2e-3 / 4e-4 (<= 9.8e-4 / 1.6e-4).
+    V1 all in half (voc_f16_stages 31) measures 1.64e-3 / 3.1e-4 and 1.02e-3 / 1.7e-4 (test_vocoder_in_ieee_half...), all in bf16
+    (voc_f16 0) 7.3e-3 / 1.36e-3 and 6.7e-3 / 1.33e-3.  voc: the generator's name (default: the one of the last ctx_for call)."""
     if prec == "f32":
         return check_f32(a, b, what)
     mx, rms, _, _ = stats(a, b)
     _errlog("wav-e2e" if e2e else "wav-voc", what, mx, rms)
-    lim_mx, lim_rms = (4e-3, 8e-4) if e2e else (2e-3, 4e-4)
-    assert mx <= lim_mx and rms <= lim_rms, f"{what}: wav err max {mx:.3e} rms {rms:.3e}"
+    mixed = (voc if voc is not None else _last_voc[0]) == "v1"
+    if mixed:
+        lim_mx, lim_rms = (6e-3, 1.2e-3) if e2e else (5e-3, 9e-4)
+    else:
+        lim_mx, lim_rms = (4e-3, 8e-4) if e2e else (2e-3, 4e-4)
+    assert mx <= lim_mx and rms <= lim_rms, f"{what}: wav err max {mx:.3e} rms {rms:.3e} (limits {lim_mx:.0e} / {lim_rms:.0e})"
 
 
 E2E = ["e2e_styletts_tiny_T8", "e2e_fs2_tiny_T8", "e2e_styletts_tiny_T16_pred", "e2e_fs2_tiny_T16_pred",
@@ -1071,8 +1082,6 @@ def test_streaming_pair_kernel_equals_two_conv_slab_launches():
             assert np.isfinite(got).all() and np.array_equal(got, ref), (B, Pmax)
             ctx.set_int("pairstream", 1); got = ctx.vocode_mel(mel, P)        # default: streamed from ~200 k rows up ((9, 420) is), two launches below
             assert np.isfinite(got).all() and np.array_equal(got, ref), (B, Pmax)
-            ctx.set_int("pairstream", 2); alt = ctx.vocode_mel(mel, P)        # k = 3 on the register-resident kernel (running sum added after bf16 rounding)
-            assert np.isfinite(alt).all() and np.abs(alt - ref).max() < 2e-2, (B, Pmax)
     finally:
         ctx.set_int("pairstream", 1)
 
@@ -1226,23 +1235,30 @@ def test_config4_hifigan_v1_alone_1024_frames():
 
 
 def test_vocoder_in_ieee_half_against_bf16_and_the_oracle():
-    """Round 5: the vocoder's 16-bit tensors are IEEE half (zvx_set_int("voc_f16", 1), the default); voc_f16 = 0 runs the bf16 kernels of
-    rounds 1-4 on the same context.  On a 256-frame N(0,1) mel both must meet the oracle, and half must be at least 3x closer (measured
-    ~8x: 11 significand bits against 8)."""
+    """The generator's 16-bit arithmetic per stage: voc_f16 = 0 runs the bf16 kernels of rounds 1-4 everywhere, voc_f16_stages = 31 IEEE half
+    everywhere (round 5), the default (voc_f16_stages -1) half everywhere but V1's 128-channel stage (round 6).  On a 256-frame N(0,1) mel all
+    three meet the oracle within their own limits; all-half is at least 3x closer than all-bf16 (measured ~8x: 11 significand bits against
+    8), the default sits between the two and at least 1.5x closer than all-bf16."""
     h, hsd = voc_sd("v1")
     ctx = ctx_for("styletts", "v1", "bf16")
     mel = np.random.default_rng(21).standard_normal((256, 80)).astype(np.float32)
     ref = O.hifigan_generator(mel.T, hsd, h)
+    P1 = np.array([256], np.int32)
     try:
-        ctx.set_int("voc_f16", 0); wb = ctx.vocode_mel(mel[None], np.array([256], np.int32))[0]
-        ctx.set_int("voc_f16", 1); wh = ctx.vocode_mel(mel[None], np.array([256], np.int32))[0]
+        ctx.set_int("voc_f16", 0); wb = ctx.vocode_mel(mel[None], P1)[0]
+        ctx.set_int("voc_f16", 1); ctx.set_int("voc_f16_stages", 31); wh = ctx.vocode_mel(mel[None], P1)[0]
+        ctx.set_int("voc_f16_stages", 0b11011); wm = ctx.vocode_mel(mel[None], P1)[0]
+        ctx.set_int("voc_f16_stages", -1); wd = ctx.vocode_mel(mel[None], P1)[0]
     finally:
-        ctx.set_int("voc_f16", 1)
-    eb, eh = stats(wb, ref), stats(wh, ref)
-    _errlog("wav-voc", "voc_f16 A/B bf16", eb[0], eb[1]); _errlog("wav-voc", "voc_f16 A/B half", eh[0], eh[1])
+        ctx.set_int("voc_f16", 1); ctx.set_int("voc_f16_stages", -1)
+    assert np.array_equal(wd, wm)                        # the default IS "all but stage 2" on this generator
+    eb, eh, em = stats(wb, ref), stats(wh, ref), stats(wd, ref)
+    _errlog("wav-voc", "voc_f16 A/B bf16", eb[0], eb[1]); _errlog("wav-voc", "voc_f16 A/B half", eh[0], eh[1]); _errlog("wav-voc", "voc_f16 A/B default", em[0], em[1])
     assert eb[0] <= 1e-2 and eb[1] <= 2e-3, f"bf16 vocoder: {eb[:2]}"
-    check_wav(wh, ref, "bf16", "half vocoder", e2e=False)
+    check_wav(wh, ref, "bf16", "half vocoder", e2e=False, voc="all-half")
+    check_wav(wd, ref, "bf16", "default vocoder", e2e=False)
     assert eh[1] * 3 <= eb[1], f"half rms {eh[1]:.3e} is not 3x below bf16 rms {eb[1]:.3e}"
+    assert eh[1] <= em[1] and em[1] * 1.5 <= eb[1], f"default rms {em[1]:.3e} (half {eh[1]:.3e}, bf16 {eb[1]:.3e})"
 
 
 @pytest.mark.parametrize("voc", ["v1", "v2", "v3"])
@@ -1498,7 +1514,7 @@ def test_reference_written_checkpoint_reproduces_the_reference_output(prec, tmp_
             assert ml == int(g[tag + "_mel_len"]), f"{tag}: mel_len {ml} != {int(g[tag + '_mel_len'])}"
             check_f32(logd[0], g[tag + "_log_duration"], f"{tag}: log_duration")
             check_mel(mel.T, g[tag + "_mel"].T, prec, f"{tag}: mel", "styletts")
-            check_wav(wav, g[tag + "_wav"], prec, f"{tag}: wav")
+            check_wav(wav, g[tag + "_wav"], prec, f"{tag}: wav", voc="tiny3")
             outs.append(wav)
         synth._model.close()
     assert np.array_equal(outs[0], outs[2]) and np.array_equal(outs[1], outs[3])             # converted directory == reference layout read directly

@@ -30,8 +30,24 @@
 
 // Per-launch timing without marker packets: when the caller has armed a pair of events (gemm_profile_events), the
 // dispatch itself carries them (hipExtLaunchKernelGGL start/stop events = the kernel's own begin/end timestamps).
-static thread_local hipEvent_t g_ev_start = nullptr, g_ev_stop = nullptr;
-static thread_local bool g_dry_run = false;     // gemm_variant_of(): walk the launcher's decisions without dispatching
+// (gemm.hip is compiled as TWO translation units -- zerovox_amd/build.py: -DZVX_GEMM_PART=1 = everything but the fused ResBlock-pair kernels,
+// -DZVX_GEMM_PART=2 = those kernels and launch_resfuse() -- so that a clean build takes the time of the larger half; no macro: one unit)
+#ifndef ZVX_GEMM_PART
+#define ZVX_GEMM_PART 0
+#endif
+#define ZVX_PART_MAIN (ZVX_GEMM_PART != 2)
+#define ZVX_PART_RESFUSE (ZVX_GEMM_PART != 1)
+#if ZVX_GEMM_PART == 2
+extern thread_local hipEvent_t zvx_gemm_ev_start, zvx_gemm_ev_stop;
+extern thread_local bool zvx_gemm_dry_run;
+#else
+thread_local hipEvent_t zvx_gemm_ev_start = nullptr, zvx_gemm_ev_stop = nullptr;
+thread_local bool zvx_gemm_dry_run = false;     // gemm_variant_of(): walk the launcher's decisions without dispatching
+#endif
+#define g_ev_start zvx_gemm_ev_start
+#define g_ev_stop zvx_gemm_ev_stop
+#define g_dry_run zvx_gemm_dry_run
+
 #define ZVX_LAUNCH(kernel, grid, block, lds, stream, ...) \
     do { if (g_dry_run) break; \
          if (g_ev_start) hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, g_ev_start, g_ev_stop, 0, __VA_ARGS__); \
@@ -562,6 +578,7 @@ __device__ __forceinline__ void epilogue_direct(const GemmArgs& a, f32x16 (&acc)
         }
 }
 
+#if ZVX_PART_MAIN
 // ================================================================================================
 // conv-slab kernel: bf16 1-D convolutions / linears against STATIC weights.
 //
@@ -1361,6 +1378,8 @@ static bool launch_convreg_c(const GemmArgs& a, hipStream_t stream) {
     return false;
 }
 
+#endif  // ZVX_PART_MAIN
+#if ZVX_PART_RESFUSE
 // ================================================================================================
 // resfuse kernel: one HiFi-GAN ResBlock1 iteration (hifigan.py:51-55) in a single launch for C = 32 / 64:
 //     xt = lrelu(conv1_dilated(lrelu(x)) + b1)  -> stays in LDS (bf16)  ->  x' = conv2(xt) + b2 + x
@@ -1832,10 +1851,8 @@ static bool launch_resfuse_persist_c(const GemmArgs& a, hipStream_t stream) {
         if (a.ntaps == 11) { ZVX_RFP_MODE(11) }
     } else {
         if (a.ntaps == 3) { ZVX_RFP_MODE(3) }
-        if constexpr (C != 128) {                          // C = 128: only k = 3 keeps its 24 fragments per wave resident
-            if (a.ntaps == 7) { ZVX_RFP_MODE(7) }
-            if constexpr (C <= 32) { if (a.ntaps == 11) { ZVX_RFP_MODE(11) } }
-        }
+        if (a.ntaps == 7) { ZVX_RFP_MODE(7) }
+        if constexpr (C <= 32) { if (a.ntaps == 11) { ZVX_RFP_MODE(11) } }
     }
 #undef ZVX_RFP_MODE
 #undef ZVX_RFP
@@ -1899,14 +1916,16 @@ int launch_resfuse(GemmArgs a, hipStream_t stream) {
         // C = 64, k = 11 (44 fragments = 176 registers per wave): one 32-row block per wave, 36 fragments resident and 8
         // re-read from L2 per tile, register-lean epilogue -- 0.85 ms against 0.95 ms for the per-tile kernel
         if (a.N == 64 && a.ntaps == 11 && launch_resfuse_persist_c<64, 1>(a, stream)) return 17;
-        if (a.N == 128 && a.ntaps == 3 && launch_resfuse_persist_c<128>(a, stream)) return 13;      // 24 fragments per wave: resident
-        if (a.N == 16 && launch_resfuse_persist_c<16>(a, stream)) return 12;
-        if (a.N == 8 && launch_resfuse_persist_c<8>(a, stream)) return 11;
+        // (round 6: the C = 128 / 16 / 8 instantiations of this kernel are gone -- C = 128 pairs run on pairstream.hip or as the two conv-slab
+        // launches it is bit-identical to, C = 16 / 8 stages on narrowstage.hip or, where that declines, as two launches per pair: 84 fewer
+        // instantiations, none of them on a default path since round 5)
     }
     if (a.N == 32 && launch_resfuse_c<32, 256, 4, 1, 2>(a, stream)) return 16;
     if (a.N == 64 && launch_resfuse_c<64, 128, 2, 2, 2>(a, stream)) return 17;
     return -1;
 }
+#endif  // ZVX_PART_RESFUSE
+#if ZVX_PART_MAIN
 
 struct Variant { const char* name; int dt, bm, bn; };
 static const Variant kVariants[] = {
@@ -2260,4 +2279,5 @@ int gemm_variant_of(const GemmArgs& a) {
     return id;
 }
 
+#endif  // ZVX_PART_MAIN
 }  // namespace zvx

@@ -123,7 +123,7 @@ struct zvx_ctx {
     int norm_fuse_maxb = 1 << 20;          // zvx_set_int("norm_fuse_maxb", n): batches of at most n utterances may take the one-launch InstanceNorm of the StyleTTS decoder (0: never; A/B)
     int dec_sc_fuse = 1;                   // zvx_set_int("dec_sc_fuse", 0): the 1x1 shortcut of a StyleTTS residual block as its own launch (A/B; the fused form skips one 16-bit rounding of the conv2 result)
     int dec_flat = 1;                      // zvx_set_int("dec_flat", 0): the StyleTTS decoder's convolutions per utterance instead of batch-flattened (A/B, bit-identical)
-    int voc_f16_stages = 0x7fffffff;       // zvx_set_int("voc_f16_stages", mask): which domains of the generator (bit 0: mel / conv_pre, bit i: upsampling stage i) compute in IEEE half when voc_f16 is on; the others in bf16
+    int voc_f16_stages = -1;               // zvx_set_int("voc_f16_stages", mask): which domains of the generator (bit 0: mel / conv_pre, bit i: upsampling stage i) compute in IEEE half when voc_f16 is on, the others in bf16; -1 (default): all but a 128-channel ResBlock1 stage
     int voc_h16_ok = -1;                   // every contraction weight of the generator has an IEEE-half copy (decided on the first vocoder call)
     int voc_f16 = 1;                       // zvx_set_int("voc_f16", 0): the vocoder's activations / weights / running sum in bf16 instead of IEEE half (A/B; round 5)
     int dec_f16 = 1;                       // zvx_set_int("dec_f16", 0): StyleTTS decoder activations / weights in bf16 instead of IEEE half (A/B)
@@ -133,6 +133,7 @@ struct zvx_ctx {
     int use_resstream = 1;                 // zvx_set_int("resstream", 0): ResBlocks of the narrow stages as per-pair launches (A/B, bit-equal)
     int rs_seg_min = 0;                    // zvx_set_int("rs_seg_min", -1): streaming ResBlock segments never shorter than 2048 rows (A/B of the single-request sizing)
     int rs_opt = 3;                        // zvx_set_int("rs_opt", v): StreamArgs.opt of the streaming ResBlock kernels (bit 0: staggered wave priorities)
+    int spk_chunk = 0;                     // zvx_set_int("spk_chunk", n): speaker-encoder batches larger than n clips run as sub-batches of n (0: whole batch)
     int spk_s2_fuse = 1;                   // zvx_set_int("spk_s2_fuse", 0): the level transitions as two launches of the gathered-row GEMM (A/B)
     int spk_pool_fuse = 1;                 // zvx_set_int("spk_pool_fuse", 0): the speaker encoder's SE pool as its own pass everywhere (A/B)
     int slab_small = 2, slab_flat = 1;     // zvx_set_int("slab_small" / "slab_flat", v): conv-slab tile choice for single requests / whole-grid XCD remap (A/B; per context)
@@ -149,7 +150,7 @@ struct zvx_ctx {
     int use_stagefuse = 1;                 // zvx_set_int("stagefuse", 0): narrow vocoder stages (C = 16 / 8) as per-pair launches instead of ONE launch per stage (narrowstage.hip; A/B)
     struct NsWeights { void* W = nullptr; float* bias = nullptr; int woff[18] = {0}; };
     std::map<std::string, NsWeights> ns_weights;   // narrowstage.hip fragment order, per (stage, dtype), built on first use
-    int use_pairstream = 1;                // zvx_set_int("pairstream", v): C = 128 ResBlock pairs on pairstream.hip: 1 = every k (default; jobs under ~200 k rows run the bit-identical two-launch path), 3 = every k and every job size (tests), 4 = like 3 with 256-row segments for small jobs, 2 = k >= 7 only (k = 3 on the register-resident resfuse kernel, which adds the running sum after rounding to bf16), 0 = none, -1 = no fused kernel at all for C = 128 (two conv-slab launches per pair: the bit-equality reference)
+    int use_pairstream = 1;                // zvx_set_int("pairstream", v): C = 128 ResBlock pairs on pairstream.hip: 1 = every k (default; jobs under ~200 k rows run the bit-identical two-launch path), 3 = every k and every job size (tests), 4 = like 3 with 256-row segments for small jobs, <= 0 = two conv-slab launches per pair (the bit-equality reference)
     int shape_log = 0;                     // zvx_set_int("shape_log", 1): one stderr line per timed launch (profile 2)
     int max_frames = 1 << 18;              // hard cap on a predicted mel length (guards the allocation, fs2.py:678-681 has none)
     hipEvent_t stage_ev[ZVX_T_COUNT][2];
@@ -1189,7 +1190,16 @@ void run_vocoder(zvx_ctx* c, const float* mel, int ldm, int Lmel_max, const int*
     // output; domain i = everything of upsampling stage i (the ConvTranspose's OUTPUT, the ResBlocks' tensors, weights and running sum, the
     // stage's result).  A ConvTranspose reads domain i - 1 with that domain's weights and writes domain i (the run-time epilogue converts:
     // one rounding either way).  Bit k of the mask: domain k in IEEE half, else bf16.
-    auto dom = [&](int k) -> int { return (half_ok && ((c->voc_f16_stages >> k) & 1)) ? (int)DT_F16 : c->dt; };
+    // Default (mask -1): half everywhere except a ResBlock1 stage of 128 channels -- the pair kernel's stage (HiFi-GAN V1's second): 43 % of
+    // that generator's matrix work, where the f16 multiplier array's extra power is 0.3 of the 0.8-1.0 ms the all-half generator costs at
+    // the board's power limit, for 1/5 of the error budget (tools/ab_voc_stages.py, tools/vocoder_error_budget.py)
+    int mask = c->voc_f16_stages;
+    if (mask < 0) {
+        mask = 0x7fffffff;
+        int cw = c->voc_c0;
+        for (int i = 0; i < (int)c->voc_rates.size(); i++) { cw /= 2; if (cw == 128 && c->voc_resblock == 1) mask &= ~(1 << (i + 1)); }
+    }
+    auto dom = [&](int k) -> int { return (half_ok && ((mask >> k) & 1)) ? (int)DT_F16 : c->dt; };
     auto vtd = [&](const std::string& n, int d) -> const Tensor& { return c->t(d == DT_F16 ? n + ".h16" : n); };      // a contraction weight in a domain's dtype
     const size_t es = dtype_size(c->dt);
     int dt = dom(0);                                                  // the domain of the launches being issued
@@ -1471,7 +1481,7 @@ void run_vocoder(zvx_ctx* c, const float* mel, int ldm, int Lmel_max, const int*
                             // one launch: xt = lrelu(c1(x_act)+b1) stays in LDS; x' = c2(xt) + b2 + x      hifigan.py:51-55
                             a.X = cur; a.W = w2.dev; a.Wp = c->packed[w2.dev]; a.Wp2 = c->packed[w1.dev];
                             a.bias1 = c->pf(rb + ".c1_" + ts + "_b"); a.slope1 = 0.1f; a.fused = 1;
-                            a.no_pairstream = (c->use_pairstream <= 0 || (c->use_pairstream == 2 && k == 3)) ? 1 : (c->use_pairstream == 3 ? 2 : (c->use_pairstream == 4 ? 3 : 0));
+                            a.no_pairstream = c->use_pairstream <= 0 ? 1 : (c->use_pairstream == 3 ? 2 : (c->use_pairstream == 4 ? 3 : 0));
                             set_taps_1d(a, k, 1);
                             for (int q = 0; q < k; q++) a.dv1[q] = (q - (k - 1) / 2) * dil[t];
                             a.bias = c->pf(rb + ".c2_" + ts + "_b");
@@ -1479,11 +1489,9 @@ void run_vocoder(zvx_ctx* c, const float* mel, int ldm, int Lmel_max, const int*
                             rb_tail(a);
                             // the fused kernels cover a subset of (C, k, dilation, LDS footprint): ask the launcher (dry run) first
                             const int fv = gemm_variant_of(a);
-                            fuse = fv >= 0 && !(c->use_pairstream < 0 && Cout == 128);
-                            // C = 128 with the pair kernel as the default: where it declines (small jobs), run the two conv-slab launches it
-                            // is bit-identical to, not the register-resident pair kernel (k = 3), whose running-sum rounding differs --
+                            // C = 128: the pair kernel, or -- where it declines (small jobs) -- the two conv-slab launches it is bit-identical to:
                             // an utterance must come out the same alone and inside a large batch
-                            if ((c->use_pairstream == 1 || c->use_pairstream >= 3) && Cout == 128 && fv != 23) fuse = false;
+                            fuse = fv >= 0 && !(Cout == 128 && fv != 23);
                         }
                         if (!fuse) {
                             // xt = c1(lrelu(x)); stored as lrelu(xt)                       hifigan.py:51-53
@@ -1536,6 +1544,22 @@ void run_vocoder(zvx_ctx* c, const float* mel, int ldm, int Lmel_max, const int*
 // speaker encoder (ResNetSE34V2.py:176-212)
 // ------------------------------------------------------------------------------------------------
 void run_spkemb(zvx_ctx* c, const float* ref_mels, const int32_t* lens, int B, int Tmax, float* out, int flags) {
+    // Large batches run as sub-batches of `spk_chunk` clips (zvx_set_int): the maps of a residual block -- input, conv1 result, conv2 result,
+    // shortcut -- then fit the 256 MB Infinity Cache together, and the HBM-bound passes of the C = 32 / 64 levels (3 x 3 convolutions at
+    // 3-4 TB/s, the squeeze-excite apply pass over three tensors) find their operands there.  Every clip is computed exactly as before
+    // (tiles never cross clips): bit-identical for any chunk size.
+    if (c->spk_chunk > 0 && B > c->spk_chunk) {
+        const int CH = c->spk_chunk, keep = c->spk_chunk;
+        struct Restore { zvx_ctx* c; int v; ~Restore() { c->spk_chunk = v; } } restore{c, keep};
+        c->spk_chunk = 0;
+        for (int b0 = 0; b0 < B; b0 += CH) {
+            const int nb = std::min(CH, B - b0);
+            const bool last = b0 + nb >= B;
+            run_spkemb(c, ref_mels + (size_t)b0 * Tmax * c->n_mels, lens + b0, nb, Tmax, out + (size_t)b0 * c->H,
+                       last ? flags : (flags | ((flags & ZVX_DEVICE_OUT) ? ZVX_NO_SYNC : 0)));
+        }
+        return;
+    }
     const int dt = c->dt, F0 = c->n_mels, H = c->H;
     const size_t es = c->es();
     for (int b = 0; b < B; b++) if (lens[b] < 2 || lens[b] > Tmax) fail(ZVX_E_INVALID, "ref mel length %d out of range (2..%d)", lens[b], Tmax);
@@ -1917,7 +1941,7 @@ zvx_status zvx_set_int(zvx_ctx* c, const char* key, int64_t value) {
         else if (std::string(key) == "profile_only") { c->sync(); c->profile_only = (int)value; }
         else if (std::string(key) == "shape_log") c->shape_log = (int)value;
         else if (std::string(key) == "resstream") c->use_resstream = (int)value;
-        else if (std::string(key) == "pairstream") c->use_pairstream = (int)value;
+        else if (std::string(key) == "pairstream") { if (value == 2) fail(ZVX_E_INVALID, "pairstream 2 (k = 3 on the register-resident pair kernel) was removed in round 6"); c->use_pairstream = (int)value; }
         else if (std::string(key) == "voc_chunk") c->voc_chunk = (int)value;
         else if (std::string(key) == "flash") c->use_flash = (int)value;
         else if (std::string(key) == "attn_f32") c->use_attn_f32 = (int)value;
@@ -1954,6 +1978,7 @@ zvx_status zvx_set_int(zvx_ctx* c, const char* key, int64_t value) {
         else if (std::string(key) == "rs_seg_min") c->rs_seg_min = (int)value;
         else if (std::string(key) == "slab_small") c->slab_small = (int)value;
         else if (std::string(key) == "spk_pool_fuse") c->spk_pool_fuse = (int)value;
+        else if (std::string(key) == "spk_chunk") c->spk_chunk = (int)std::max<int64_t>(0, value);
         else if (std::string(key) == "spk_s2_fuse") c->spk_s2_fuse = (int)value;
         else if (std::string(key) == "slab_flat") c->slab_flat = (int)value;
         else if (std::string(key) == "max_frames") { if (value < 1 || value > (1 << 24)) fail(ZVX_E_INVALID, "max_frames out of range"); c->max_frames = (int)value; }
