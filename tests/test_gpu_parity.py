@@ -293,6 +293,32 @@ def test_vocoder_v3_routing_no_gathered_row_fallback():
     mel = rng.standard_normal((4, 96, 80)).astype(np.float32)
     v = _variants_of(ctx, lambda: ctx.vocode_mel(mel, np.full(4, 96, np.int32)))
     assert v and not [n for n in v if n.startswith("gemm_")], v
+    # round 6: a ResBlock2 whose two weight sets fit the registers is ONE launch (rb2fuse_kernel: lrelu(x1) stays in LDS): all three blocks of
+    # the C = 32 stage, the k = 3 block of the C = 64 stage
+    assert v.get("rb2fuse_bf16_c64") == 1 and v.get("rb2fuse_bf16_c32") == 3, v
+
+
+@pytest.mark.parametrize("voc", ["v3", "tiny2"])
+def test_fused_resblock2_equals_the_per_convolution_launches(voc):
+    """rb2fuse_kernel (a whole ResBlock2 per launch for C = 32 / 64: x1 = x + c_0(lrelu(x)) kept in LDS as lrelu(x1), x2 = x1 + c_1(lrelu(x1)),
+    k = 3 / 5 / 7 with second dilations up to 12 = 36 halo rows either side) against zvx_set_int("rb2fuse", 0), every convolution its own
+    launch: the same 16-bit rounding of the intermediate and the same accumulation order -- bit-identical waveforms, in half and in bf16;
+    ragged batches, one-frame utterances, utterances shorter than a tile's halo and longer than several tiles."""
+    ctx = ctx_for("styletts", voc, "bf16")
+    rng = np.random.default_rng(71)
+    try:
+        for f16 in (1, 0):
+            ctx.set_int("voc_f16", f16)
+            for B, Pmax in ((3, 23), (1, 1), (2, 300), (5, 70), (1, 2)):
+                P = rng.integers(1, Pmax + 1, B).astype(np.int32); P[0] = Pmax
+                mel = np.zeros((B, Pmax, 80), np.float32)
+                for b in range(B):
+                    mel[b, :P[b]] = rng.standard_normal((P[b], 80)).astype(np.float32)
+                ctx.set_int("rb2fuse", 0); ref = ctx.vocode_mel(mel, P)
+                ctx.set_int("rb2fuse", 1); got = ctx.vocode_mel(mel, P)
+                assert np.isfinite(got).all() and np.array_equal(got, ref), (voc, f16, B, Pmax, float(np.abs(got - ref).max()))
+    finally:
+        ctx.set_int("rb2fuse", 1); ctx.set_int("voc_f16", 1)
 
 
 def test_speaker_encoder_routing_persistent_kernels():

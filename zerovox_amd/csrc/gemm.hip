@@ -3,7 +3,7 @@
 //   gemm_kernel             generic gathered-row GEMM (this comment): f32 path, attention products, 2-D taps
 //   convslab_kernel         bf16 1-D convs / linears against static weights: slab in LDS, fragment-packed weight stream
 //   convreg_kernel          single square convs with C <= 64: all weight fragments in registers
-//   resfuse_kernel          fused ResBlock1 pair, one tile per workgroup (fallback)
+//   rb2fuse_kernel          a whole ResBlock2 (two dilated convolutions + residuals), one tile per workgroup (HiFi-GAN V3)
 //   resfuse_persist_kernel  fused ResBlock1 pair, persistent + wave-specialised (C = 8 .. 128)
 //   epilogue / epilogue_rows / epilogue_direct   MFMA-layout, LDS-transposed row-major, and bf16-staged epilogues
 //
@@ -1212,13 +1212,22 @@ __global__ __launch_bounds__(512, 2) void conv2d_s2_kernel(const GemmArgs a, con
     const int Wo = a.wout, win = a.win, hin = a.hin, M = a.M;
     const float rWo = 1.0f / (float)Wo;
 
-    uint4 w[9][KS], wd[FUSE_DS ? KS : 1];
+    // C = 64: 36 fragments = 144 registers next to 13 in-flight row requests and the accumulators overflowed the 256-register budget by 8
+    // (round 5 shipped that spill); the LAST tap's four fragments now live in LDS (4 KiB per channel tile, read back per tile: 4 ds_reads)
+    constexpr bool WLDS = C == 64;
+    constexpr int NTR = WLDS ? 8 : 9;
+    uint4 w[NTR][KS], wd[FUSE_DS ? KS : 1];
+    unsigned char* const wl = slab + ((4 * SRP * PITCH_ + 15) & ~15) + 3 * N * sizeof(float);
     {
         const uint4* Wq = (const uint4*)a.Wp + ((long)wc * 9 * 4) * 64 + lane;
 #pragma unroll
-        for (int t = 0; t < 9; t++)
+        for (int t = 0; t < NTR; t++)
 #pragma unroll
             for (int kk = 0; kk < KS; kk++) w[t][kk] = Wq[(t * 4 + kk) * 64];
+        if (WLDS && wr == 0) {
+#pragma unroll
+            for (int kk = 0; kk < KS; kk++) *(uint4*)(wl + ((wc * KS + kk) * 64 + lane) * 16) = Wq[(8 * 4 + kk) * 64];
+        }
         if (FUSE_DS) {
             const uint4* Dq = (const uint4*)a.ds_Wp + ((long)wc * 4) * 64 + lane;
 #pragma unroll
@@ -1278,13 +1287,17 @@ __global__ __launch_bounds__(512, 2) void conv2d_s2_kernel(const GemmArgs a, con
             const int off = (du < 0 ? -Wo : 0) + (dv < 0 ? -1 : 0);
             const unsigned char* rowp = slab + (plane * SRP + xrow0 + off) * PITCH_ + koff;
 #pragma unroll
-            for (int kk = 0; kk < KS; kk++)
+            for (int kk = 0; kk < KS; kk++) {
+                uint4 wt;
+                if (WLDS && tp == 8) wt = *(const uint4*)(wl + ((wc * KS + kk) * 64 + lane) * 16);
+                else wt = w[tp < NTR ? tp : 0][kk];
 #pragma unroll
                 for (int j = 0; j < TM; j++) {
                     const uint4 xf = *(const uint4*)(rowp + j * 32 * PITCH_ + kk * 32);
-                    acc[j] = mfma16<false>(w[tp][kk], xf, acc[j]);
+                    acc[j] = mfma16<false>(wt, xf, acc[j]);
                     if (FUSE_DS && tp == 4) accd[j] = mfma16<false>(wd[kk], xf, accd[j]);
                 }
+            }
         }
         {
             unsigned short* const ob = (unsigned short*)a.out + (long)b * a.o_bs + wc * 32 + 4 * (lane >> 5);
@@ -1316,7 +1329,7 @@ __global__ __launch_bounds__(512, 2) void conv2d_s2_kernel(const GemmArgs a, con
 // this is a dry run)
 template <int C, int BM, int WM, int WN, int MAXHP, bool FUSE_DS>
 static void launch_conv2d_s2_variant(const GemmArgs& a, hipStream_t stream) {
-    const size_t lds = (((size_t)4 * (BM + MAXHP) * (C * 2 + 16) + 15) & ~(size_t)15) + 3 * 2 * C * sizeof(float);
+    const size_t lds = (((size_t)4 * (BM + MAXHP) * (C * 2 + 16) + 15) & ~(size_t)15) + 3 * 2 * C * sizeof(float) + (C == 64 ? (size_t)WN * (C / 16) * 1024 : 0);
     const int ntm = (a.M + BM - 1) / BM, ntiles = ntm * a.nbatch;
     int G = persistent_cus() & ~7;
     if (G < 8) G = 8;
@@ -1381,139 +1394,189 @@ static bool launch_convreg_c(const GemmArgs& a, hipStream_t stream) {
 #endif  // ZVX_PART_MAIN
 #if ZVX_PART_RESFUSE
 // ================================================================================================
-// resfuse kernel: one HiFi-GAN ResBlock1 iteration (hifigan.py:51-55) in a single launch for C = 32 / 64:
-//     xt = lrelu(conv1_dilated(lrelu(x)) + b1)  -> stays in LDS (bf16)  ->  x' = conv2(xt) + b2 + x
-// x arrives in the activated domain (lrelu(x)); the tile's conv1 output (BM rows incl. conv2's halo) never
-// leaves the CU, which removes 3 of the 5 HBM passes of the unfused pair.  Weights of both convs live in
-// registers (conv2's are fetched while conv1's results are written to LDS).
+// rb2fuse kernel (round 6): a whole HiFi-GAN ResBlock2 (hifigan.py:77-82 with two dilations, config_v3) in ONE launch for C = 32 / 64:
+//     x1 = x + conv_d1(lrelu(x));   x2 = x1 + conv_d2(lrelu(x1))
+// Tensors live in the activated domain (lrelu(x) is what is stored), so lrelu(x1) -- exactly what the second convolution consumes
+// and what the unfused path writes to HBM between its two launches -- stays in LDS (16-bit, same rounding), and the block's result
+// leaves through the shared row-major epilogue (running sum / stage mean / next activation as the launch asks).  Rounds 1-5 ran
+// every convolution as its own launch: six trips of the stage tensor per block, two now (x in, result out; + the running sum where
+// it applies).  One tile per workgroup, all weight fragments of both convolutions in registers; the second convolution's dilation (up to 12 at k = 7: 36 halo rows
+// either side) is what the first one over-computes: BM rows of x1 for BM - 2 h2 rows of x2.
 // ================================================================================================
 template <int C, int NT, int BM, int WM, int WN, int MINW, bool F16 = false>
-__global__ __launch_bounds__(256, MINW) void resfuse_kernel(const GemmArgs a) {
+__global__ __launch_bounds__(256, MINW) void rb2fuse_kernel(const GemmArgs a, const int H2, const int ntm, const int ntiles, const int chunk) {
     constexpr int TM = BM / WM / 32;
     constexpr int KS = C / 16;
     constexpr int PITCH_ = C * 2 + 16;
     constexpr int CPR = C / 8;
-    constexpr int H2 = (NT - 1) / 2;                      // conv2 halo (dilation 1)
-    constexpr int BMO = BM - 2 * H2;                      // output rows per tile
-    constexpr int NIT = ((BM + 64) * CPR + 255) / 256;
+    constexpr int NIT = ((BM + 32) * CPR + 255) / 256;     // conv1 halo <= 16 rows either side
     static_assert(WM * WN == 4 && WN * 32 == C, "wave layout");
+    static_assert(NT * KS <= 24, "both convolutions' weight fragments stay in registers");
     extern __shared__ __attribute__((aligned(16))) unsigned char slab[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave % WM, wc = wave / WM;
-    int wg;
-    {
-        const int nwg = gridDim.x, id = blockIdx.x, q = nwg >> 3, r = nwg & 7, xcd = id & 7;
-        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
-    }
-    const int m0 = wg * BMO, b = blockIdx.y;
-    const int out_len = a.out_len ? a.out_len[b] : a.M;
-    const int in_len = a.in_len ? a.in_len[b] : a.in_len_static;
-    if (m0 >= out_len || m0 >= a.M) return;
-    const int H1 = a.halo_l;                              // conv1 halo = dilation*(NT-1)/2 (symmetric)
+    const int BMO = BM - 2 * H2;                           // output rows per tile
+    const int H1 = a.halo_l;                               // conv1 halo = d1 (NT-1)/2 (symmetric)
     const int SR = BM + 2 * H1;
     unsigned char* t1 = slab + ((SR * PITCH_ + 15) & ~15);
-    const unsigned short* Xp = (const unsigned short*)a.X + (long)b * a.x_bs;
 
-    // conv1's weight fragments -> registers; conv2's go to a second register set when both fit (NT*KS <= 24),
-    // otherwise they replace conv1's tap by tap inside the conv1 loop (each right after that tap's last MFMA).
-    constexpr bool TWO_SETS = (NT * KS <= 24);
-    uint4 w[NT][KS];
-    uint4 w2[TWO_SETS ? NT : 1][TWO_SETS ? KS : 1];
-    const uint4* W1q = (const uint4*)a.Wp2 + ((long)wc * NT * 4) * 64 + lane;
-    const uint4* W2q = (const uint4*)a.Wp + ((long)wc * NT * 4) * 64 + lane;
+    // PERSISTENT: the fragments of both convolutions (up to 40 per wave) are loaded once per workgroup, which then walks a contiguous run of
+    // tiles -- one tile per workgroup re-fetched them per 184-256 output rows: 7x the bytes of the tile's own rows at C = 32, k = 7
+    uint4 w[NT][KS], w2[NT][KS];
+    {
+        const uint4* W1q = (const uint4*)a.Wp2 + ((long)wc * NT * 4) * 64 + lane;
+        const uint4* W2q = (const uint4*)a.Wp + ((long)wc * NT * 4) * 64 + lane;
 #pragma unroll
-    for (int t = 0; t < NT; t++)
+        for (int t = 0; t < NT; t++)
 #pragma unroll
-        for (int kk = 0; kk < KS; kk++) {
-            w[t][kk] = W1q[(t * 4 + kk) * 64];
-            if (TWO_SETS) w2[t][kk] = W2q[(t * 4 + kk) * 64];
-        }
-    {   // slab rows s <-> global row m0 - H2 - H1 + s
-        uint4 sv[NIT];
-#pragma unroll
-        for (int it = 0; it < NIT; it++) {
-            const int c = tid + it * 256;
-            const int row = c / CPR, q = c % CPR;
-            const int g = m0 - H2 - H1 + row;
-            sv[it] = make_uint4(0, 0, 0, 0);
-            if (c < SR * CPR && g >= 0 && g < in_len) sv[it] = *(const uint4*)(Xp + (long)g * a.ldx + q * 8);
-        }
-#pragma unroll
-        for (int it = 0; it < NIT; it++) {
-            const int c = tid + it * 256;
-            if (c < SR * CPR) *(uint4*)(slab + (c / CPR) * PITCH_ + (c % CPR) * 16) = sv[it];
-        }
+            for (int kk = 0; kk < KS; kk++) { w[t][kk] = W1q[(t * 4 + kk) * 64]; w2[t][kk] = W2q[(t * 4 + kk) * 64]; }
     }
-    __syncthreads();
-
-    f32x16 acc[1][TM];
     const int koff = (lane >> 5) * 16;
     const int wrow = wr * (BM / WM);
-    // ---- conv1 (dilated): T1 row i <-> global row m0 - H2 + i, reads slab rows i + H1 + dv1[t] ----
+    const int tbeg = blockIdx.x * chunk, tend = tbeg + chunk < ntiles ? tbeg + chunk : ntiles;
+    bool first = true;
+    for (int tile = tbeg; tile < tend; tile++) {
+        const int b = tile / ntm, m0 = (tile - b * ntm) * BMO;
+        const int out_len = a.out_len ? a.out_len[b] : a.M;
+        const int in_len = a.in_len ? a.in_len[b] : a.in_len_static;
+        if (m0 >= out_len || m0 >= a.M) continue;          // (uniform over the workgroup)
+        if (!first) __syncthreads();                       // the previous tile's epilogue is done with the slab's area (its stage) and with x1
+        first = false;
+        const unsigned short* Xp = (const unsigned short*)a.X + (long)b * a.x_bs;
+        {   // slab rows s <-> global row m0 - H2 - H1 + s
+            uint4 sv[NIT];
+            int tq = tid;
+            asm volatile("" : "+v"(tq));                   // per-tile address arithmetic stays inside the tile loop
 #pragma unroll
-    for (int j = 0; j < TM; j++)
-#pragma unroll
-        for (int e = 0; e < 16; e++) acc[0][j][e] = 0.f;
-#pragma unroll
-    for (int t = 0; t < NT; t++) {
-        const unsigned char* rowp = slab + (wrow + (lane & 31) + H1 + a.dv1[t]) * PITCH_ + koff;
-#pragma unroll
-        for (int kk = 0; kk < KS; kk++) {
-#pragma unroll
-            for (int j = 0; j < TM; j++) {
-                const uint4 xf = *(const uint4*)(rowp + j * 32 * PITCH_ + kk * 32);
-                acc[0][j] = mfma16<F16>(w[t][kk], xf, acc[0][j]);
+            for (int it = 0; it < NIT; it++) {
+                const int c = tq + it * 256;
+                const int row = c / CPR, q = c % CPR;
+                const int g = m0 - H2 - H1 + row;
+                sv[it] = make_uint4(0, 0, 0, 0);
+                if (c < SR * CPR && g >= 0 && g < in_len) sv[it] = *(const uint4*)(Xp + (long)g * a.ldx + q * 8);
             }
-            if (!TWO_SETS) w[t][kk] = W2q[(t * 4 + kk) * 64];        // conv2's fragment takes the freed register
+#pragma unroll
+            for (int it = 0; it < NIT; it++) {
+                const int c = tq + it * 256;
+                if (c < SR * CPR) *(uint4*)(slab + (c / CPR) * PITCH_ + (c % CPR) * 16) = sv[it];
+            }
         }
-    }
-    // ---- T1 = lrelu(acc + b1) as bf16, zero outside the sequence (conv2 zero-pads ITS input, hifigan.py:39-44) ----
+        __syncthreads();
+
+        f32x16 acc[1][TM];
+        // ---- conv1 (dilation d1): x1 row i <-> global row m0 - H2 + i, reads slab rows i + H1 + dv1[t] ----
 #pragma unroll
-    for (int j = 0; j < TM; j++) {
-        const int i = wrow + j * 32 + (lane & 31);
-        const int g = m0 - H2 + i;
-        const bool inside = g >= 0 && g < in_len;
+        for (int j = 0; j < TM; j++)
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const int co = wc * 32 + 8 * q + 4 * (lane >> 5);
-            const float4 bb = *(const float4*)(a.bias1 + co);
-            float v[4] = {acc[0][j][4 * q] + bb.x, acc[0][j][4 * q + 1] + bb.y, acc[0][j][4 * q + 2] + bb.z, acc[0][j][4 * q + 3] + bb.w};
+            for (int e = 0; e < 16; e++) acc[0][j][e] = 0.f;
 #pragma unroll
-            for (int e = 0; e < 4; e++) { v[e] = v[e] >= 0.f ? v[e] : v[e] * a.slope1; if (!inside) v[e] = 0.f; }
-            uint2 pk;
-            if (F16) { pk.x = pack_f16x2_sat(v[0], v[1]); pk.y = pack_f16x2_sat(v[2], v[3]); }
-            else {
-                pk.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
-                pk.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
-            }
-            *(uint2*)(t1 + i * PITCH_ + co * 2) = pk;
+        for (int t = 0; t < NT; t++) {
+            const unsigned char* rowp = slab + (wrow + (lane & 31) + H1 + a.dv1[t]) * PITCH_ + koff;
+#pragma unroll
+            for (int kk = 0; kk < KS; kk++)
+#pragma unroll
+                for (int j = 0; j < TM; j++) {
+                    const uint4 xf = *(const uint4*)(rowp + j * 32 * PITCH_ + kk * 32);
+                    acc[0][j] = mfma16<F16>(w[t][kk], xf, acc[0][j]);
+                }
         }
-    }
-    __syncthreads();
-    // ---- conv2 (dilation 1): output row j <-> global m0 + j, reads T1 rows j + H2 + dv[t] ----
+        // ---- lrelu(x1) = lrelu(acc + b1 + x) as 16 bit (x = inverse lrelu of the slab's centre rows), zero outside the sequence (the second
+        //      convolution zero-pads ITS input, hifigan.py:68-75).  Same operation order as the unfused launch's epilogue: bias, residual, activation
 #pragma unroll
-    for (int j = 0; j < TM; j++)
+        for (int j = 0; j < TM; j++) {
+            const int i = wrow + j * 32 + (lane & 31);
+            const int g = m0 - H2 + i;
+            const bool inside = g >= 0 && g < in_len;
 #pragma unroll
-        for (int e = 0; e < 16; e++) acc[0][j][e] = 0.f;
-#pragma unroll
-    for (int t = 0; t < NT; t++) {
-        const unsigned char* rowp = t1 + (wrow + (lane & 31) + H2 + a.dv[t]) * PITCH_ + koff;
-#pragma unroll
-        for (int kk = 0; kk < KS; kk++)
-#pragma unroll
-            for (int j = 0; j < TM; j++) {
-                const uint4 xf = *(const uint4*)(rowp + j * 32 * PITCH_ + kk * 32);
-                acc[0][j] = mfma16<F16>(TWO_SETS ? w2[TWO_SETS ? t : 0][TWO_SETS ? kk : 0] : w[t][kk], xf, acc[0][j]);
+            for (int q = 0; q < 4; q++) {
+                const int co = wc * 32 + 8 * q + 4 * (lane >> 5);
+                const float4 bb = *(const float4*)(a.bias1 + co);
+                const uint2 xr = *(const uint2*)(slab + (i + H1) * PITCH_ + co * 2);
+                const f32x2 r01 = inv_lrelu2(F16 ? unpack_f16x2(xr.x) : unpack_bf16x2(xr.x), a.res_inv_slope);
+                const f32x2 r23 = inv_lrelu2(F16 ? unpack_f16x2(xr.y) : unpack_bf16x2(xr.y), a.res_inv_slope);
+                f32x2 v01 = (f32x2){acc[0][j][4 * q] + bb.x, acc[0][j][4 * q + 1] + bb.y} + r01;
+                f32x2 v23 = (f32x2){acc[0][j][4 * q + 2] + bb.z, acc[0][j][4 * q + 3] + bb.w} + r23;
+                v01 = lrelu2(v01, a.slope1); v23 = lrelu2(v23, a.slope1);
+                if (!inside) { v01 = (f32x2){0.f, 0.f}; v23 = (f32x2){0.f, 0.f}; }
+                uint2 pk;
+                if (F16) { pk.x = pack_f16x2_sat(v01.x, v01.y); pk.y = pack_f16x2_sat(v23.x, v23.y); }
+                else { pk.x = pack_bf16x2(v01.x, v01.y); pk.y = pack_bf16x2(v23.x, v23.y); }
+                *(uint2*)(t1 + i * PITCH_ + co * 2) = pk;
             }
+        }
+        __syncthreads();
+        // ---- conv2 (dilation d2): output row j <-> global m0 + j, reads x1 rows j + H2 + dv[t] ----
+#pragma unroll
+        for (int j = 0; j < TM; j++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[0][j][e] = 0.f;
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+            const unsigned char* rowp = t1 + (wrow + (lane & 31) + H2 + a.dv[t]) * PITCH_ + koff;
+#pragma unroll
+            for (int kk = 0; kk < KS; kk++)
+#pragma unroll
+                for (int j = 0; j < TM; j++) {
+                    const uint4 xf = *(const uint4*)(rowp + j * 32 * PITCH_ + kk * 32);
+                    acc[0][j] = mfma16<F16>(w2[t][kk], xf, acc[0][j]);
+                }
+        }
+        // (no barrier: the x slab has been dead since the barrier above -- its area becomes the transpose stage; x1 stays readable)
+        const int lim = (m0 + BMO < out_len) ? m0 + BMO : out_len;
+        // residual x1 = inverse lrelu of the x1 rows of this tile (output row j <-> x1 row j + H2): no global re-read
+        epilogue_rows<TM, 1, 1, -1, F16>(a, acc, b, m0 + wrow, wc * 32, lim, lane, slab + wave * (32 * (32 * 4 + 16)),
+                                   t1 + (wrow + H2) * PITCH_, PITCH_);
     }
-    __syncthreads();                                       // T1 is dead: its area becomes the transpose stage
-    const int lim = (m0 + BMO < out_len) ? m0 + BMO : out_len;
-    // residual x = inverse-lrelu of the slab rows of this tile (output row j <-> slab row j + H2 + H1): no global re-read
-    epilogue_rows<TM, 1, 1, -1, F16>(a, acc, b, m0 + wrow, wc * 32, lim, lane, t1 + wave * (32 * (32 * 4 + 16)),
-                               slab + (wrow + H2 + H1) * PITCH_, PITCH_);
 }
 
+template <int C, int NT, int BM, int WM, int WN, int MINW>
+static bool launch_rb2fuse_c(const GemmArgs& a, int h2, hipStream_t stream) {
+    const int bmo = BM - 2 * h2;
+    if (bmo < 32 || a.halo_l > 16) return false;
+    const size_t pitch = C * 2 + 16;
+    const size_t sb = (((size_t)(BM + 2 * a.halo_l) * pitch + 15) & ~(size_t)15);
+    if (sb < (size_t)4 * 32 * (32 * 4 + 16)) return false;           // the slab's area doubles as the epilogue's transpose stage
+    const size_t lds = sb + (size_t)(BM + 2 * h2) * pitch;
+    if (lds > 160 * 1024) return false;
+    // persistent workgroups: as many per CU as LDS and the register budget (MINW waves per SIMD) allow, each walking a contiguous run of tiles
+    const int ntm = (a.M + bmo - 1) / bmo, ntiles = ntm * a.nbatch;
+    int per_cu = (int)((size_t)160 * 1024 / lds);
+    if (per_cu > MINW) per_cu = MINW;
+    if (per_cu < 1) per_cu = 1;
+    const int slots = persistent_cus() * per_cu;
+    const int chunk = (ntiles + slots - 1) / slots;
+    const dim3 grid((ntiles + chunk - 1) / chunk);
+    if (a.dtype == DT_F16) { auto kfn = rb2fuse_kernel<C, NT, BM, WM, WN, MINW, true>; if (!lds_opt_in((const void*)kfn)) return false; ZVX_LAUNCH(kfn, grid, dim3(256), lds, stream, a, h2, ntm, ntiles, chunk); }
+    else { auto kfn = rb2fuse_kernel<C, NT, BM, WM, WN, MINW, false>; if (!lds_opt_in((const void*)kfn)) return false; ZVX_LAUNCH(kfn, grid, dim3(256), lds, stream, a, h2, ntm, ntiles, chunk); }
+    return true;
+}
+
+// a.fused == 2: both convolutions of a ResBlock2 (conv1: Wp2 / bias1 / dv1, conv2: Wp / bias / dv; same kernel size, two dilations) + the
+// block's residual epilogue.  Variant id, or -1 when the shape is not covered (the caller then runs the two launches)
+int launch_rb2fuse(GemmArgs a, hipStream_t stream) {
+    if (a.dtype == DT_F32 || !a.Wp || !a.Wp2 || a.N != a.K || a.nheads != 1 || a.wout > 0 || a.bflat || a.K2) return -1;
+    if (!(a.ntaps == 3 || a.ntaps == 5 || a.ntaps == 7) || !(a.N == 32 || a.N == 64)) return -1;
+    const int h = (a.ntaps - 1) / 2, d1 = a.dv1[1] - a.dv1[0], d2 = a.dv[1] - a.dv[0];
+    if (d1 < 1 || d2 < 1) return -1;
+    for (int t = 0; t < a.ntaps; t++) if (a.dv1[t] != (t - h) * d1 || a.dv[t] != (t - h) * d2) return -1;
+    // the shared run-time epilogue with the residual taken from LDS: what the vocoder asks of a ResBlock's closing convolution
+    if (a.alpha != 1.f || a.bias_mode != 1 || !a.bias || !a.bias1 || a.post_scale || a.res_mode != 2 || a.res != a.X || a.res_dtype != a.dtype || a.ldo % 8 ||
+        (a.out && a.out_dtype != a.dtype) || (a.accum && (a.lda % 8 || a.accum_dtype != a.dtype)) || a.in_len != a.out_len || a.ldx != a.N) return -1;
+    a.halo_l = a.halo_r = h * d1;
+    a.fused = 2;
+    // (C = 64, k = 5 / 7: 2 x 20 / 28 fragments do not fit the registers next to the accumulators and the epilogue -- the caller runs those
+    // blocks' convolutions as two launches, which at 3.3-4.5 TB/s of the stage tensor measured as fast as / faster than a fused tile that
+    // re-fetches its weights per 104-184 output rows)
+    if (a.N == 32) {
+        if (a.ntaps == 3 && launch_rb2fuse_c<32, 3, 256, 4, 1, 2>(a, h * d2, stream)) return 30;
+        if (a.ntaps == 5 && launch_rb2fuse_c<32, 5, 256, 4, 1, 2>(a, h * d2, stream)) return 30;
+        if (a.ntaps == 7 && launch_rb2fuse_c<32, 7, 256, 4, 1, 2>(a, h * d2, stream)) return 30;
+    } else {
+        if (a.ntaps == 3 && launch_rb2fuse_c<64, 3, 128, 2, 2, 2>(a, h * d2, stream)) return 31;
+    }
+    return -1;
+}
 
 // ================================================================================================
 // resfuse, persistent form: the same fused ResBlock1 pair, but the weights are loaded ONCE per CU.
@@ -1859,29 +1922,6 @@ static bool launch_resfuse_persist_c(const GemmArgs& a, hipStream_t stream) {
     return false;
 }
 
-template <int C, int BM, int WM, int WN, int MINW>
-static bool launch_resfuse_c(const GemmArgs& a, hipStream_t stream) {
-    const int h2 = (a.ntaps - 1) / 2, bmo = BM - 2 * h2;
-    dim3 grid((a.M + bmo - 1) / bmo, a.nbatch);
-    const size_t pitch = C * 2 + 16;
-    size_t lds = (((size_t)(BM + 2 * a.halo_l) * pitch + 15) & ~(size_t)15) + (size_t)(BM + 2 * h2 + 32) * pitch;
-    if (a.dtype == DT_F16) {
-        switch (a.ntaps) {
-            case 3: ZVX_LAUNCH((resfuse_kernel<C, 3, BM, WM, WN, MINW, true>), grid, dim3(256), lds, stream, a); return true;
-            case 7: ZVX_LAUNCH((resfuse_kernel<C, 7, BM, WM, WN, MINW, true>), grid, dim3(256), lds, stream, a); return true;
-            case 11: ZVX_LAUNCH((resfuse_kernel<C, 11, BM, WM, WN, MINW, true>), grid, dim3(256), lds, stream, a); return true;
-        }
-        return false;
-    }
-    switch (a.ntaps) {
-        case 3: ZVX_LAUNCH((resfuse_kernel<C, 3, BM, WM, WN, MINW>), grid, dim3(256), lds, stream, a); return true;
-        case 7: ZVX_LAUNCH((resfuse_kernel<C, 7, BM, WM, WN, MINW>), grid, dim3(256), lds, stream, a); return true;
-        case 11: ZVX_LAUNCH((resfuse_kernel<C, 11, BM, WM, WN, MINW>), grid, dim3(256), lds, stream, a); return true;
-    }
-    return false;
-}
-
-// Fused ResBlock1 pair; returns the variant id or -1 when the shape is not covered (caller then issues the two convs).
 int launch_resfuse(GemmArgs a, hipStream_t stream) {
     if (a.dtype == DT_F32 || !a.Wp || !a.Wp2 || a.N != a.K || a.nheads != 1 || a.wout > 0) return -1;
     if (!(a.ntaps == 3 || a.ntaps == 7 || a.ntaps == 11)) return -1;
@@ -1920,9 +1960,7 @@ int launch_resfuse(GemmArgs a, hipStream_t stream) {
         // launches it is bit-identical to, C = 16 / 8 stages on narrowstage.hip or, where that declines, as two launches per pair: 84 fewer
         // instantiations, none of them on a default path since round 5)
     }
-    if (a.N == 32 && launch_resfuse_c<32, 256, 4, 1, 2>(a, stream)) return 16;
-    if (a.N == 64 && launch_resfuse_c<64, 128, 2, 2, 2>(a, stream)) return 17;
-    return -1;
+    return -1;                                                 // (round 6: the per-tile fallback kernel is gone -- the caller runs the pair as two launches)
 }
 #endif  // ZVX_PART_RESFUSE
 #if ZVX_PART_MAIN
@@ -1944,6 +1982,7 @@ static const Variant kVariants[] = {
     {"narrowstage_c16", DT_BF16, 256, 16}, {"narrowstage_c8", DT_BF16, 512, 8},      // whole narrow stages in one launch (narrowstage.hip)
     {"conv2d_persist_c32", DT_BF16, 384, 32}, {"conv2d_persist_c64", DT_BF16, 256, 64},   // persistent 3 x 3 convolutions of the speaker encoder (26, 27)
     {"conv2d_s2_c32", DT_BF16, 256, 64}, {"conv2d_s2_c64", DT_BF16, 128, 128},            // ... its stride-2 level transitions (28: + shortcut, 29)
+    {"rb2fuse_bf16_c32", DT_BF16, 256, 32}, {"rb2fuse_bf16_c64", DT_BF16, 128, 64},       // a whole ResBlock2 per launch (30, 31; HiFi-GAN V3)
 };
 const char* gemm_variant_name(int id) { return kVariants[id].name; }
 int gemm_num_variants() { return (int)(sizeof(kVariants) / sizeof(kVariants[0])); }
@@ -2274,7 +2313,7 @@ int launch_gemm(const GemmArgs& a, hipStream_t stream) {
 
 int gemm_variant_of(const GemmArgs& a) {
     g_dry_run = true;
-    const int id = a.fused ? launch_resfuse(a, nullptr) : launch_gemm(a, nullptr);
+    const int id = a.fused == 2 ? launch_rb2fuse(a, nullptr) : (a.fused ? launch_resfuse(a, nullptr) : launch_gemm(a, nullptr));
     g_dry_run = false;
     return id;
 }

@@ -133,7 +133,6 @@ struct zvx_ctx {
     int use_resstream = 1;                 // zvx_set_int("resstream", 0): ResBlocks of the narrow stages as per-pair launches (A/B, bit-equal)
     int rs_seg_min = 0;                    // zvx_set_int("rs_seg_min", -1): streaming ResBlock segments never shorter than 2048 rows (A/B of the single-request sizing)
     int rs_opt = 3;                        // zvx_set_int("rs_opt", v): StreamArgs.opt of the streaming ResBlock kernels (bit 0: staggered wave priorities)
-    int spk_chunk = 0;                     // zvx_set_int("spk_chunk", n): speaker-encoder batches larger than n clips run as sub-batches of n (0: whole batch)
     int spk_s2_fuse = 1;                   // zvx_set_int("spk_s2_fuse", 0): the level transitions as two launches of the gathered-row GEMM (A/B)
     int spk_pool_fuse = 1;                 // zvx_set_int("spk_pool_fuse", 0): the speaker encoder's SE pool as its own pass everywhere (A/B)
     int slab_small = 2, slab_flat = 1;     // zvx_set_int("slab_small" / "slab_flat", v): conv-slab tile choice for single requests / whole-grid XCD remap (A/B; per context)
@@ -147,6 +146,7 @@ struct zvx_ctx {
     void sat_scan(const void* x, int dt, long bs, int ld, int B, int rows_max, const int* rows, int C) {
         if (sat_check && x && dt == DT_F16) launch_count_sat16(x, bs, ld, B, rows_max, rows, C, sat_count_dev(), stream);
     }
+    int use_rb2fuse = 1;                   // zvx_set_int("rb2fuse", 0): every convolution of a ResBlock2 (HiFi-GAN V3 / resblock "2") as its own launch instead of one launch per block (A/B)
     int use_stagefuse = 1;                 // zvx_set_int("stagefuse", 0): narrow vocoder stages (C = 16 / 8) as per-pair launches instead of ONE launch per stage (narrowstage.hip; A/B)
     struct NsWeights { void* W = nullptr; float* bias = nullptr; int woff[18] = {0}; };
     std::map<std::string, NsWeights> ns_weights;   // narrowstage.hip fragment order, per (stage, dtype), built on first use
@@ -279,7 +279,7 @@ struct zvx_ctx {
         GemmEvent ev{};
         const bool prof = profile >= 2 && (profile_only < 0 || gemm_variant_of(a) == profile_only);
         if (prof) { ev.a = new_event(); ev.b = new_event(); gemm_profile_events(ev.a, ev.b); }
-        int id = a.fused ? launch_resfuse(a, stream) : launch_gemm(a, stream);
+        int id = a.fused == 2 ? launch_rb2fuse(a, stream) : (a.fused ? launch_resfuse(a, stream) : launch_gemm(a, stream));
         if (prof) gemm_profile_events(nullptr, nullptr);
         if (id < 0) fail(ZVX_E_INVALID, "launch_gemm rejected shape M=%d N=%d K=%d taps=%d", a.M, a.N, a.K, a.ntaps);
         if (sat_check && a.nheads == 1) {                   // (audit mode: the attention products run fused, their output is scanned by fft_block)
@@ -1441,6 +1441,31 @@ void run_vocoder(zvx_ctx* c, const float* mel, int ldm, int Lmel_max, const int*
                         }
                     }
                 }
+                if (c->voc_resblock == 2 && nd == 2 && dt != DT_F32 && c->use_rb2fuse && !c->sat_check && (Cout == 32 || Cout == 64)) {
+                    // a whole ResBlock2 (hifigan.py:77-82: x1 = x + c_0(lrelu(x)); x2 = x1 + c_1(lrelu(x1))) as ONE launch: lrelu(x1) stays in LDS
+                    // (rb2fuse_kernel, round 6) -- two trips of the stage tensor per block instead of six
+                    const Tensor& w1 = vt(rb + ".c_0_w"); const Tensor& w2 = vt(rb + ".c_1_w");
+                    if (c->packed.count(w1.dev) && c->packed.count(w2.dev)) {
+                        GemmArgs a = gemm_base(dt);
+                        a.M = rows; a.N = Cout; a.K = Cout; a.nbatch = Bs; a.in_len = lens; a.out_len = lens; a.ldw = Cout; a.w_ts = (long)Cout * Cout;
+                        a.x_bs = (long)rows * Cout; a.ldx = Cout; a.o_bs = (long)rows * Cout; a.ldo = Cout;
+                        a.X = X0s; a.W = w2.dev; a.Wp = c->packed[w2.dev]; a.Wp2 = c->packed[w1.dev];
+                        a.bias1 = c->pf(rb + ".c_0_b"); a.slope1 = 0.1f; a.fused = 2;
+                        set_taps_1d(a, k, dil[1]);
+                        for (int q = 0; q < k; q++) a.dv1[q] = (q - (k - 1) / 2) * dil[0];
+                        a.bias = c->pf(rb + ".c_1_b"); a.bias_mode = 1;
+                        a.res = X0s; a.r_bs = (long)rows * Cout; a.ldr = Cout; a.res_mode = 2; a.res_inv_slope = 10.0f; a.res_dtype = dt;
+                        a.accum = XSs; a.accum_dtype = dt; a.a_bs = (long)rows * Cout; a.lda = Cout;
+                        if (nk == 1) { a.accum_mode = 0; a.accum = nullptr; }
+                        else if (j == 0) a.accum_mode = 2;
+                        else if (j < nk - 1) a.accum_mode = 3;
+                        else a.accum_mode = 1;
+                        if (j == nk - 1 || nk == 1) { a.out = As; a.out_scale = 1.0f / nk; a.act = ACT_LRELU; a.slope = next_slope; }
+                        else a.out = nullptr;
+                        a.flops = 2.0 * 2.0 * Bs * (double)rows * Cout * Cout * k;
+                        if (gemm_variant_of(a) >= 0) { to_main(); c->gemm(a); t_first = nd; }
+                    }
+                }
                 for (int t = t_first; t < nd; t++) {
                     const bool last = (t == nd - 1);
                     if (last) to_main(); else to_aux();
@@ -1544,22 +1569,6 @@ void run_vocoder(zvx_ctx* c, const float* mel, int ldm, int Lmel_max, const int*
 // speaker encoder (ResNetSE34V2.py:176-212)
 // ------------------------------------------------------------------------------------------------
 void run_spkemb(zvx_ctx* c, const float* ref_mels, const int32_t* lens, int B, int Tmax, float* out, int flags) {
-    // Large batches run as sub-batches of `spk_chunk` clips (zvx_set_int): the maps of a residual block -- input, conv1 result, conv2 result,
-    // shortcut -- then fit the 256 MB Infinity Cache together, and the HBM-bound passes of the C = 32 / 64 levels (3 x 3 convolutions at
-    // 3-4 TB/s, the squeeze-excite apply pass over three tensors) find their operands there.  Every clip is computed exactly as before
-    // (tiles never cross clips): bit-identical for any chunk size.
-    if (c->spk_chunk > 0 && B > c->spk_chunk) {
-        const int CH = c->spk_chunk, keep = c->spk_chunk;
-        struct Restore { zvx_ctx* c; int v; ~Restore() { c->spk_chunk = v; } } restore{c, keep};
-        c->spk_chunk = 0;
-        for (int b0 = 0; b0 < B; b0 += CH) {
-            const int nb = std::min(CH, B - b0);
-            const bool last = b0 + nb >= B;
-            run_spkemb(c, ref_mels + (size_t)b0 * Tmax * c->n_mels, lens + b0, nb, Tmax, out + (size_t)b0 * c->H,
-                       last ? flags : (flags | ((flags & ZVX_DEVICE_OUT) ? ZVX_NO_SYNC : 0)));
-        }
-        return;
-    }
     const int dt = c->dt, F0 = c->n_mels, H = c->H;
     const size_t es = c->es();
     for (int b = 0; b < B; b++) if (lens[b] < 2 || lens[b] > Tmax) fail(ZVX_E_INVALID, "ref mel length %d out of range (2..%d)", lens[b], Tmax);
@@ -1949,6 +1958,7 @@ zvx_status zvx_set_int(zvx_ctx* c, const char* key, int64_t value) {
         else if (std::string(key) == "voc_f16") c->voc_f16 = (int)value;
         else if (std::string(key) == "voc_f16_stages") c->voc_f16_stages = (int)value;
         else if (std::string(key) == "stagefuse") c->use_stagefuse = (int)value;
+        else if (std::string(key) == "rb2fuse") c->use_rb2fuse = (int)value;
         else if (std::string(key) == "f16_sat_check") {       // (re)arms the audit and zeroes its counter
             c->sync(); c->sat_check = value ? 1 : 0;
             HIPCHK(hipMemsetAsync(c->sat_count_dev(), 0, 64, c->stream));
@@ -1978,7 +1988,6 @@ zvx_status zvx_set_int(zvx_ctx* c, const char* key, int64_t value) {
         else if (std::string(key) == "rs_seg_min") c->rs_seg_min = (int)value;
         else if (std::string(key) == "slab_small") c->slab_small = (int)value;
         else if (std::string(key) == "spk_pool_fuse") c->spk_pool_fuse = (int)value;
-        else if (std::string(key) == "spk_chunk") c->spk_chunk = (int)std::max<int64_t>(0, value);
         else if (std::string(key) == "spk_s2_fuse") c->spk_s2_fuse = (int)value;
         else if (std::string(key) == "slab_flat") c->slab_flat = (int)value;
         else if (std::string(key) == "max_frames") { if (value < 1 || value > (1 << 24)) fail(ZVX_E_INVALID, "max_frames out of range"); c->max_frames = (int)value; }

@@ -128,6 +128,8 @@ void gemm_profile_events(hipEvent_t start, hipEvent_t stop);
 int gemm_variant_of(const GemmArgs& a);
 // fused HiFi-GAN ResBlock1 pair (conv1 -> lrelu -> conv2 -> + x) for C = 32 / 64 bf16; -1 if the shape is not covered
 int launch_resfuse(GemmArgs a, hipStream_t stream);
+// fused HiFi-GAN ResBlock2 (two dilated convolutions with their residuals, hifigan.py:77-82) for C = 32 / 64, k = 3 / 5 / 7; -1 if not covered
+int launch_rb2fuse(GemmArgs a, hipStream_t stream);
 // fragment-order packing of a bf16 weight [ntaps][N][K] for the conv-slab kernel
 size_t packed_weight_elems(int ntaps, int N, int K);
 // combined stream of two packed weights with the same N (GemmArgs::X2): per 32-channel tile the fragments of A, then those of B
