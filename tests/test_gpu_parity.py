@@ -293,9 +293,9 @@ def test_vocoder_v3_routing_no_gathered_row_fallback():
     mel = rng.standard_normal((4, 96, 80)).astype(np.float32)
     v = _variants_of(ctx, lambda: ctx.vocode_mel(mel, np.full(4, 96, np.int32)))
     assert v and not [n for n in v if n.startswith("gemm_")], v
-    # round 6: a ResBlock2 whose two weight sets fit the registers is ONE launch (rb2fuse_kernel: lrelu(x1) stays in LDS): all three blocks of
-    # the C = 32 stage, the k = 3 block of the C = 64 stage
-    assert v.get("rb2fuse_bf16_c64") == 1 and v.get("rb2fuse_bf16_c32") == 3, v
+    # round 6: a ResBlock2 is ONE launch where that measured faster (rb2fuse_kernel: lrelu(x1) stays in LDS): all three blocks of the C = 32
+    # stage, the k = 3 / 5 blocks of the C = 64 stage (k = 7 with its 36-row halo stays two launches)
+    assert v.get("rb2fuse_bf16_c64") == 2 and v.get("rb2fuse_bf16_c32") == 3, v
 
 
 @pytest.mark.parametrize("voc", ["v3", "tiny2"])

@@ -1404,14 +1404,13 @@ static bool launch_convreg_c(const GemmArgs& a, hipStream_t stream) {
 // either side) is what the first one over-computes: BM rows of x1 for BM - 2 h2 rows of x2.
 // ================================================================================================
 template <int C, int NT, int BM, int WM, int WN, int MINW, bool F16 = false>
-__global__ __launch_bounds__(256, MINW) void rb2fuse_kernel(const GemmArgs a, const int H2, const int ntm, const int ntiles, const int chunk) {
+__global__ __launch_bounds__(256, MINW) void rb2fuse_kernel(const GemmArgs a, const int H2, const int ntm, const int ntiles) {
     constexpr int TM = BM / WM / 32;
     constexpr int KS = C / 16;
     constexpr int PITCH_ = C * 2 + 16;
     constexpr int CPR = C / 8;
     constexpr int NIT = ((BM + 32) * CPR + 255) / 256;     // conv1 halo <= 16 rows either side
     static_assert(WM * WN == 4 && WN * 32 == C, "wave layout");
-    static_assert(NT * KS <= 24, "both convolutions' weight fragments stay in registers");
     extern __shared__ __attribute__((aligned(16))) unsigned char slab[];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1421,33 +1420,38 @@ __global__ __launch_bounds__(256, MINW) void rb2fuse_kernel(const GemmArgs a, co
     const int SR = BM + 2 * H1;
     unsigned char* t1 = slab + ((SR * PITCH_ + 15) & ~15);
 
-    // PERSISTENT: the fragments of both convolutions (up to 40 per wave) are loaded once per workgroup, which then walks a contiguous run of
-    // tiles -- one tile per workgroup re-fetched them per 184-256 output rows: 7x the bytes of the tile's own rows at C = 32, k = 7
-    uint4 w[NT][KS], w2[NT][KS];
-    {
-        const uint4* W1q = (const uint4*)a.Wp2 + ((long)wc * NT * 4) * 64 + lane;
-        const uint4* W2q = (const uint4*)a.Wp + ((long)wc * NT * 4) * 64 + lane;
+    // One tile per workgroup, 3-4 workgroups per CU: a PERSISTENT form with the fragments of both convolutions resident across tiles was
+    // measured and lost (C = 32: 0.41 / 0.63 / 0.82 ms against 0.33 / 0.53 / 0.64 for k = 3 / 5 / 7) -- the registers it holds across the
+    // row-major epilogue halve the occupancy, and these tiles are bound by their serial phases (fill, conv, epilogue), not by the weight fetch.
+    // conv1's fragments -> registers; conv2's go to a second set when both fit (NT KS <= 24), else they replace conv1's tap by tap.
+    constexpr bool TWO_SETS = (NT * KS <= 24);
+    uint4 w[NT][KS];
+    uint4 w2[TWO_SETS ? NT : 1][TWO_SETS ? KS : 1];
+    const uint4* W1q = (const uint4*)a.Wp2 + ((long)wc * NT * 4) * 64 + lane;
+    const uint4* W2q = (const uint4*)a.Wp + ((long)wc * NT * 4) * 64 + lane;
 #pragma unroll
-        for (int t = 0; t < NT; t++)
+    for (int t = 0; t < NT; t++)
 #pragma unroll
-            for (int kk = 0; kk < KS; kk++) { w[t][kk] = W1q[(t * 4 + kk) * 64]; w2[t][kk] = W2q[(t * 4 + kk) * 64]; }
-    }
+        for (int kk = 0; kk < KS; kk++) {
+            w[t][kk] = W1q[(t * 4 + kk) * 64];
+            if (TWO_SETS) w2[t][kk] = W2q[(t * 4 + kk) * 64];
+        }
     const int koff = (lane >> 5) * 16;
     const int wrow = wr * (BM / WM);
-    const int tbeg = blockIdx.x * chunk, tend = tbeg + chunk < ntiles ? tbeg + chunk : ntiles;
-    bool first = true;
-    for (int tile = tbeg; tile < tend; tile++) {
+    int tile;
+    {   // every XCD walks a contiguous range of tiles (neighbouring tiles share halo rows in its L2)
+        const int nwg = gridDim.x, id = blockIdx.x, q = nwg >> 3, r = nwg & 7, xcd = id & 7;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
+    }
+    {
         const int b = tile / ntm, m0 = (tile - b * ntm) * BMO;
         const int out_len = a.out_len ? a.out_len[b] : a.M;
         const int in_len = a.in_len ? a.in_len[b] : a.in_len_static;
-        if (m0 >= out_len || m0 >= a.M) continue;          // (uniform over the workgroup)
-        if (!first) __syncthreads();                       // the previous tile's epilogue is done with the slab's area (its stage) and with x1
-        first = false;
+        if (tile >= ntiles || m0 >= out_len || m0 >= a.M) return;
         const unsigned short* Xp = (const unsigned short*)a.X + (long)b * a.x_bs;
         {   // slab rows s <-> global row m0 - H2 - H1 + s
             uint4 sv[NIT];
-            int tq = tid;
-            asm volatile("" : "+v"(tq));                   // per-tile address arithmetic stays inside the tile loop
+            const int tq = tid;
 #pragma unroll
             for (int it = 0; it < NIT; it++) {
                 const int c = tq + it * 256;
@@ -1480,6 +1484,10 @@ __global__ __launch_bounds__(256, MINW) void rb2fuse_kernel(const GemmArgs a, co
                     const uint4 xf = *(const uint4*)(rowp + j * 32 * PITCH_ + kk * 32);
                     acc[0][j] = mfma16<F16>(w[t][kk], xf, acc[0][j]);
                 }
+            if (!TWO_SETS) {
+#pragma unroll
+                for (int kk = 0; kk < KS; kk++) w[t][kk] = W2q[(t * 4 + kk) * 64];   // conv2's fragments take the freed registers
+            }
         }
         // ---- lrelu(x1) = lrelu(acc + b1 + x) as 16 bit (x = inverse lrelu of the slab's centre rows), zero outside the sequence (the second
         //      convolution zero-pads ITS input, hifigan.py:68-75).  Same operation order as the unfused launch's epilogue: bias, residual, activation
@@ -1519,7 +1527,7 @@ __global__ __launch_bounds__(256, MINW) void rb2fuse_kernel(const GemmArgs a, co
 #pragma unroll
                 for (int j = 0; j < TM; j++) {
                     const uint4 xf = *(const uint4*)(rowp + j * 32 * PITCH_ + kk * 32);
-                    acc[0][j] = mfma16<F16>(w2[t][kk], xf, acc[0][j]);
+                    acc[0][j] = mfma16<F16>(TWO_SETS ? w2[TWO_SETS ? t : 0][TWO_SETS ? kk : 0] : w[t][kk], xf, acc[0][j]);
                 }
         }
         // (no barrier: the x slab has been dead since the barrier above -- its area becomes the transpose stage; x1 stays readable)
@@ -1539,16 +1547,10 @@ static bool launch_rb2fuse_c(const GemmArgs& a, int h2, hipStream_t stream) {
     if (sb < (size_t)4 * 32 * (32 * 4 + 16)) return false;           // the slab's area doubles as the epilogue's transpose stage
     const size_t lds = sb + (size_t)(BM + 2 * h2) * pitch;
     if (lds > 160 * 1024) return false;
-    // persistent workgroups: as many per CU as LDS and the register budget (MINW waves per SIMD) allow, each walking a contiguous run of tiles
     const int ntm = (a.M + bmo - 1) / bmo, ntiles = ntm * a.nbatch;
-    int per_cu = (int)((size_t)160 * 1024 / lds);
-    if (per_cu > MINW) per_cu = MINW;
-    if (per_cu < 1) per_cu = 1;
-    const int slots = persistent_cus() * per_cu;
-    const int chunk = (ntiles + slots - 1) / slots;
-    const dim3 grid((ntiles + chunk - 1) / chunk);
-    if (a.dtype == DT_F16) { auto kfn = rb2fuse_kernel<C, NT, BM, WM, WN, MINW, true>; if (!lds_opt_in((const void*)kfn)) return false; ZVX_LAUNCH(kfn, grid, dim3(256), lds, stream, a, h2, ntm, ntiles, chunk); }
-    else { auto kfn = rb2fuse_kernel<C, NT, BM, WM, WN, MINW, false>; if (!lds_opt_in((const void*)kfn)) return false; ZVX_LAUNCH(kfn, grid, dim3(256), lds, stream, a, h2, ntm, ntiles, chunk); }
+    const dim3 grid(ntiles);
+    if (a.dtype == DT_F16) { auto kfn = rb2fuse_kernel<C, NT, BM, WM, WN, MINW, true>; if (!lds_opt_in((const void*)kfn)) return false; ZVX_LAUNCH(kfn, grid, dim3(256), lds, stream, a, h2, ntm, ntiles); }
+    else { auto kfn = rb2fuse_kernel<C, NT, BM, WM, WN, MINW, false>; if (!lds_opt_in((const void*)kfn)) return false; ZVX_LAUNCH(kfn, grid, dim3(256), lds, stream, a, h2, ntm, ntiles); }
     return true;
 }
 
@@ -1565,15 +1567,15 @@ int launch_rb2fuse(GemmArgs a, hipStream_t stream) {
         (a.out && a.out_dtype != a.dtype) || (a.accum && (a.lda % 8 || a.accum_dtype != a.dtype)) || a.in_len != a.out_len || a.ldx != a.N) return -1;
     a.halo_l = a.halo_r = h * d1;
     a.fused = 2;
-    // (C = 64, k = 5 / 7: 2 x 20 / 28 fragments do not fit the registers next to the accumulators and the epilogue -- the caller runs those
-    // blocks' convolutions as two launches, which at 3.3-4.5 TB/s of the stage tensor measured as fast as / faster than a fused tile that
-    // re-fetches its weights per 104-184 output rows)
+    // (C = 64, k = 7 -- second dilation 12, 36 halo rows either side, 87 KiB of LDS = one workgroup per CU -- measured 0.72 ms fused
+    // against 0.49 ms as two launches: the caller runs that block's convolutions separately)
     if (a.N == 32) {
         if (a.ntaps == 3 && launch_rb2fuse_c<32, 3, 256, 4, 1, 2>(a, h * d2, stream)) return 30;
         if (a.ntaps == 5 && launch_rb2fuse_c<32, 5, 256, 4, 1, 2>(a, h * d2, stream)) return 30;
         if (a.ntaps == 7 && launch_rb2fuse_c<32, 7, 256, 4, 1, 2>(a, h * d2, stream)) return 30;
     } else {
-        if (a.ntaps == 3 && launch_rb2fuse_c<64, 3, 128, 2, 2, 2>(a, h * d2, stream)) return 31;
+        if (a.ntaps == 3 && launch_rb2fuse_c<64, 3, 256, 2, 2, 2>(a, h * d2, stream)) return 31;
+        if (a.ntaps == 5 && launch_rb2fuse_c<64, 5, 256, 2, 2, 2>(a, h * d2, stream)) return 31;
     }
     return -1;
 }
@@ -1982,7 +1984,7 @@ static const Variant kVariants[] = {
     {"narrowstage_c16", DT_BF16, 256, 16}, {"narrowstage_c8", DT_BF16, 512, 8},      // whole narrow stages in one launch (narrowstage.hip)
     {"conv2d_persist_c32", DT_BF16, 384, 32}, {"conv2d_persist_c64", DT_BF16, 256, 64},   // persistent 3 x 3 convolutions of the speaker encoder (26, 27)
     {"conv2d_s2_c32", DT_BF16, 256, 64}, {"conv2d_s2_c64", DT_BF16, 128, 128},            // ... its stride-2 level transitions (28: + shortcut, 29)
-    {"rb2fuse_bf16_c32", DT_BF16, 256, 32}, {"rb2fuse_bf16_c64", DT_BF16, 128, 64},       // a whole ResBlock2 per launch (30, 31; HiFi-GAN V3)
+    {"rb2fuse_bf16_c32", DT_BF16, 256, 32}, {"rb2fuse_bf16_c64", DT_BF16, 256, 64},       // a whole ResBlock2 per launch (30, 31; HiFi-GAN V3)
 };
 const char* gemm_variant_name(int id) { return kVariants[id].name; }
 int gemm_num_variants() { return (int)(sizeof(kVariants) / sizeof(kVariants[0])); }

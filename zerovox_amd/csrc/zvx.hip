@@ -126,6 +126,7 @@ struct zvx_ctx {
     int voc_f16_stages = -1;               // zvx_set_int("voc_f16_stages", mask): which domains of the generator (bit 0: mel / conv_pre, bit i: upsampling stage i) compute in IEEE half when voc_f16 is on, the others in bf16; -1 (default): all but a 128-channel ResBlock1 stage
     int voc_h16_ok = -1;                   // every contraction weight of the generator has an IEEE-half copy (decided on the first vocoder call)
     int voc_f16 = 1;                       // zvx_set_int("voc_f16", 0): the vocoder's activations / weights / running sum in bf16 instead of IEEE half (A/B; round 5)
+    int dec_y16 = 1;                       // zvx_set_int("dec_y16", 0): the half FFT-block decoder's pre-norm sums in f32 instead of half (A/B; round 6)
     int dec_f16 = 1;                       // zvx_set_int("dec_f16", 0): StyleTTS decoder activations / weights in bf16 instead of IEEE half (A/B)
     int use_attn_f32 = 1;                  // zvx_set_int("attn_f32", 0): the encoder's attention as V^T / score / P.V GEMMs + softmax (A/B)
     int use_flash = 1;                     // zvx_set_int("flash", 0): the decoder's attention as score GEMM + softmax + PV GEMM (A/B)
@@ -638,6 +639,13 @@ void fft_block(zvx_ctx* c, void* x, int dt, int B, int Lmax, const int* len_dev,
     void* P = c->buf("fft.P", (size_t)B * nheads * Lmax * Lp * es);
     void* o = c->buf("fft.o", (size_t)B * Ls * H * es);
     float* y = c->fbuf("fft.y", (size_t)B * Ls * H);
+    // half blocks (the FS2 / SCLN decoder in the 16-bit mode; round 6): the pre-norm sums y = fc(O) + x and y = conv_k1(h) + x leave their GEMMs
+    // as IEEE half through the compile-time decoder epilogue (raw 16-bit residual, ZVX_EPI_DEC) instead of f32 through the run-time one, and the
+    // LayerNorm / SCLN pass reads 2 bytes per element instead of 4: one more rounding at 2^-11 of a value the norm then rescales
+    // (zvx_set_int("dec_y16", 0): f32, A/B)
+    const bool y16 = h16 && c->dec_y16;
+    void* const yv = y16 ? c->buf("fft.y16", (size_t)B * Ls * H * 2) : (void*)y;
+    const int ydt = y16 ? (int)DT_F16 : (int)DT_F32;
     void* hbuf = c->buf("fft.h", (size_t)B * Ls * F * es);
 
     // f32 blocks (phoneme encoder) in bf16 mode: the static-weight GEMMs take bf16 split planes [hi | hi | lo] of their f32 input
@@ -756,14 +764,14 @@ void fft_block(zvx_ctx* c, void* x, int dt, int B, int Lmax, const int* len_dev,
         a.M = Lmax; a.N = H; a.K = H; a.nbatch = B; a.in_len = len_dev; a.out_len = len_dev; if (flat) a.bflat = Ls;
         a.bias = c->pf(w.p + ".bo"); a.bias_mode = 1;
         a.res = x; a.r_bs = (long)Ls * H; a.ldr = H; a.res_mode = 1; a.res_dtype = dt;
-        a.out = y; a.out_dtype = DT_F32; a.o_bs = (long)Ls * H; a.ldo = H;
+        a.out = yv; a.out_dtype = ydt; a.o_bs = (long)Ls * H; a.ldo = H;
         if (split) { if (!fused_f32) split_of((const float*)o, H, xs); as_split(a, xs, H, w.p + ".wo"); }
         c->gemm(a);
     }
-    const double ln_bytes = (double)B * Lmax * H * (4.0 + es);
+    const double ln_bytes = (double)B * Lmax * H * ((y16 ? 2.0 : 4.0) + es);
     c->timed(0, ln_bytes, [&] {
-        if (w.scln) launch_layernorm(y, DT_F32, H, x, dt, H, B, Ls, len_dev, H, 1, 1e-8f, nullptr, nullptr, w.bg, w.bg_bs, nullptr, c->stream);
-        else launch_layernorm(y, DT_F32, H, x, dt, H, B, Ls, len_dev, H, 0, 1e-5f, c->pf(w.p + ".ln1_g"), c->pf(w.p + ".ln1_b"), nullptr, 0, nullptr, c->stream, split ? xs : nullptr, sp16);
+        if (w.scln) launch_layernorm(yv, ydt, H, x, dt, H, B, Ls, len_dev, H, 1, 1e-8f, nullptr, nullptr, w.bg, w.bg_bs, nullptr, c->stream);
+        else launch_layernorm(yv, ydt, H, x, dt, H, B, Ls, len_dev, H, 0, 1e-5f, c->pf(w.p + ".ln1_g"), c->pf(w.p + ".ln1_b"), nullptr, 0, nullptr, c->stream, split ? xs : nullptr, sp16);
     });
     c->sat_scan(x, dt, (long)Ls * H, H, B, Lmax, len_dev, H);
     {   // h = relu(conv_k9(x))                                         fs2.py:198-200
@@ -788,13 +796,13 @@ void fft_block(zvx_ctx* c, void* x, int dt, int B, int Lmax, const int* len_dev,
         set_taps_1d(a, c->ffn_k1, 1);
         a.bias = c->pf(w.p + ".b2"); a.bias_mode = 1;
         a.res = x; a.r_bs = (long)Ls * H; a.ldr = H; a.res_mode = 1; a.res_dtype = dt;
-        a.out = y; a.out_dtype = DT_F32; a.o_bs = (long)Ls * H; a.ldo = H;
+        a.out = yv; a.out_dtype = ydt; a.o_bs = (long)Ls * H; a.ldo = H;
         if (split) as_split(a, c->buf("fft.hs", (size_t)B * Ls * 3 * F * 2), F, w.p + ".w2");
         c->gemm(a);
     }
     c->timed(0, ln_bytes, [&] {
-        if (w.scln) launch_layernorm(y, DT_F32, H, x, dt, H, B, Ls, len_dev, H, 1, 1e-8f, nullptr, nullptr, w.bg + 2 * H, w.bg_bs, w.post_add, c->stream);
-        else launch_layernorm(y, DT_F32, H, x, dt, H, B, Ls, len_dev, H, 0, 1e-5f, c->pf(w.p + ".ln2_g"), c->pf(w.p + ".ln2_b"), nullptr, 0, w.post_add, c->stream, split ? xs : nullptr, sp16);
+        if (w.scln) launch_layernorm(yv, ydt, H, x, dt, H, B, Ls, len_dev, H, 1, 1e-8f, nullptr, nullptr, w.bg + 2 * H, w.bg_bs, w.post_add, c->stream);
+        else launch_layernorm(yv, ydt, H, x, dt, H, B, Ls, len_dev, H, 0, 1e-5f, c->pf(w.p + ".ln2_g"), c->pf(w.p + ".ln2_b"), nullptr, 0, w.post_add, c->stream, split ? xs : nullptr, sp16);
     });
     c->sat_scan(x, dt, (long)Ls * H, H, B, Lmax, len_dev, H);
     if (split && !w.scln) c->fft_xs_ready = x;                                       // the next block on the same buffer finds its input planes in fft.xs
@@ -1955,6 +1963,7 @@ zvx_status zvx_set_int(zvx_ctx* c, const char* key, int64_t value) {
         else if (std::string(key) == "flash") c->use_flash = (int)value;
         else if (std::string(key) == "attn_f32") c->use_attn_f32 = (int)value;
         else if (std::string(key) == "dec_f16") c->dec_f16 = (int)value;
+        else if (std::string(key) == "dec_y16") c->dec_y16 = (int)value;
         else if (std::string(key) == "voc_f16") c->voc_f16 = (int)value;
         else if (std::string(key) == "voc_f16_stages") c->voc_f16_stages = (int)value;
         else if (std::string(key) == "stagefuse") c->use_stagefuse = (int)value;
