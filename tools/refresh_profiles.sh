@@ -47,10 +47,11 @@ if [ "$QUICK" = "extra" ]; then
   python $ROOT/bench.py --decoder fastspeech2 --no-cpu-baseline > $OUT/bench_fs2dec.json 2> $OUT/bench_fs2dec.err
   profile_workload v2 --vocoder v2
   python $ROOT/bench.py --vocoder v2 --no-cpu-baseline > $OUT/bench_v2.json 2> $OUT/bench_v2.err
-  python $ROOT/bench.py --vocoder v2 --set stagefuse=0 --no-cpu-baseline > $OUT/bench_v2_pair_kernels.json 2> $OUT/bench_v2_pair_kernels.err     # A/B (round 5): V2's narrow stages on the per-pair kernels of rounds 1-4
   python $ROOT/bench.py --vocoder v2 --set front_overlap=0 --no-cpu-baseline > $OUT/bench_v2_serial.json 2> $OUT/bench_v2_serial.err
   profile_workload v3 --vocoder v3
   python $ROOT/bench.py --vocoder v3 --no-cpu-baseline > $OUT/bench_v3.json 2> $OUT/bench_v3.err
+  python $ROOT/bench.py --vocoder v3 --set rb2fuse=0 --no-cpu-baseline > $OUT/bench_v3_unfused.json 2> $OUT/bench_v3_unfused.err          # A/B (round 6): every convolution of a ResBlock2 its own launch
+  python $ROOT/bench.py --decoder fastspeech2 --set dec_y16=0 --no-cpu-baseline > $OUT/bench_fs2dec_y32.json 2> $OUT/bench_fs2dec_y32.err  # A/B (round 6): f32 pre-norm sums
   profile_workload b1_t64 --batch 1 --phonemes 64
   python $ROOT/bench.py --batch 1 --phonemes 64 --no-cpu-baseline > $OUT/bench_b1_t64.json 2> $OUT/bench_b1_t64.err
   profile_workload cfg4_b1 --config 4 --batch 1
@@ -62,11 +63,14 @@ profile_workload bench_n1
 trace_only bench_n1_serial --set front_overlap=0
 python $ROOT/bench.py > $OUT/bench_n1.json 2> $OUT/bench_n1.err
 python $ROOT/bench.py --exact-encoder --no-cpu-baseline > $OUT/bench_n1_exact_encoder.json 2> $OUT/bench_n1_exact_encoder.err
-python $ROOT/bench.py --host-out --no-cpu-baseline > $OUT/bench_n1_host_out.json 2> $OUT/bench_n1_host_out.err
+python $ROOT/bench.py --host-out --no-cpu-baseline > $OUT/bench_n1_host_out.json 2> $OUT/bench_n1_host_out.err                       # round 6: ZVX_HOST_ASYNC (pinned slots + copy stream)
+python $ROOT/bench.py --host-out --host-out-sync --no-cpu-baseline > $OUT/bench_n1_host_out_sync.json 2> $OUT/bench_n1_host_out_sync.err   # ... against round 5's form: every call waits for its own copy
+python $ROOT/bench.py --precision f32 --steps 5 --warmup 1 --no-cpu-baseline > $OUT/bench_n1_f32.json 2> $OUT/bench_n1_f32.err            # the reference's arithmetic (exact-f32 MFMA everywhere)
 python $ROOT/bench.py --set front_overlap=0 --no-cpu-baseline > $OUT/bench_n1_serial.json 2> $OUT/bench_n1_serial.err                 # A/B: every call's front end behind the previous vocoder
 python $ROOT/bench.py --set enc_split=1 --no-cpu-baseline > $OUT/bench_n1_bf16_planes.json 2> $OUT/bench_n1_bf16_planes.err          # A/B: the encoder's split products on bf16 planes (rounds 2-3)
 python $ROOT/bench.py --in-flight 2 --no-cpu-baseline > $OUT/bench_n1_in_flight2.json 2> $OUT/bench_n1_in_flight2.err
 python $ROOT/bench.py --set voc_f16=0 --no-cpu-baseline > $OUT/bench_n1_voc_bf16.json 2> $OUT/bench_n1_voc_bf16.err                    # A/B (round 5): the bf16 vocoder kernels of rounds 1-4
+python $ROOT/bench.py --set voc_f16_stages=31 --no-cpu-baseline > $OUT/bench_n1_voc_half.json 2> $OUT/bench_n1_voc_half.err             # A/B (round 6): IEEE half in every stage (round 5's default)
 python $ROOT/bench.py --no-cpu-baseline > $OUT/bench_n1_again.json 2> $OUT/bench_n1_again.err                                         # ... and the default once more right behind it (same box, minutes apart)
 for V in 1 0; do timeout 120 python $ROOT/tools/power_readout.py --what vocoder --voc-f16 $V > $OUT/power_vocoder_f16_$V.txt 2>&1; done   # J per vocoder pass, half against bf16
 timeout 120 python $ROOT/tools/power_readout.py --what step > $OUT/power_step.txt 2>&1
