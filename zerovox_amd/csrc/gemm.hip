@@ -329,6 +329,9 @@ __device__ __forceinline__ f32x2 unpack16x2(unsigned u, bool f16) { return f16 ?
 // ... and (round 5) the mel decoders' residual convolutions: alpha = 1, bias per channel or none, RAW 16-bit residual (res = 1) or none,
 // result x out_scale, no activation, 16-bit output -- (conv2(t) [+ shortcut] [+ x]) / sqrt(2) of a StyleTTS residual block
 #define ZVX_EPI_DEC(res) (16 | 8 | (res))
+// ... and (round 6) "bias + activation -> 16 bit" with the OTHER 16-bit type on the output side: the ConvTranspose in front of a vocoder stage
+// whose arithmetic differs from the previous one's (zvx_set_int "voc_f16_stages"): half in -> bf16 out or bf16 in -> half out
+#define ZVX_EPI_FLIP (ZVX_EPI(0, 0, 1) | 32)
 // H16 (compile-time modes only): the 16-bit tensors are IEEE half and the KERNEL has set MODE.FP16_OVFL (f16_saturate_mode): plain converts
 
 template <int TM, int TN, int RES_LDS = 0, int EPI = -1, bool H16 = false>   // RES_LDS: residual source: 0 global memory, 1 padded LDS slab
@@ -641,7 +644,7 @@ __global__ __launch_bounds__(256, MINW) void convslab_kernel(const GemmArgs a) {
     constexpr int NIT = ((BM + MAXH) * 8 + 255) / 256;    // staging iterations (halo_l + halo_r <= MAXH rows)
     static_assert(WM * WN == 4, "4 waves");
     extern __shared__ __attribute__((aligned(16))) unsigned char slab[];
-    if (F16 && EPI >= 0 && EPI != ZVX_EPI(0, 0, 1)) f16_saturate_mode();   // compile-time half epilogues convert without clamps (mfma_util.h)
+    if (F16 && EPI >= 0 && EPI != ZVX_EPI(0, 0, 1) && EPI != ZVX_EPI_FLIP) f16_saturate_mode();   // compile-time half epilogues convert without clamps (mfma_util.h)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: SGPR arithmetic, scalar branches
     const int wr = wave % WM, wc = wave / WM;
@@ -874,7 +877,9 @@ __global__ __launch_bounds__(256, MINW) void convslab_kernel(const GemmArgs a) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // tail DMAs
     }
     __syncthreads();                             // every wave is done with the slab: its LDS becomes the transpose stage
-    if (EPI == ZVX_EPI(0, 0, 1))
+    if (EPI == ZVX_EPI_FLIP)
+        epilogue_direct<TM, TN, !F16>(a, acc, b, m0 + wr * (BM / WM), n0 + wc * (BN / WN), out_len, lane, slab + wave * (32 * (TN * 64 + 16)));
+    else if (EPI == ZVX_EPI(0, 0, 1))
         epilogue_direct<TM, TN, F16>(a, acc, b, m0 + wr * (BM / WM), n0 + wc * (BN / WN), out_len, lane, slab + wave * (32 * (TN * 64 + 16)));
     else
         epilogue_rows<TM, TN, 0, EPI, (F16 && EPI >= 0)>(a, acc, b, m0 + wr * (BM / WM), n0 + wc * (BN / WN), out_len, lane, slab + wave * (32 * (TN * 32 * 4 + 16)));
@@ -1995,21 +2000,23 @@ static void launch_slab_variant(const GemmArgs& a, dim3 grid, size_t lds, hipStr
     const bool fullk = a.K % SLAB_KC == 0 && a.K2 == 0;            // (a second source rides the partial-chunk variants: its K2 is any multiple of 16)
     // IEEE-half operands: every epilogue of the register-ring tiles (the vocoder's and the decoders' launches); on the other tile shapes the
     // run-time epilogue and the "bias + activation -> 16 bit" one
-    if constexpr (R == 0 || EPI == -1 || EPI == ZVX_EPI(0, 0, 1)) {
+    if constexpr (R == 0 || EPI == -1 || EPI == ZVX_EPI(0, 0, 1) || EPI == ZVX_EPI_FLIP) {
         if (a.dtype == DT_F16) {
             if (fullk) ZVX_LAUNCH((convslab_kernel<BM, BN, WM, WN, true, MINW, R, EPI, 64, true>), grid, dim3(256), lds, stream, a);
-            else ZVX_LAUNCH((convslab_kernel<BM, BN, WM, WN, false, MINW, R, EPI, 64, true>), grid, dim3(256), lds, stream, a);
+            else if constexpr (EPI != ZVX_EPI_FLIP) ZVX_LAUNCH((convslab_kernel<BM, BN, WM, WN, false, MINW, R, EPI, 64, true>), grid, dim3(256), lds, stream, a);
             return;
         }
     }
     if constexpr (EPI < 0 || !(EPI & 16)) {                        // (the decoders' compile-time form exists in half only)
         if (fullk) ZVX_LAUNCH((convslab_kernel<BM, BN, WM, WN, true, MINW, R, EPI>), grid, dim3(256), lds, stream, a);
-        else ZVX_LAUNCH((convslab_kernel<BM, BN, WM, WN, false, MINW, R, EPI>), grid, dim3(256), lds, stream, a);
+        else if constexpr (EPI != ZVX_EPI_FLIP) ZVX_LAUNCH((convslab_kernel<BM, BN, WM, WN, false, MINW, R, EPI>), grid, dim3(256), lds, stream, a);   // (the flipped-output form: whole K chunks only, epi_mode_of)
     }
 }
 
 // compile-time epilogue mode of a launch (see ZVX_EPI / ZVX_EPI_DEC), or -1 when it needs the run-time epilogue
 static int epi_mode_of(const GemmArgs& a) {
+    if (a.alpha == 1.f && !a.post_scale && a.out && a.out_dtype != a.dtype && a.dtype != DT_F32 && a.out_dtype != DT_F32 && !a.out_split3 && a.bias_mode == 1 && a.bias &&
+        (a.act == ACT_NONE || a.act == ACT_LRELU) && !a.res_mode && !(a.accum && a.accum_mode) && a.out_scale == 1.f && a.K % SLAB_KC == 0 && !a.K2) return ZVX_EPI_FLIP;
     if (a.alpha != 1.f || a.post_scale || (a.out && a.out_dtype != a.dtype) || a.dtype == DT_F32 || a.out_split3 || a.bias_mode == 2) return -1;
     const int am = a.accum ? a.accum_mode : 0;
     // the mel decoders' residual form (half only): (conv [+ raw residual]) x out_scale, no activation, 16-bit output
@@ -2219,6 +2226,7 @@ static int launch_convslab(GemmArgs a, hipStream_t stream) {
         case 0: launch_slab_variant<128, 256, 1, 4, 2, 0>(a, grid, lds, stream); break;      // (register-ring variant)
         case 1: switch (epi_mode_of(a)) {                   // (always the register-ring variant: wreg)
                     case ZVX_EPI(0, 0, 1): launch_slab_variant<256, 128, 2, 2, 2, 0, ZVX_EPI(0, 0, 1)>(a, grid, lds, stream); break;
+                    case ZVX_EPI_FLIP: launch_slab_variant<256, 128, 2, 2, 2, 0, ZVX_EPI_FLIP>(a, grid, lds, stream); break;
                     case ZVX_EPI(1, 0, 1): launch_slab_variant<256, 128, 2, 2, 2, 0, ZVX_EPI(1, 0, 1)>(a, grid, lds, stream); break;
                     case ZVX_EPI(1, 2, 0): launch_slab_variant<256, 128, 2, 2, 2, 0, ZVX_EPI(1, 2, 0)>(a, grid, lds, stream); break;
                     case ZVX_EPI(1, 3, 0): launch_slab_variant<256, 128, 2, 2, 2, 0, ZVX_EPI(1, 3, 0)>(a, grid, lds, stream); break;
