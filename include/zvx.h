@@ -80,7 +80,7 @@ int64_t    zvx_get_int(const zvx_ctx* ctx, const char* key);
  * the reference has none, fs2.py:678-681 -- a garbage log-duration must not drive an allocation -> ZVX_E_BUFFER).
  * "f16_sat_check" 0/1: the saturation audit of the half mode (see zvx_get_int "f16_sat_events"); setting it (re)zeroes the counter.
  * Every other key is an A/B switch of a scheduling / tiling / arithmetic choice (INTEGRATION.md has the table: "enc_split",
- * "front_overlap", "front_prio", "dec_flat", "dec_sc_fuse", "dec_f16", "voc_f16", "stagefuse", "pairstream", "resstream", "slab_small", "slab_flat",
+ * "front_overlap", "front_prio", "dec_flat", "dec_sc_fuse", "dec_f16", "dec_y16", "voc_f16", "voc_f16_stages", "stagefuse", "rb2fuse", "pairstream", "resstream", "slab_small", "slab_flat",
  * "poison_pads", "spk_pool_fuse", "spk_s2_fuse", ...);
  * all of them live in the context.  Unknown keys: ZVX_E_INVALID. */
 zvx_status zvx_set_int(zvx_ctx* ctx, const char* key, int64_t value);
@@ -126,9 +126,11 @@ zvx_status zvx_decode_features(zvx_ctx* ctx, const float* features, const int32_
 zvx_status zvx_vocode(zvx_ctx* ctx, const int32_t* pad_to, void* wav, int64_t wav_stride, int flags);
 
 /* Stand-alone vocoder: mel [B][Pmax][n_mels], P[B] frames -> wav rows of P[b]*hop samples.
- * Arithmetic of the 16-bit mode (round 5): weights, activations and the running sum of the generator are IEEE half on the f16 MFMA;
- * every 16-bit store SATURATES at +-65504 (MODE.FP16_OVFL in the kernels) -- a mel scaled far past the trained range gives a finite,
- * clipped waveform, never Inf / NaN (zvx_set_int "voc_f16" 0: the bf16 kernels of rounds 1-4).
+ * Arithmetic of the 16-bit mode: weights, activations and the running sum of the generator are IEEE half on the f16 MFMA (round 5) in
+ * every stage but a ResBlock1 stage of 128 channels, which computes in bf16 (round 6; zvx_set_int "voc_f16_stages": a mask of the stages
+ * in half, "voc_f16" 0: the bf16 kernels of rounds 1-4 everywhere).  Every half store SATURATES at +-65504 (MODE.FP16_OVFL in the
+ * kernels) -- a mel scaled far past the trained range gives a finite, clipped waveform, never Inf / NaN; whether a clamp ever engaged on
+ * given weights and inputs: zvx_set_int "f16_sat_check" / zvx_get_int "f16_sat_events".
  * Non-finite input (NaN / Inf in a mel): the call succeeds and nothing faults; the samples of THAT utterance are unspecified (finite or
  * not -- the leaky-relu forms are compiled without NaN propagation guarantees); every other utterance of the batch and every later call
  * are bit for bit what they are without it.  The reference would propagate the NaN through that utterance as well. */

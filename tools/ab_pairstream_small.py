@@ -10,7 +10,7 @@ for B, P in ((1, 1024), (1, 448), (2, 896), (4, 896), (8, 896), (16, 896)):
     mel = np.random.default_rng(7).standard_normal((B, P, 80)).astype(np.float32)
     mel_d = ctx.dev_alloc(mel.nbytes); ctx.dev_from_host(mel_d, mel); wav_d = ctx.dev_alloc(B * P * 256 * 4)
     Pn = np.full(B, P, np.int32)
-    for mode in (0, 1):
+    for mode in (-1, 1):
         ctx.set_int("pairstream", mode)
         for _ in range(5): ctx.vocode_mel_device(mel_d, Pn, P, wav_d, P * 256, no_sync=True)
         ctx.sync(); t0 = time.perf_counter()
