@@ -202,7 +202,8 @@ __global__ void k_layernorm(const void* x, int xdt, int ldx, void* y, int ydt, i
         return;
     }
     const long xo = ((long)b * rows_max + r) * ldx, yo = ((long)b * rows_max + r) * ldy;
-    if (ydt != DT_F32 && !planes && (C & 7) == 0 && C <= 1024 && (ldx & 7) == 0 && (ldy & 7) == 0) {
+    if ((C & 7) == 0 && C <= 1024 && (ldx & 7) == 0 && (ldy & 7) == 0) {
+        // (round 6: every output form takes this path -- the phoneme encoder's f32 rows + 16-bit split planes and the variance predictors' f32 rows too)
         // 16-bit output rows (the FFT-block decoder's 12 LayerNorm / SCLN passes per call, f32 or 16-bit in): the row is read ONCE, as
         // 16-byte vectors (8 elements per lane and round, one or two rounds), and stays in registers for the mean, the centred second
         // moment and the affine -- the element-wise form below reads it three times, element by element: 52 us for 28672 x 528 (1.7 TB/s)
@@ -244,7 +245,20 @@ __global__ void k_layernorm(const void* x, int xdt, int ldx, void* y, int ydt, i
                 const float4 p0 = *(const float4*)(post_add + (long)b * C + c), p1 = *(const float4*)(post_add + (long)b * C + c + 4);
                 o[0] += p0.x; o[1] += p0.y; o[2] += p0.z; o[3] += p0.w; o[4] += p1.x; o[5] += p1.y; o[6] += p1.z; o[7] += p1.w;
             }
-            *(uint4*)((unsigned short*)y + yo + c) = pack8(o, ydt);
+            if (ydt != DT_F32) *(uint4*)((unsigned short*)y + yo + c) = pack8(o, ydt);
+            else {
+                *(float4*)((float*)y + yo + c) = make_float4(o[0], o[1], o[2], o[3]);
+                *(float4*)((float*)y + yo + c + 4) = make_float4(o[4], o[5], o[6], o[7]);
+            }
+            if (planes) {                                    // [hi | hi | lo] of the result: the next split-product GEMM's operand (what k_split3 would write)
+                unsigned short hh[8], ll[8];
+#pragma unroll
+                for (int e = 0; e < 8; e++) split2x(o[e], planes_f16, hh[e], ll[e]);
+                const uint4 hv = make_uint4(hh[0] | ((unsigned)hh[1] << 16), hh[2] | ((unsigned)hh[3] << 16), hh[4] | ((unsigned)hh[5] << 16), hh[6] | ((unsigned)hh[7] << 16));
+                const uint4 lv = make_uint4(ll[0] | ((unsigned)ll[1] << 16), ll[2] | ((unsigned)ll[3] << 16), ll[4] | ((unsigned)ll[5] << 16), ll[6] | ((unsigned)ll[7] << 16));
+                unsigned short* po = planes + ((long)b * rows_max + r) * 3 * C + c;
+                *(uint4*)po = hv; *(uint4*)(po + C) = hv; *(uint4*)(po + 2 * C) = lv;
+            }
         }
         return;
     }
