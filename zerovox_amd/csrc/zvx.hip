@@ -126,6 +126,7 @@ struct zvx_ctx {
     int voc_f16_stages = -1;               // zvx_set_int("voc_f16_stages", mask): which domains of the generator (bit 0: mel / conv_pre, bit i: upsampling stage i) compute in IEEE half when voc_f16 is on, the others in bf16; -1 (default): all but a 128-channel ResBlock1 stage
     int voc_h16_ok = -1;                   // every contraction weight of the generator has an IEEE-half copy (decided on the first vocoder call)
     int voc_f16 = 1;                       // zvx_set_int("voc_f16", 0): the vocoder's activations / weights / running sum in bf16 instead of IEEE half (A/B; round 5)
+    int dec_qkv = 1;                       // zvx_set_int("dec_qkv", 0): the half FFT-block decoder's Q | K and V projections as two launches (A/B; round 6)
     int dec_y16 = 1;                       // zvx_set_int("dec_y16", 0): the half FFT-block decoder's pre-norm sums in f32 instead of half (A/B; round 6)
     int dec_f16 = 1;                       // zvx_set_int("dec_f16", 0): StyleTTS decoder activations / weights in bf16 instead of IEEE half (A/B)
     int use_attn_f32 = 1;                  // zvx_set_int("attn_f32", 0): the encoder's attention as V^T / score / P.V GEMMs + softmax (A/B)
@@ -579,6 +580,37 @@ void upload_weights(zvx_ctx* c) {
         }
         for (auto& kv : add) c->tensors[kv.first] = kv.second;
     }
+    // half FFT blocks (the FS2 / SCLN decoder in the 16-bit mode): Q, K and V projections as ONE GEMM too (round 6) -- [Wq; Wk; Wv] in IEEE half,
+    // fragment-packed, and the concatenated f32 biases
+    {
+        std::vector<std::pair<std::string, Tensor>> add;
+        for (auto& kv : c->tensors) {
+            const std::string& nm = kv.first;
+            const std::string sfx = ".wqk.h16";
+            if (nm.size() <= sfx.size() || nm.compare(nm.size() - sfx.size(), sfx.size(), sfx) != 0) continue;
+            const std::string pre = nm.substr(0, nm.size() - sfx.size());
+            if (!c->has(pre + ".wv.h16") || !c->has(pre + ".bqk") || !c->has(pre + ".bv")) continue;
+            const Tensor& wqk = kv.second; const Tensor& wv = c->t(pre + ".wv.h16");
+            if (wqk.dims.size() != 3 || wv.dims.size() != 3 || wqk.dim(0) != 1 || wv.dim(0) != 1 || wv.dim(2) != wqk.dim(2) || wqk.dim(2) % 8) continue;
+            Tensor w = wqk; w.dims = {1, wqk.dim(1) + wv.dim(1), wqk.dim(2)}; w.numel = wqk.numel + wv.numel; w.host = nullptr;
+            w.dev = c->buf(pre + ".wqkv.h16", w.numel * 2);
+            HIPCHK(hipMemcpyAsync(w.dev, wqk.dev, wqk.numel * 2, hipMemcpyDeviceToDevice, c->stream));
+            HIPCHK(hipMemcpyAsync((char*)w.dev + wqk.numel * 2, wv.dev, wv.numel * 2, hipMemcpyDeviceToDevice, c->stream));
+            void* pk = c->buf(pre + ".wqkv.h16.packed", packed_weight_elems(1, w.dim(1), w.dim(2)) * 2);
+            launch_pack_weights(w.dev, 1, w.dim(1), w.dim(2), pk, c->stream);
+            c->packed[w.dev] = pk;
+            add.emplace_back(pre + ".wqkv.h16", w);
+            if (!c->has(pre + ".bqkv")) {
+                const Tensor& bqk = c->t(pre + ".bqk"); const Tensor& bv = c->t(pre + ".bv");
+                Tensor bb = bqk; bb.dims = {(int)(bqk.numel + bv.numel)}; bb.numel = bqk.numel + bv.numel; bb.host = nullptr;
+                bb.dev = c->buf(pre + ".bqkv", bb.numel * 4);
+                HIPCHK(hipMemcpyAsync(bb.dev, bqk.dev, bqk.numel * 4, hipMemcpyDeviceToDevice, c->stream));
+                HIPCHK(hipMemcpyAsync((float*)bb.dev + bqk.numel, bv.dev, bv.numel * 4, hipMemcpyDeviceToDevice, c->stream));
+                add.emplace_back(pre + ".bqkv", bb);
+            }
+        }
+        for (auto& kv : add) c->tensors[kv.first] = kv.second;
+    }
     if (c->enc_split) build_split_weights(c, c->enc_split == 2);
     HIPCHK(hipStreamSynchronize(c->stream));
     DevBuf& st = c->bufs["weights_staging"];
@@ -688,6 +720,17 @@ void fft_block(zvx_ctx* c, void* x, int dt, int B, int Lmax, const int* len_dev,
         c->timed(4.0 * B * nheads * (double)Lmax * Lmax * d, (double)B * Lmax * 4.0 * H * 4, [&] { launch_attention_f32(af, c->stream, false); });
     } else {
     if (split) split_of((const float*)x, H, xs);
+    const bool qkv16 = h16 && c->dec_qkv && c->has(w.p + ".wqkv.h16") && c->has(w.p + ".bqkv");
+    void* qkvbuf = qkv16 ? c->buf("fft.qkv16", (size_t)B * Ls * 3 * H * es) : nullptr;
+    if (qkv16) {   // half blocks: [Q | K | V] = x [Wq; Wk; Wv]^T + b in ONE launch (round 6), then the 16-bit transpose of its V columns
+        GemmArgs a = gemm_base(dt);
+        a.X = x; a.x_bs = (long)Ls * H; a.ldx = H; a.W = c->t(w.p + ".wqkv.h16").dev; a.ldw = H;
+        a.M = Lmax; a.N = 3 * H; a.K = H; a.nbatch = B; a.in_len = len_dev; a.out_len = len_dev; if (flat) a.bflat = Ls;
+        a.bias = c->pf(w.p + ".bqkv"); a.bias_mode = 1;
+        a.out = qkvbuf; a.o_bs = (long)Ls * 3 * H; a.ldo = 3 * H;
+        c->gemm(a);
+        c->timed(0, (double)B * Lmax * H * 4.0, [&] { launch_transpose16((const char*)qkvbuf + (size_t)2 * H * es, 3 * H, vt, Lp, B, Ls, H, c->stream, len_dev); });
+    } else
     {   // [Q | K] = x Wqk^T + b                                       fs2.py:143-144
         GemmArgs a = gemm_base(dt);
         a.X = x; a.x_bs = (long)Ls * H; a.ldx = H; a.W = wdev(".wqk"); a.ldw = H;
@@ -697,7 +740,8 @@ void fft_block(zvx_ctx* c, void* x, int dt, int B, int Lmax, const int* len_dev,
         a.out = qk; a.o_bs = (long)Ls * 2 * H; a.ldo = 2 * H;
         c->gemm(a);
     }
-    if (h16) {   // half: V = x Wv^T + b on the conv-slab kernel (static weights), then one 16-bit transpose to the key-contiguous layout
+    if (qkv16) {
+    } else if (h16) {   // half: V = x Wv^T + b on the conv-slab kernel (static weights), then one 16-bit transpose to the key-contiguous layout
         void* vrow = hbuf;                                                       // [B][Lmax][H]: the FFN buffer is idle here
         GemmArgs a = gemm_base(dt);
         a.X = x; a.x_bs = (long)Ls * H; a.ldx = H; a.W = wdev(".wv"); a.ldw = H;
@@ -725,7 +769,8 @@ void fft_block(zvx_ctx* c, void* x, int dt, int B, int Lmax, const int* len_dev,
     }
     FlashArgs fa;
     memset(&fa, 0, sizeof fa);
-    fa.qk = qk; fa.qk_bs = (long)Ls * 2 * H; fa.ldq = 2 * H; fa.k_off = H; fa.vt = vt; fa.vt_bs = (long)H * Lp; fa.ldv = Lp;
+    fa.qk = qk; fa.qk_bs = (long)Ls * 2 * H; fa.ldq = 2 * H; fa.k_off = H; fa.vt = vt;
+    if (qkv16) { fa.qk = qkvbuf; fa.qk_bs = (long)Ls * 3 * H; fa.ldq = 3 * H; } fa.vt_bs = (long)H * Lp; fa.ldv = Lp;
     fa.out = o; fa.o_bs = (long)Ls * H; fa.ldo = H; fa.len = len_dev; fa.L = Lmax; fa.D = d; fa.nheads = nheads; fa.nbatch = B;
     fa.scale = (float)(1.0 / pow((double)d, 0.5));
     fa.f16 = h16;
@@ -1964,6 +2009,7 @@ zvx_status zvx_set_int(zvx_ctx* c, const char* key, int64_t value) {
         else if (std::string(key) == "attn_f32") c->use_attn_f32 = (int)value;
         else if (std::string(key) == "dec_f16") c->dec_f16 = (int)value;
         else if (std::string(key) == "dec_y16") c->dec_y16 = (int)value;
+        else if (std::string(key) == "dec_qkv") c->dec_qkv = (int)value;
         else if (std::string(key) == "voc_f16") c->voc_f16 = (int)value;
         else if (std::string(key) == "voc_f16_stages") c->voc_f16_stages = (int)value;
         else if (std::string(key) == "stagefuse") c->use_stagefuse = (int)value;
