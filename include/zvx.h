@@ -80,7 +80,7 @@ int64_t    zvx_get_int(const zvx_ctx* ctx, const char* key);
  * the reference has none, fs2.py:678-681 -- a garbage log-duration must not drive an allocation -> ZVX_E_BUFFER).
  * "f16_sat_check" 0/1: the saturation audit of the half mode (see zvx_get_int "f16_sat_events"); setting it (re)zeroes the counter.
  * Every other key is an A/B switch of a scheduling / tiling / arithmetic choice (INTEGRATION.md has the table: "enc_split",
- * "front_overlap", "front_prio", "dec_flat", "dec_sc_fuse", "dec_f16", "dec_y16", "voc_f16", "voc_f16_stages", "stagefuse", "rb2fuse", "pairstream", "resstream", "slab_small", "slab_flat",
+ * "front_overlap", "front_prio", "dec_flat", "dec_sc_fuse", "dec_f16", "dec_y16", "dec_qkv", "voc_f16", "voc_f16_stages", "stagefuse", "rb2fuse", "pairstream", "resstream", "slab_small", "slab_flat",
  * "poison_pads", "spk_pool_fuse", "spk_s2_fuse", ...);
  * all of them live in the context.  Unknown keys: ZVX_E_INVALID. */
 zvx_status zvx_set_int(zvx_ctx* ctx, const char* key, int64_t value);

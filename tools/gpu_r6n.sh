@@ -4,6 +4,6 @@ set -u
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/r6n; mkdir -p $OUT; rm -f $OUT/*
 cd $ROOT
-bash tools/refresh_profiles.sh r06c > $OUT/refresh.log 2>&1
-bash tools/refresh_profiles.sh r06c extra > $OUT/refresh_extra.log 2>&1
-ls $ROOT/gpurun_out/prof_r06c | wc -l
+bash tools/refresh_profiles.sh r06d > $OUT/refresh.log 2>&1
+bash tools/refresh_profiles.sh r06d extra > $OUT/refresh_extra.log 2>&1
+ls $ROOT/gpurun_out/prof_r06d | wc -l
