@@ -1180,10 +1180,13 @@ static void launch_conv2d_persist(const GemmArgs& a, hipStream_t stream) {
     (void)lds_opt_in((const void*)conv2d_persist_kernel<C, BM, WM, WN, MAXH, 0, WGPC>);        // (per device; a refusal shows up as the launch's own error)
     (void)lds_opt_in((const void*)conv2d_persist_kernel<C, BM, WM, WN, MAXH, 1, WGPC>);
     if (a.post_scale) ZVX_LAUNCH((conv2d_persist_kernel<C, BM, WM, WN, MAXH, 1, WGPC>), dim3(G), dim3(WM * WN * 64), lds, stream, a, ntm, ntiles);
-    else if (a.se_part && a.se_part_S && (C == 32 || (a.slab_small & 512))) {      // (C = 64: the pool costs the 8-wave kernel 18-50 spilled registers: off unless slab_small bit 9, A/B)
-        (void)lds_opt_in((const void*)conv2d_persist_kernel<C, BM, WM, WN, MAXH, 0, WGPC, true>);
-        ZVX_LAUNCH((conv2d_persist_kernel<C, BM, WM, WN, MAXH, 0, WGPC, true>), dim3(G), dim3(WM * WN * 64), lds, stream, a, ntm, ntiles);
-        if (!g_dry_run) *a.se_part_S = ntm * WM;                         // tells the caller that (and in how many partials) the pool was written
+    else if (C == 32 && a.se_part && a.se_part_S) {
+        // (C = 64: the fused pool cost the 8-wave kernel 12-50 spilled registers and measured slower; that instantiation is gone -- round 6)
+        if constexpr (C == 32) {
+            (void)lds_opt_in((const void*)conv2d_persist_kernel<C, BM, WM, WN, MAXH, 0, WGPC, true>);
+            ZVX_LAUNCH((conv2d_persist_kernel<C, BM, WM, WN, MAXH, 0, WGPC, true>), dim3(G), dim3(WM * WN * 64), lds, stream, a, ntm, ntiles);
+            if (!g_dry_run) *a.se_part_S = ntm * WM;                         // tells the caller that (and in how many partials) the pool was written
+        }
     } else ZVX_LAUNCH((conv2d_persist_kernel<C, BM, WM, WN, MAXH, 0, WGPC>), dim3(G), dim3(WM * WN * 64), lds, stream, a, ntm, ntiles);
 }
 
