@@ -1380,6 +1380,17 @@ def test_asynchronous_host_delivery_equals_the_synchronous_call():
         assert np.array_equal(got[i], refs[i]["wav"][:, :n]), i
     with pytest.raises(_lib.ZvxError):
         ctx.synthesize(*cases[0], None, want_mel=True, host_async=True)
+    # predicted durations (the call waits once, for the mel lengths; the waveform still travels asynchronously) and the stand-alone vocoder
+    ph, pu, Tl, spk, dur = cases[0]
+    ref_p = ctx.synthesize(ph, pu, Tl, spk, None, None, want_mel=False, Lmax_cap=400)
+    rp = ctx.synthesize(ph, pu, Tl, spk, None, None, want_mel=False, Lmax_cap=400, host_async=True)
+    assert np.array_equal(rp["mel_len"], ref_p["mel_len"])
+    n_p = int(ref_p["mel_len"].max()) * 256
+    assert np.array_equal(ctx.wait_host(rp["slot"]), ref_p["wav"][:, :n_p])
+    rng = np.random.default_rng(5)
+    vm = rng.standard_normal((2, 30, 80)).astype(np.float32); vP = np.array([30, 11], np.int32)
+    ref_v = ctx.vocode_mel(vm, vP)
+    assert np.array_equal(ctx.wait_host(ctx.vocode_mel(vm, vP, host_async=True)), ref_v)
     # the staged API and a synchronous call between two queued ones
     r = ctx.synthesize(*cases[1], None, want_mel=False, host_async=True)
     mid = ctx.synthesize(*cases[2], None, want_mel=False)

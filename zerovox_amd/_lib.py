@@ -207,11 +207,15 @@ class Context:
         self._chk(self._lib.zvx_vocode(self._h, _ptr(pt), _ptr(wav), n, ZVX_PCM16 if pcm16 else 0))
         return wav
 
-    def vocode_mel(self, mel, P, pcm16=False):
+    def vocode_mel(self, mel, P, pcm16=False, host_async=False):
+        """host_async: the call only queues work and returns the pinned host slot (wait_host(slot) hands out the rows)."""
         mel = _f32(mel)
         B, Pmax, nm = mel.shape
         assert nm == self.n_mels
         P = _i32(P, (B,))
+        if host_async:
+            self._chk(self._lib.zvx_vocode_mel(self._h, _ptr(mel), _ptr(P), B, Pmax, None, 0, ZVX_HOST_ASYNC | (ZVX_PCM16 if pcm16 else 0)))
+            return self.get_int("host_slot")
         n = int(P.max()) * self.hop
         wav = np.empty((B, n), np.int16 if pcm16 else np.float32)
         self._chk(self._lib.zvx_vocode_mel(self._h, _ptr(mel), _ptr(P), B, Pmax, _ptr(wav), n, ZVX_PCM16 if pcm16 else 0))
